@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (K1 rank statistics + K2 p-values + K3 window
+combine) over one rank's shard of the synthetic genome, inputs resident in HBM.
+Workload at N=1: BASELINE.json configs[1] — E. coli 4.6 Mb, 200 v 200 reads/position,
+KS + weighted Stouffer (window 5), float32 signals.  For N>1 every rank owns 4.6 M
+positions of an N x 4.6 M position genome (weak scaling), computes them with a
++-nb halo, and the per-base p-value tracks are reassembled with an RCCL all-gather.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+P_ECOLI = 4_600_000
+N0 = N1 = 200
+NB = 2
+WDIF = 2.0
+SEED = 20240601
+PLANT_PERIOD = 10000
+PLANT_SHIFT = 0.8
+# s*(n0+n1) + 16 (CSR offsets) + 4 (run id) + 16*k_out + 8 (own-p re-read) = 1660 B
+ALGO_BYTES_PER_POS = 4 * (N0 + N1) + 16 + 4 + 16 * 2 + 8
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(sample_positions, threads):
+    """The oracle timed on this box's host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import numpy as np
+    from helpers import synth_ref
+    a = synth_ref(SEED, 0, sample_positions, 0, N0, PLANT_PERIOD, PLANT_SHIFT)
+    b = synth_ref(SEED, 0, sample_positions, 1, N1, PLANT_PERIOD, PLANT_SHIFT)
+    off0 = np.arange(0, (sample_positions + 1) * N0, N0, dtype=np.int64)
+    off1 = np.arange(0, (sample_positions + 1) * N1, N1, dtype=np.int64)
+    rid = np.zeros(sample_positions, np.int32)
+    try:
+        import oracle_c
+        t0 = time.perf_counter()
+        oracle_c.detect_batch(a, off0, b, off1, rid, NB, WDIF, 'stouffer', tests=1, threads=threads)
+        dt = time.perf_counter() - t0
+        kind_note = 'oracle/nanomod_oracle.c (C restatement, OpenMP)'
+        cores = threads
+    except ImportError:
+        import nanomod_oracle as orc
+        t0 = time.perf_counter()
+        for i in range(sample_positions):
+            orc.ks_2samp(a[off0[i]:off0[i + 1]], b[off1[i]:off1[i + 1]])
+        dt = time.perf_counter() - t0
+        kind_note = 'oracle/nanomod_oracle.py (numpy + scipy.special restatement, KS only)'
+        cores = 1
+    return {'value': sample_positions / dt, 'unit': 'positions/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d positions of the same 200 v 200 workload, %s, %.1f s' % (sample_positions, kind_note, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--positions', type=int, default=P_ECOLI, help='positions per GPU (default: E. coli 4.6 M)')
+    ap.add_argument('--cpu-sample', type=int, default=0, help='positions for the CPU baseline (0 = auto)')
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import nanomod_amd as nm
+    from nanomod_amd import sharding
+    L = nm._lib
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run' % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = 'cuda:%d' % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device(dev))
+
+    P = args.positions
+    total_positions = P * world
+    lo, hi = rank * P, (rank + 1) * P
+    lo_h, hi_h = sharding.halo_bounds(lo, hi, NB, total_positions)
+    n_local = hi_h - lo_h
+
+    det = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method='stouffer', tests=L.TEST_KS)
+    sig0 = torch.empty(n_local * N0, dtype=torch.float32, device=dev)
+    sig1 = torch.empty(n_local * N1, dtype=torch.float32, device=dev)
+    det.synth_fill(sig0, SEED, lo_h, n_local, 0, N0, PLANT_PERIOD, PLANT_SHIFT)
+    det.synth_fill(sig1, SEED, lo_h, n_local, 1, N1, PLANT_PERIOD, PLANT_SHIFT)
+    rid = torch.zeros(n_local, dtype=torch.int32, device=dev)       # one contiguous run
+    out = det.alloc_outputs(n_local)
+    gathered = None
+    if world > 1:
+        gathered = {k: torch.empty(total_positions, dtype=torch.float64, device=dev) for k in ('ks_p', 'comb_p')}
+
+    def step():
+        res = det.run(sig0, sig1, rid, stride0=N0, stride1=N1, npos=n_local, out=out)
+        if world > 1:
+            for k in ('ks_p', 'comb_p'):
+                dist.all_gather_into_tensor(gathered[k], res[k][lo - lo_h: lo - lo_h + P])
+        return res
+
+    for _ in range(args.warmup):
+        step()
+    timer = nm.EventTimer(max(args.steps, 1) + 8)
+    det.timer = timer
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    det.timer = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    k1_ms, k1_n = timer.read(L.KERNEL_RANK_STATS)
+    k2_ms, _ = timer.read(L.KERNEL_FINALIZE)
+    k3_ms, _ = timer.read(L.KERNEL_COMBINE)
+    if rank == 0:
+        value = total_positions * args.steps / elapsed
+        k1_avg_s = (k1_ms / max(k1_n, 1)) * 1e-3
+        achieved = ALGO_BYTES_PER_POS * n_local / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
+        line = {
+            'metric': 'genomic positions/sec (KS + Stouffer)', 'value': value, 'unit': 'positions/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32 keys / f64 p-values', 'data': 'synthetic',
+            'config': {'workload': 'E. coli 4.6 Mb x %d: %d positions/GPU, %d v %d reads/position, KS + weighted '
+                                   'Stouffer window=%d (BASELINE.json configs[1])' % (world, P, N0, N1, 2 * NB + 1),
+                       'positions_per_gpu': P, 'n0': N0, 'n1': N1, 'neighborPvalues': NB, 'WeightsDif': WDIF,
+                       'parallelism': 'position-sharded x%d, +-%d halo, RCCL all-gather of ks_p/comb_p' % (world, NB)},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'rank_stats_kernel<4,4,f32,KS>', 'kernel_avg_ms': k1_avg_s * 1e3,
+                         'algorithmic_bytes_per_position': ALGO_BYTES_PER_POS,
+                         'other_kernels_avg_ms': {'finalize': k2_ms / max(k1_n, 1), 'combine': k3_ms / max(k1_n, 1)}},
+        }
+        if not args.no_cpu:
+            threads = os.cpu_count() or 1
+            sample = args.cpu_sample or 4000
+            line['cpu_baseline'] = cpu_baseline(sample, threads)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

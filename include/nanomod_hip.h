@@ -1,0 +1,155 @@
+/* nanomod_hip.h — C ABI of the MI355X (gfx950) implementation of NanoMod's
+ * per-base two-sample testing hot path.
+ *
+ * The reference (WGLab/NanoMod) has no FFI / plugin layer: its boundary for
+ * this path is the Python function level of bin/scripts/myDetect.py
+ * (SURVEY.md §8b).  Each entry point below names the reference lines it
+ * replaces.  Plain pointers and sizes only; no exceptions cross the ABI; the
+ * library keeps no global mutable state and never retains caller buffers.
+ *
+ * Data layout: the tested positions, in the
+ * reference's iteration order (sorted (chrom,strand), then ascending
+ * position, myDetect.py:421,427-431), are rows of two CSR arrays
+ *     sig0[off0[i] .. off0[i+1])   samples of group 1 (--wrkBase1) at position i
+ *     sig1[off1[i] .. off1[i+1])   samples of group 2 (--wrkBase2)
+ * plus run_id[i]: equal ids <=> same chrom, same strand and consecutive
+ * positions (restates pos_check, myDetect.py:366-371).
+ */
+#ifndef NANOMOD_HIP_H
+#define NANOMOD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMOD_ABI_VERSION 1
+
+/* sample dtype of sig0 / sig1 */
+enum {
+  NMOD_DTYPE_F32 = 0,       /* canonical: float32 (values up-cast exactly to the fp64 the reference sees) */
+  NMOD_DTYPE_I16_MILLI = 1  /* int16 = round(norm_mean*1000): NanoMod's Events are 3-dp rounded
+                               (myRefBaseSignalAnnotation.py:1108); value = k/1000.0 in fp64 */
+};
+
+/* where the caller's buffers live */
+enum { NMOD_MEM_HOST = 0, NMOD_MEM_DEVICE = 1 };
+
+/* --testMethod (NanoMod.py:359; consumed at myDetect.py:392,395,443) */
+enum { NMOD_METHOD_KS = 0, NMOD_METHOD_STOUFFER = 1, NMOD_METHOD_FISHER = 2 };
+
+/* which per-position tests to compute.  The reference always computes all
+ * three (myDetect.py:331-343); the mask exists for the KS+combine benchmark
+ * configuration of BASELINE.json. */
+enum { NMOD_TEST_KS = 1, NMOD_TEST_MWU = 2, NMOD_TEST_WELCH = 4, NMOD_TEST_ALL = 7 };
+
+/* per-position status bits (data-dependent conditions that make the
+ * reference raise or return NaN; reported instead of aborting) */
+enum {
+  NMOD_STATUS_MWU_ALL_IDENTICAL = 1, /* scipy 1.2.1 mannwhitneyu raises ValueError (T == 0), uncaught at myDetect.py:331 */
+  NMOD_STATUS_T_NAN = 2,             /* zero variance in both groups: ttest_ind returns (nan, nan), myDetect.py:335 */
+  NMOD_STATUS_EMPTY = 4,             /* n0 == 0 or n1 == 0 (cannot occur after mfilter_coverage, myDetect.py:301-314) */
+  NMOD_STATUS_TOO_LARGE = 8          /* more samples than the max_n0 / max_n1 the caller promised: position skipped, outputs NaN */
+};
+
+/* return codes */
+enum {
+  NMOD_OK = 0,
+  NMOD_ERR_INVALID_ARG = -1,
+  NMOD_ERR_HIP = -2,          /* a HIP runtime call failed; see nmod_strerror */
+  NMOD_ERR_TOO_LARGE = -3,    /* a position has more samples per group than NMOD_MAX_GROUP */
+  NMOD_ERR_WORKSPACE = -4,    /* workspace missing or too small (device-memory mode) */
+  NMOD_ERR_NO_DEVICE = -5
+};
+
+#define NMOD_MAX_GROUP 2048   /* max samples per group per position (wave-resident sort) */
+#define NMOD_MAX_NB 64        /* max --neighborPvalues */
+
+typedef struct nmod_params {
+  int32_t struct_size;    /* sizeof(nmod_params), for ABI evolution */
+  int32_t device;         /* HIP device ordinal */
+  void*   stream;         /* hipStream_t to launch on (NULL = default stream) */
+  int32_t memspace;       /* NMOD_MEM_*: where sig/off/run_id/out pointers live */
+  int32_t dtype;          /* NMOD_DTYPE_* */
+  int32_t tests;          /* NMOD_TEST_* mask */
+  int32_t method;         /* NMOD_METHOD_* */
+  int32_t nb;             /* --neighborPvalues (NanoMod.py:357), window = 2*nb+1 */
+  int32_t want_mstd;      /* --mstd: also mean / std (ddof=0) per group (myDetect.py:437-438) */
+  double  weights_dif;    /* --WeightsDif (NanoMod.py:358; weights myDetect.py:396-400) */
+  int64_t stride0;        /* >0: fixed-stride layout, off0 may be NULL: n0 = stride0 for every position */
+  int64_t stride1;        /* >0: same for group 2 */
+  int32_t max_n0;         /* upper bound of samples per position in group 1 (0 = unknown: the library
+                             reduces off0 on the device and synchronises once to read it) */
+  int32_t max_n1;         /* same for group 2 */
+  void*   timer;          /* optional nmod_evtimer handle: HIP events are recorded around each kernel */
+} nmod_params;
+
+/* Caller-allocated SoA outputs, npos elements each; a NULL member is skipped.
+ * One (stat, p) pair per test = the tuples getKStest returns
+ * (myDetect.py:363) after the m_min_float / m_max_float clamps (:317-325),
+ * then the combined pair appended by combin_pvalues (:373-377,403-406). */
+typedef struct nmod_out {
+  double* mwu_u;   double* mwu_p;     /* myDetect.py:331-333 */
+  double* t_t;     double* t_p;       /* myDetect.py:335-337 */
+  double* ks_d;    double* ks_p;      /* myDetect.py:341-343 */
+  double* comb_st; double* comb_p;    /* myDetect.py:379-414 (not written when method == KS) */
+  double* mean0;   double* std0;      /* myDetect.py:438 (want_mstd) */
+  double* mean1;   double* std1;
+  uint8_t* status;
+} nmod_out;
+
+int nmod_abi_version(void);
+int nmod_device_count(void);                 /* number of HIP devices (0 if none) */
+const char* nmod_strerror(int rc);
+
+/* Device scratch needed by nmod_detect_batch for `npos` positions (bytes). */
+int64_t nmod_workspace_bytes(const nmod_params* prm, int64_t npos);
+
+/* Replaces the two hot loops of mtest2 (myDetect.py:427-436 per-position
+ * getKStest, :443 combin_pvalues).  NMOD_MEM_DEVICE: all pointers are device
+ * pointers, `workspace` must hold nmod_workspace_bytes(), everything is
+ * enqueued on prm->stream and the call returns without synchronising.
+ * NMOD_MEM_HOST: pointers are host memory; the library stages through device
+ * memory it allocates and frees inside the call (workspace may be NULL) and
+ * returns after the results are back. */
+int nmod_detect_batch(const nmod_params* prm, int64_t npos,
+                      const void* sig0, const int64_t* off0,
+                      const void* sig1, const int64_t* off1,
+                      const int32_t* run_id,
+                      void* workspace, int64_t workspace_bytes,
+                      nmod_out* out);
+
+/* Replaces combin_pvalues / get_combin_pvalue on a whole KS track
+ * (myDetect.py:373-414).  ks_d is only read when nb == 0 (:413). */
+int nmod_combine_track(const nmod_params* prm, int64_t npos,
+                       const double* ks_d, const double* ks_p, const int32_t* run_id,
+                       double* comb_st, double* comb_p);
+
+/* Benchmark input generator (no reference counterpart).
+ * Counter-based and integer-only, so tests restate it bit-exactly on the CPU:
+ *   h = mix64(seed, group, pos, read);  s = sum of the four 16-bit fields of h;
+ *   x = float(s - 131070) * (1/37837.2f)  [ + shift  at planted positions of group 1 ]
+ * Fills sig[(pos - pos_begin) * n_per_pos + read] for pos in [pos_begin, pos_begin+npos).
+ * A position is planted iff plant_period > 0 and (pos % plant_period) is 0, 1 or plant_period-1. */
+int nmod_synth_fill(const nmod_params* prm, uint64_t seed, int64_t pos_begin, int64_t npos,
+                    int32_t group, int32_t n_per_pos, int64_t plant_period, float plant_shift,
+                    void* sig_out);
+
+/* HIP-event timer: records (start, stop) around every kernel the library
+ * launches while prm->timer points to it; read it after synchronising. */
+enum { NMOD_KERNEL_RANK_STATS = 0, NMOD_KERNEL_FINALIZE = 1, NMOD_KERNEL_COMBINE = 2,
+       NMOD_KERNEL_SYNTH = 3, NMOD_KERNEL_COUNT = 4 };
+int nmod_evtimer_create(int32_t capacity_per_kernel, void** timer);
+int nmod_evtimer_reset(void* timer);
+int nmod_evtimer_read(void* timer, int32_t kernel, double* total_ms, int32_t* launches);
+int nmod_evtimer_destroy(void* timer);
+
+/* Lane-permutation self test of the wave primitives the sort is built from
+ * (runs tiny kernels; returns NMOD_OK or the number of the first failing primitive). */
+int nmod_selftest(int32_t device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANOMOD_HIP_H */

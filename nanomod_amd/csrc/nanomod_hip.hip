@@ -1,0 +1,603 @@
+// C-ABI implementation (include/nanomod_hip.h): argument checking, workspace
+// carving, size-class binning, kernel launches on the caller's stream, the
+// host-memory staging mode, the HIP-event timer and the wave-primitive self test.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/nanomod_hip.h"
+#include "rank_stats.hpp"
+#include "rank_stats_launch.hpp"
+#include "pvalue_kernels.hpp"
+
+namespace nmod {
+
+thread_local hipError_t g_last_hip = hipSuccess;   // only feeds nmod_strerror's text
+thread_local char g_errbuf[256];
+
+#define NMOD_HIP(call)                                   \
+  do {                                                   \
+    hipError_t e_ = (call);                              \
+    if (e_ != hipSuccess) { g_last_hip = e_; return NMOD_ERR_HIP; } \
+  } while (0)
+
+// ---------------------------------------------------------------- event timer
+struct EvTimer {
+  int capacity;
+  std::vector<hipEvent_t> start[NMOD_KERNEL_COUNT], stop[NMOD_KERNEL_COUNT];
+  int used[NMOD_KERNEL_COUNT];
+};
+
+struct ScopedKernelTimer {
+  EvTimer* t; int k; hipStream_t s; int slot;
+  ScopedKernelTimer(void* timer, int kernel, hipStream_t stream) : t((EvTimer*)timer), k(kernel), s(stream), slot(-1) {
+    if (t && t->used[k] < t->capacity) { slot = t->used[k]; hipEventRecord(t->start[k][slot], s); }
+  }
+  ~ScopedKernelTimer() {
+    if (slot >= 0) { hipEventRecord(t->stop[k][slot], s); t->used[k] = slot + 1; }
+  }
+};
+
+// ---------------------------------------------------------------- workspace
+struct Workspace {
+  uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments;
+  double* tmp_ks_d; double* tmp_ks_p;
+  int32_t* order; uint8_t* cls; int32_t* meta;     // meta: [0..35] counts, [36..71] offsets, [72..107] cursors, [108..109] max n0/n1
+  int64_t bytes;
+};
+constexpr int kMetaInts = 128;
+constexpr int kNumPairs = kNumSizeClasses * kNumSizeClasses;
+
+static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+static Workspace carve(void* base, int64_t npos) {
+  Workspace w;
+  char* p = (char*)base;
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) { char* r = p ? p + o : nullptr; o += align256(bytes); return r; };
+  w.ks_num = (uint32_t*)take(4 * npos);
+  w.mwu_s = (uint64_t*)take(8 * npos);
+  w.tie = (uint64_t*)take(8 * npos);
+  w.moments = (double*)take(32 * npos);
+  w.tmp_ks_d = (double*)take(8 * npos);
+  w.tmp_ks_p = (double*)take(8 * npos);
+  w.order = (int32_t*)take(4 * npos);
+  w.cls = (uint8_t*)take(npos);
+  w.meta = (int32_t*)take(kMetaInts * 4);
+  w.bytes = o;
+  return w;
+}
+
+// ---------------------------------------------------------------- binning kernels
+struct BinArgs {
+  int64_t npos; const int64_t* off0; const int64_t* off1; int64_t stride0, stride1;
+  int cmax0, cmax1; uint8_t* cls; int32_t* meta; int32_t* order;
+};
+
+__device__ __forceinline__ int dev_class_of(int64_t n) {
+  int c = 0;
+  while (c < kNumSizeClasses && n > (64LL << c)) ++c;
+  return c;   // == kNumSizeClasses when too large
+}
+
+__global__ __launch_bounds__(256) void max_n_kernel(int64_t npos, const int64_t* off0, const int64_t* off1, int32_t* meta) {
+  __shared__ int m0s, m1s;
+  if (threadIdx.x == 0) { m0s = 0; m1s = 0; }
+  __syncthreads();
+  int m0 = 0, m1 = 0;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npos; p += (int64_t)gridDim.x * 256) {
+    if (off0) m0 = max(m0, (int)min((int64_t)INT32_MAX, off0[p + 1] - off0[p]));
+    if (off1) m1 = max(m1, (int)min((int64_t)INT32_MAX, off1[p + 1] - off1[p]));
+  }
+  atomicMax(&m0s, m0); atomicMax(&m1s, m1);
+  __syncthreads();
+  if (threadIdx.x == 0) { atomicMax(&meta[108], m0s); atomicMax(&meta[109], m1s); }
+}
+
+__global__ __launch_bounds__(256) void classify_kernel(BinArgs a) {
+  __shared__ int hist[kNumPairs];
+  for (int i = threadIdx.x; i < kNumPairs; i += 256) hist[i] = 0;
+  __syncthreads();
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.npos; p += (int64_t)gridDim.x * 256) {
+    int64_t n0 = a.stride0 > 0 ? a.stride0 : a.off0[p + 1] - a.off0[p];
+    int64_t n1 = a.stride1 > 0 ? a.stride1 : a.off1[p + 1] - a.off1[p];
+    int c0 = dev_class_of(n0), c1 = dev_class_of(n1);
+    int cid = (c0 > a.cmax0 || c1 > a.cmax1 || n0 <= 0 || n1 <= 0) ? 255 : c0 * kNumSizeClasses + c1;
+    a.cls[p] = (uint8_t)cid;
+    if (cid != 255) atomicAdd(&hist[cid], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kNumPairs; i += 256) if (hist[i]) atomicAdd(&a.meta[i], hist[i]);
+}
+
+__global__ void class_offsets_kernel(int32_t* meta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int acc = 0;
+    for (int i = 0; i < kNumPairs; ++i) { meta[36 + i] = acc; meta[72 + i] = 0; acc += meta[i]; }
+  }
+}
+
+// positions of one 256-chunk that share a class stay contiguous and ordered inside the class list
+__global__ __launch_bounds__(256) void scatter_kernel(BinArgs a) {
+  __shared__ int base[kNumPairs];
+  for (int64_t chunk = blockIdx.x; chunk * 256 < a.npos; chunk += gridDim.x) {
+    int64_t p = chunk * 256 + threadIdx.x;
+    int cid = (p < a.npos) ? a.cls[p] : 255;
+    // rank inside the chunk among earlier threads of the same class (wave ballots + per-wave prefix)
+    int rank = 0;
+    __shared__ int wave_cnt[4][kNumPairs];
+    for (int i = threadIdx.x; i < 4 * kNumPairs; i += 256) (&wave_cnt[0][0])[i] = 0;
+    __syncthreads();
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long same = 0;
+    for (int c = 0; c < kNumPairs; ++c) {              // all lanes take part in every ballot
+      unsigned long long m = __ballot(cid == c);
+      if (cid == c) same = m;
+    }
+    if (cid != 255) {
+      rank = __popcll(same & ((1ull << lane) - 1ull));
+      if (rank == 0) wave_cnt[wave][cid] = __popcll(same);
+    }
+    __syncthreads();
+    if (cid != 255) for (int w = 0; w < wave; ++w) rank += wave_cnt[w][cid];
+    if (threadIdx.x < kNumPairs) {
+      int c = threadIdx.x;
+      int tot = wave_cnt[0][c] + wave_cnt[1][c] + wave_cnt[2][c] + wave_cnt[3][c];
+      base[c] = tot ? atomicAdd(&a.meta[72 + c], tot) : 0;
+    }
+    __syncthreads();
+    if (cid != 255) a.order[a.meta[36 + cid] + base[cid] + rank] = (int32_t)p;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- helpers
+static int check_params(const nmod_params* prm) {
+  if (!prm || prm->struct_size != (int32_t)sizeof(nmod_params)) return NMOD_ERR_INVALID_ARG;
+  if (prm->dtype != NMOD_DTYPE_F32 && prm->dtype != NMOD_DTYPE_I16_MILLI) return NMOD_ERR_INVALID_ARG;
+  if (prm->memspace != NMOD_MEM_HOST && prm->memspace != NMOD_MEM_DEVICE) return NMOD_ERR_INVALID_ARG;
+  if (prm->method < NMOD_METHOD_KS || prm->method > NMOD_METHOD_FISHER) return NMOD_ERR_INVALID_ARG;
+  if (prm->nb < 0 || prm->nb > NMOD_MAX_NB) return NMOD_ERR_INVALID_ARG;
+  if ((prm->tests & ~NMOD_TEST_ALL) != 0) return NMOD_ERR_INVALID_ARG;
+  return NMOD_OK;
+}
+
+static int fill_combine_args(const nmod_params* prm, CombineArgs& ca) {
+  ca.nb = prm->nb; ca.method = prm->method;
+  double dif = prm->weights_dif;
+  if (prm->method == NMOD_METHOD_STOUFFER && !(dif > 0.0)) return NMOD_ERR_INVALID_ARG;
+  // myDetect.py:396-400: 100 in the middle, each step outwards divides by WeightsDif
+  int nb = prm->nb;
+  ca.w[nb] = 100.0;
+  for (int k = 1; k <= nb; ++k) { ca.w[nb - k] = ca.w[nb - k + 1] / dif; ca.w[nb + k] = ca.w[nb + k - 1] / dif; }
+  double ss = 0.0;
+  for (int k = 0; k <= 2 * nb; ++k) ss += ca.w[k] * ca.w[k];
+  ca.wnorm = sqrt(ss);
+  return NMOD_OK;
+}
+
+static int launch_combine(const nmod_params* prm, hipStream_t stream, int64_t npos, const double* ks_d,
+                          const double* ks_p, const int32_t* run_id, double* comb_st, double* comb_p) {
+  CombineArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  int rc = fill_combine_args(prm, ca);
+  if (rc != NMOD_OK) return rc;
+  ca.npos = npos; ca.ks_d = ks_d; ca.ks_p = ks_p; ca.run_id = run_id; ca.comb_st = comb_st; ca.comb_p = comb_p;
+  unsigned blocks = (unsigned)((npos + kCombineTile - 1) / kCombineTile);
+  if (blocks == 0) return NMOD_OK;
+  ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_COMBINE, stream);
+  hipLaunchKernelGGL(combine_kernel, dim3(blocks), dim3(kCombineTile), 0, stream, ca);
+  NMOD_HIP(hipGetLastError());
+  return NMOD_OK;
+}
+
+static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0, const int64_t* off0,
+                         const void* sig1, const int64_t* off1, const int32_t* run_id, void* workspace,
+                         int64_t workspace_bytes, nmod_out* out) {
+  hipStream_t stream = (hipStream_t)prm->stream;
+  if (npos == 0) return NMOD_OK;
+  if (!sig0 || !sig1 || !out) return NMOD_ERR_INVALID_ARG;
+  if ((prm->stride0 <= 0 && !off0) || (prm->stride1 <= 0 && !off1)) return NMOD_ERR_INVALID_ARG;
+  if (npos > INT32_MAX) return NMOD_ERR_INVALID_ARG;
+  const bool want_comb = prm->method != NMOD_METHOD_KS && (out->comb_st || out->comb_p);
+  if (want_comb && (!out->comb_st || !out->comb_p)) return NMOD_ERR_INVALID_ARG;
+  if (want_comb && prm->nb > 0 && !run_id) return NMOD_ERR_INVALID_ARG;
+  Workspace ws = carve(workspace, npos);
+  if (!workspace || workspace_bytes < ws.bytes) return NMOD_ERR_WORKSPACE;
+
+  hipDeviceProp_t prop;
+  NMOD_HIP(hipGetDeviceProperties(&prop, prm->device));
+  const int num_cus = prop.multiProcessorCount;
+
+  int tests = prm->tests;
+  if (want_comb) tests |= NMOD_TEST_KS;
+  const bool all = (tests & (NMOD_TEST_MWU | NMOD_TEST_WELCH)) != 0 || prm->want_mstd;
+
+  // ---- size classes
+  const bool uniform = prm->stride0 > 0 && prm->stride1 > 0;
+  int64_t max0 = prm->stride0 > 0 ? prm->stride0 : prm->max_n0;
+  int64_t max1 = prm->stride1 > 0 ? prm->stride1 : prm->max_n1;
+  NMOD_HIP(hipMemsetAsync(ws.meta, 0, kMetaInts * 4, stream));
+  if (max0 <= 0 || max1 <= 0) {
+    hipLaunchKernelGGL(max_n_kernel, dim3(1024), dim3(256), 0, stream, npos,
+                       prm->stride0 > 0 ? nullptr : off0, prm->stride1 > 0 ? nullptr : off1, ws.meta);
+    NMOD_HIP(hipGetLastError());
+    int32_t mx[2];
+    NMOD_HIP(hipMemcpyAsync(mx, ws.meta + 108, 8, hipMemcpyDeviceToHost, stream));
+    NMOD_HIP(hipStreamSynchronize(stream));
+    if (max0 <= 0) max0 = mx[0];
+    if (max1 <= 0) max1 = mx[1];
+  }
+  int cmax0 = size_class_of(std::max<int64_t>(max0, 1)), cmax1 = size_class_of(std::max<int64_t>(max1, 1));
+  if (cmax0 < 0 || cmax1 < 0) return NMOD_ERR_TOO_LARGE;
+
+  RankStatsArgs ra;
+  memset(&ra, 0, sizeof(ra));
+  ra.sig0 = sig0; ra.sig1 = sig1; ra.off0 = off0; ra.off1 = off1;
+  ra.stride0 = prm->stride0 > 0 ? prm->stride0 : 0; ra.stride1 = prm->stride1 > 0 ? prm->stride1 : 0;
+  ra.npos = npos; ra.ks_num = ws.ks_num; ra.mwu_s = ws.mwu_s; ra.tie = ws.tie; ra.moments = ws.moments;
+
+  auto launch = [&](int c0, int c1, int64_t work) -> hipError_t {
+    if (prm->dtype == NMOD_DTYPE_F32)
+      return all ? launch_rank_stats_d0_a1(c0, c1, num_cus, work, stream, ra)
+                 : launch_rank_stats_d0_a0(c0, c1, num_cus, work, stream, ra);
+    return all ? launch_rank_stats_d1_a1(c0, c1, num_cus, work, stream, ra)
+               : launch_rank_stats_d1_a0(c0, c1, num_cus, work, stream, ra);
+  };
+
+  if (uniform) {
+    ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
+    NMOD_HIP(launch(cmax0, cmax1, npos));
+  } else {
+    BinArgs ba;
+    ba.npos = npos; ba.off0 = off0; ba.off1 = off1; ba.stride0 = ra.stride0; ba.stride1 = ra.stride1;
+    ba.cmax0 = cmax0; ba.cmax1 = cmax1; ba.cls = ws.cls; ba.meta = ws.meta; ba.order = ws.order;
+    unsigned blocks = (unsigned)std::min<int64_t>((npos + 255) / 256, 4096);
+    hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, stream, ba);
+    hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(64), 0, stream, ws.meta);
+    hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), 0, stream, ba);
+    NMOD_HIP(hipGetLastError());
+    ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
+    for (int c0 = 0; c0 <= cmax0; ++c0)
+      for (int c1 = 0; c1 <= cmax1; ++c1) {
+        int cid = c0 * kNumSizeClasses + c1;
+        ra.pos_list = ws.order; ra.class_meta = ws.meta; ra.class_id = cid;
+        NMOD_HIP(launch(c0, c1, npos));
+      }
+  }
+
+  // ---- p-values
+  FinalizeArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.npos = npos; fa.off0 = off0; fa.off1 = off1; fa.stride0 = ra.stride0; fa.stride1 = ra.stride1;
+  fa.ks_num = ws.ks_num; fa.mwu_s = ws.mwu_s; fa.tie = ws.tie; fa.moments = ws.moments;
+  fa.tests = tests; fa.want_mstd = prm->want_mstd; fa.out = *out;
+  fa.max_n0 = 64LL << cmax0; fa.max_n1 = 64LL << cmax1;
+  if (want_comb) {                       // the combine needs the KS track even if the caller does not
+    if (!fa.out.ks_d) fa.out.ks_d = ws.tmp_ks_d;
+    if (!fa.out.ks_p) fa.out.ks_p = ws.tmp_ks_p;
+  }
+  {
+    ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_FINALIZE, stream);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, stream, fa);
+    NMOD_HIP(hipGetLastError());
+  }
+  if (want_comb) {
+    int rc = launch_combine(prm, stream, npos, fa.out.ks_d, fa.out.ks_p, run_id, out->comb_st, out->comb_p);
+    if (rc != NMOD_OK) return rc;
+  }
+  return NMOD_OK;
+}
+
+// ---------------------------------------------------------------- host staging
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, const int64_t* off0,
+                       const void* sig1, const int64_t* off1, const int32_t* run_id, nmod_out* out) {
+  if (npos == 0) return NMOD_OK;
+  if (!sig0 || !sig1 || !out) return NMOD_ERR_INVALID_ARG;
+  if ((prm->stride0 <= 0 && !off0) || (prm->stride1 <= 0 && !off1)) return NMOD_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)prm->stream;
+  const size_t esz = prm->dtype == NMOD_DTYPE_F32 ? 4 : 2;
+  const int64_t tot0 = prm->stride0 > 0 ? prm->stride0 * npos : off0[npos] - off0[0];
+  const int64_t tot1 = prm->stride1 > 0 ? prm->stride1 * npos : off1[npos] - off1[0];
+  nmod_params dp = *prm;
+  dp.memspace = NMOD_MEM_DEVICE;
+  // the offsets are in host memory here, so the size check is free
+  int64_t m0 = prm->stride0 > 0 ? prm->stride0 : 0, m1 = prm->stride1 > 0 ? prm->stride1 : 0;
+  if (prm->stride0 <= 0) for (int64_t i = 0; i < npos; ++i) m0 = std::max(m0, off0[i + 1] - off0[i]);
+  if (prm->stride1 <= 0) for (int64_t i = 0; i < npos; ++i) m1 = std::max(m1, off1[i + 1] - off1[i]);
+  if (m0 > NMOD_MAX_GROUP || m1 > NMOD_MAX_GROUP) return NMOD_ERR_TOO_LARGE;
+  dp.max_n0 = (int32_t)std::max<int64_t>(m0, 1); dp.max_n1 = (int32_t)std::max<int64_t>(m1, 1);
+
+  DevBuf d_sig0, d_sig1, d_off0, d_off1, d_run, d_ws, d_out;
+  NMOD_HIP(d_sig0.alloc(tot0 * esz)); NMOD_HIP(d_sig1.alloc(tot1 * esz));
+  const int64_t base0 = prm->stride0 > 0 ? 0 : off0[0], base1 = prm->stride1 > 0 ? 0 : off1[0];
+  NMOD_HIP(hipMemcpyAsync(d_sig0.p, (const char*)sig0 + base0 * esz, tot0 * esz, hipMemcpyHostToDevice, stream));
+  NMOD_HIP(hipMemcpyAsync(d_sig1.p, (const char*)sig1 + base1 * esz, tot1 * esz, hipMemcpyHostToDevice, stream));
+  std::vector<int64_t> r0, r1;             // offsets rebased to the staged copy
+  if (prm->stride0 <= 0) {
+    r0.resize(npos + 1); for (int64_t i = 0; i <= npos; ++i) r0[i] = off0[i] - base0;
+    NMOD_HIP(d_off0.alloc((npos + 1) * 8));
+    NMOD_HIP(hipMemcpyAsync(d_off0.p, r0.data(), (npos + 1) * 8, hipMemcpyHostToDevice, stream));
+  }
+  if (prm->stride1 <= 0) {
+    r1.resize(npos + 1); for (int64_t i = 0; i <= npos; ++i) r1[i] = off1[i] - base1;
+    NMOD_HIP(d_off1.alloc((npos + 1) * 8));
+    NMOD_HIP(hipMemcpyAsync(d_off1.p, r1.data(), (npos + 1) * 8, hipMemcpyHostToDevice, stream));
+  }
+  if (run_id) {
+    NMOD_HIP(d_run.alloc(npos * 4));
+    NMOD_HIP(hipMemcpyAsync(d_run.p, run_id, npos * 4, hipMemcpyHostToDevice, stream));
+  }
+  const int64_t wsb = nmod_workspace_bytes(&dp, npos);
+  NMOD_HIP(d_ws.alloc(wsb));
+  // one device slab for the 12 fp64 tracks + status
+  NMOD_HIP(d_out.alloc((size_t)npos * (12 * 8 + 1)));
+  double* slab = (double*)d_out.p;
+  nmod_out dout;
+  double** hp = (double**)out;             // the 12 leading members are double*
+  double** dpv = (double**)&dout;
+  for (int k = 0; k < 12; ++k) dpv[k] = hp[k] ? slab + (int64_t)k * npos : nullptr;
+  dout.status = out->status ? (uint8_t*)(slab + 12 * npos) : nullptr;
+
+  int rc = detect_device(&dp, npos, d_sig0.p, (const int64_t*)d_off0.p, d_sig1.p, (const int64_t*)d_off1.p,
+                         (const int32_t*)d_run.p, d_ws.p, wsb, &dout);
+  if (rc != NMOD_OK) { hipStreamSynchronize(stream); return rc; }
+  const bool no_comb = prm->method == NMOD_METHOD_KS;
+  for (int k = 0; k < 12; ++k) {
+    if (!hp[k]) continue;
+    if (no_comb && (k == 6 || k == 7)) continue;                       // comb_* untouched
+    if (!prm->want_mstd && k >= 8) continue;
+    if (k < 2 && !(prm->tests & NMOD_TEST_MWU)) continue;
+    if ((k == 2 || k == 3) && !(prm->tests & NMOD_TEST_WELCH)) continue;
+    if ((k == 4 || k == 5) && !(prm->tests & NMOD_TEST_KS) && no_comb) continue;
+    NMOD_HIP(hipMemcpyAsync(hp[k], dpv[k], npos * 8, hipMemcpyDeviceToHost, stream));
+  }
+  if (out->status) NMOD_HIP(hipMemcpyAsync(out->status, dout.status, npos, hipMemcpyDeviceToHost, stream));
+  NMOD_HIP(hipStreamSynchronize(stream));
+  return NMOD_OK;
+}
+
+// ---------------------------------------------------------------- self test kernels
+__global__ void selftest_perm_kernel(int* out) {
+  int lane = threadIdx.x & 63;
+  float x = (float)lane;
+  int k = 0;
+  out[64 * k++ + lane] = (int)lane_xor<1>(x);
+  out[64 * k++ + lane] = (int)lane_xor<2>(x);
+  out[64 * k++ + lane] = (int)lane_xor<4>(x);
+  out[64 * k++ + lane] = (int)lane_xor<8>(x);
+  out[64 * k++ + lane] = (int)lane_xor<16>(x);
+  out[64 * k++ + lane] = (int)lane_mirror<2>(x, lane);
+  out[64 * k++ + lane] = (int)lane_mirror<4>(x, lane);
+  out[64 * k++ + lane] = (int)lane_mirror<8>(x, lane);
+  out[64 * k++ + lane] = (int)lane_mirror<16>(x, lane);
+  out[64 * k++ + lane] = (int)lane_mirror<32>(x, lane);
+  out[64 * k++ + lane] = (int)lane_mirror<64>(x, lane);
+  out[64 * k++ + lane] = (int)lane_prev(x, -1.0f);
+  out[64 * k++ + lane] = (int)lane_next(x, -1.0f);
+  out[64 * k++ + lane] = wave_scan_max_i32((lane * 37) % 64 == 5 ? 1000 : (lane * 7) % 23);
+  out[64 * k++ + lane] = (int)wave_max_u32((unsigned)((lane * 29) % 61));
+  out[64 * k++ + lane] = (int)wave_sum_u64((unsigned long long)lane * 3ull + (1ull << 33)) ;
+  out[64 * k++ + lane] = (int)(wave_sum_u64((unsigned long long)lane * 3ull + (1ull << 33)) >> 32);
+  out[64 * k++ + lane] = (int)wave_sum_f64(0.5 * lane);
+}
+
+template <int R>
+__global__ void selftest_sort_kernel(const float* in, float* out, int* runs) {
+  int lane = threadIdx.x & 63;
+  const float inf = __builtin_inff();
+  LaneSel sel;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) sel.s[b] = ((lane >> b) & 1) ? inf : -inf;
+  float x[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) x[r] = in[r * 64 + lane];
+  wave_sort<R>(x, sel, lane);
+  store_sorted<R>(out, x, lane);
+  store_runs<R>(runs, x, lane);
+}
+
+template <int R>
+static int selftest_sort(int code) {
+  const int N = 64 * R;
+  std::vector<float> h(N), sorted(N), got(N);
+  std::vector<int> runs(N);
+  uint32_t s = 12345u + R;
+  for (int i = 0; i < N; ++i) { s = s * 1664525u + 1013904223u; h[i] = (float)((int)((s >> 8) % 97) - 48) * 0.25f; }   // many ties
+  sorted = h; std::sort(sorted.begin(), sorted.end());
+  float *din, *dout; int* druns;
+  NMOD_HIP(hipMalloc(&din, N * 4)); NMOD_HIP(hipMalloc(&dout, N * 4)); NMOD_HIP(hipMalloc(&druns, N * 4));
+  NMOD_HIP(hipMemcpy(din, h.data(), N * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(selftest_sort_kernel<R>, dim3(1), dim3(64), 0, 0, din, dout, druns);
+  NMOD_HIP(hipMemcpy(got.data(), dout, N * 4, hipMemcpyDeviceToHost));
+  NMOD_HIP(hipMemcpy(runs.data(), druns, N * 4, hipMemcpyDeviceToHost));
+  hipFree(din); hipFree(dout); hipFree(druns);
+  for (int i = 0; i < N; ++i) if (got[i] != sorted[i]) return code;
+  for (int i = 0; i < N; ++i) {
+    int st = i, en = i + 1;
+    while (st > 0 && sorted[st - 1] == sorted[i]) --st;
+    while (en < N && sorted[en] == sorted[i]) ++en;
+    if (runs[i] != (st | (en << 16))) return code + 1;
+  }
+  return NMOD_OK;
+}
+
+}  // namespace nmod
+
+// =================================================================== C ABI
+using namespace nmod;
+
+extern "C" {
+
+int nmod_abi_version(void) { return NMOD_ABI_VERSION; }
+
+int nmod_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* nmod_strerror(int rc) {
+  switch (rc) {
+    case NMOD_OK: return "ok";
+    case NMOD_ERR_INVALID_ARG: return "invalid argument";
+    case NMOD_ERR_HIP:
+      snprintf(g_errbuf, sizeof(g_errbuf), "HIP runtime error: %s", hipGetErrorString(g_last_hip));
+      return g_errbuf;
+    case NMOD_ERR_TOO_LARGE: return "a position has more samples per group than NMOD_MAX_GROUP (2048)";
+    case NMOD_ERR_WORKSPACE: return "workspace missing or smaller than nmod_workspace_bytes()";
+    case NMOD_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown error code";
+  }
+}
+
+int64_t nmod_workspace_bytes(const nmod_params* prm, int64_t npos) {
+  (void)prm;
+  if (npos < 0) return 0;
+  return carve(nullptr, npos).bytes;
+}
+
+int nmod_detect_batch(const nmod_params* prm, int64_t npos, const void* sig0, const int64_t* off0,
+                      const void* sig1, const int64_t* off1, const int32_t* run_id, void* workspace,
+                      int64_t workspace_bytes, nmod_out* out) {
+  int rc = check_params(prm);
+  if (rc != NMOD_OK) return rc;
+  if (npos < 0) return NMOD_ERR_INVALID_ARG;
+  if (nmod_device_count() <= prm->device || prm->device < 0) return NMOD_ERR_NO_DEVICE;
+  NMOD_HIP(hipSetDevice(prm->device));
+  if (prm->memspace == NMOD_MEM_DEVICE)
+    return detect_device(prm, npos, sig0, off0, sig1, off1, run_id, workspace, workspace_bytes, out);
+  return detect_host(prm, npos, sig0, off0, sig1, off1, run_id, out);
+}
+
+int nmod_combine_track(const nmod_params* prm, int64_t npos, const double* ks_d, const double* ks_p,
+                       const int32_t* run_id, double* comb_st, double* comb_p) {
+  int rc = check_params(prm);
+  if (rc != NMOD_OK) return rc;
+  if (npos < 0 || prm->method == NMOD_METHOD_KS) return NMOD_ERR_INVALID_ARG;
+  if (npos == 0) return NMOD_OK;
+  if (!ks_p || !comb_st || !comb_p || (prm->nb == 0 && !ks_d) || (prm->nb > 0 && !run_id)) return NMOD_ERR_INVALID_ARG;
+  if (nmod_device_count() <= prm->device || prm->device < 0) return NMOD_ERR_NO_DEVICE;
+  NMOD_HIP(hipSetDevice(prm->device));
+  hipStream_t stream = (hipStream_t)prm->stream;
+  if (prm->memspace == NMOD_MEM_DEVICE)
+    return launch_combine(prm, stream, npos, ks_d, ks_p, run_id, comb_st, comb_p);
+  DevBuf d_d, d_p, d_r, d_o;
+  NMOD_HIP(d_d.alloc(npos * 8)); NMOD_HIP(d_p.alloc(npos * 8)); NMOD_HIP(d_r.alloc(npos * 4)); NMOD_HIP(d_o.alloc(npos * 16));
+  if (ks_d) NMOD_HIP(hipMemcpyAsync(d_d.p, ks_d, npos * 8, hipMemcpyHostToDevice, stream));
+  NMOD_HIP(hipMemcpyAsync(d_p.p, ks_p, npos * 8, hipMemcpyHostToDevice, stream));
+  if (run_id) NMOD_HIP(hipMemcpyAsync(d_r.p, run_id, npos * 4, hipMemcpyHostToDevice, stream));
+  double* o = (double*)d_o.p;
+  rc = launch_combine(prm, stream, npos, (const double*)d_d.p, (const double*)d_p.p, (const int32_t*)d_r.p, o, o + npos);
+  if (rc != NMOD_OK) { hipStreamSynchronize(stream); return rc; }
+  NMOD_HIP(hipMemcpyAsync(comb_st, o, npos * 8, hipMemcpyDeviceToHost, stream));
+  NMOD_HIP(hipMemcpyAsync(comb_p, o + npos, npos * 8, hipMemcpyDeviceToHost, stream));
+  NMOD_HIP(hipStreamSynchronize(stream));
+  return NMOD_OK;
+}
+
+int nmod_synth_fill(const nmod_params* prm, uint64_t seed, int64_t pos_begin, int64_t npos, int32_t group,
+                    int32_t n_per_pos, int64_t plant_period, float plant_shift, void* sig_out) {
+  int rc = check_params(prm);
+  if (rc != NMOD_OK) return rc;
+  if (npos < 0 || n_per_pos <= 0 || !sig_out || (group != 0 && group != 1)) return NMOD_ERR_INVALID_ARG;
+  if (prm->memspace != NMOD_MEM_DEVICE) return NMOD_ERR_INVALID_ARG;
+  if (nmod_device_count() <= prm->device || prm->device < 0) return NMOD_ERR_NO_DEVICE;
+  NMOD_HIP(hipSetDevice(prm->device));
+  if (npos == 0) return NMOD_OK;
+  hipStream_t stream = (hipStream_t)prm->stream;
+  SynthArgs sa;
+  sa.seed = seed; sa.pos_begin = pos_begin; sa.npos = npos; sa.group = group; sa.n_per_pos = n_per_pos;
+  sa.plant_period = plant_period; sa.plant_shift = plant_shift; sa.dtype = prm->dtype; sa.out = sig_out;
+  int64_t total = npos * (int64_t)n_per_pos;
+  unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+  ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_SYNTH, stream);
+  hipLaunchKernelGGL(synth_kernel, dim3(blocks), dim3(256), 0, stream, sa);
+  NMOD_HIP(hipGetLastError());
+  return NMOD_OK;
+}
+
+int nmod_evtimer_create(int32_t capacity_per_kernel, void** timer) {
+  if (!timer || capacity_per_kernel <= 0) return NMOD_ERR_INVALID_ARG;
+  EvTimer* t = new EvTimer();
+  t->capacity = capacity_per_kernel;
+  for (int k = 0; k < NMOD_KERNEL_COUNT; ++k) {
+    t->used[k] = 0;
+    t->start[k].resize(capacity_per_kernel); t->stop[k].resize(capacity_per_kernel);
+    for (int i = 0; i < capacity_per_kernel; ++i) {
+      if (hipEventCreate(&t->start[k][i]) != hipSuccess || hipEventCreate(&t->stop[k][i]) != hipSuccess) return NMOD_ERR_HIP;
+    }
+  }
+  *timer = t;
+  return NMOD_OK;
+}
+
+int nmod_evtimer_reset(void* timer) {
+  if (!timer) return NMOD_ERR_INVALID_ARG;
+  EvTimer* t = (EvTimer*)timer;
+  for (int k = 0; k < NMOD_KERNEL_COUNT; ++k) t->used[k] = 0;
+  return NMOD_OK;
+}
+
+int nmod_evtimer_read(void* timer, int32_t kernel, double* total_ms, int32_t* launches) {
+  if (!timer || kernel < 0 || kernel >= NMOD_KERNEL_COUNT || !total_ms || !launches) return NMOD_ERR_INVALID_ARG;
+  EvTimer* t = (EvTimer*)timer;
+  double tot = 0.0;
+  for (int i = 0; i < t->used[kernel]; ++i) {
+    float ms = 0.f;
+    NMOD_HIP(hipEventSynchronize(t->stop[kernel][i]));
+    NMOD_HIP(hipEventElapsedTime(&ms, t->start[kernel][i], t->stop[kernel][i]));
+    tot += ms;
+  }
+  *total_ms = tot; *launches = t->used[kernel];
+  return NMOD_OK;
+}
+
+int nmod_evtimer_destroy(void* timer) {
+  if (!timer) return NMOD_ERR_INVALID_ARG;
+  EvTimer* t = (EvTimer*)timer;
+  for (int k = 0; k < NMOD_KERNEL_COUNT; ++k)
+    for (int i = 0; i < t->capacity; ++i) { hipEventDestroy(t->start[k][i]); hipEventDestroy(t->stop[k][i]); }
+  delete t;
+  return NMOD_OK;
+}
+
+int nmod_selftest(int32_t device) {
+  if (nmod_device_count() <= device || device < 0) return NMOD_ERR_NO_DEVICE;
+  NMOD_HIP(hipSetDevice(device));
+  const int NP = 18;
+  int* d; std::vector<int> h(64 * NP);
+  NMOD_HIP(hipMalloc(&d, 64 * NP * 4));
+  hipLaunchKernelGGL(selftest_perm_kernel, dim3(1), dim3(64), 0, 0, d);
+  NMOD_HIP(hipMemcpy(h.data(), d, 64 * NP * 4, hipMemcpyDeviceToHost));
+  hipFree(d);
+  int scan_in[64], run = 0, mx = 0;
+  for (int l = 0; l < 64; ++l) { scan_in[l] = (l * 37) % 64 == 5 ? 1000 : (l * 7) % 23; mx = std::max(mx, (l * 29) % 61); }
+  unsigned long long tot = 0; double ftot = 0;
+  for (int l = 0; l < 64; ++l) { tot += (unsigned long long)l * 3ull + (1ull << 33); ftot += 0.5 * l; }
+  for (int l = 0; l < 64; ++l) {
+    run = std::max(run, scan_in[l]);
+    const int expect[NP] = {l ^ 1, l ^ 2, l ^ 4, l ^ 8, l ^ 16, l ^ 1, l ^ 3, l ^ 7, l ^ 15, l ^ 31, l ^ 63,
+                            l == 0 ? -1 : l - 1, l == 63 ? -1 : l + 1, run, mx, (int)(unsigned)tot, (int)(tot >> 32), (int)ftot};
+    for (int k = 0; k < NP; ++k) if (h[64 * k + l] != expect[k]) return 1 + k;
+  }
+  int rc;
+  if ((rc = selftest_sort<1>(100)) != NMOD_OK) return rc;
+  if ((rc = selftest_sort<2>(110)) != NMOD_OK) return rc;
+  if ((rc = selftest_sort<4>(120)) != NMOD_OK) return rc;
+  if ((rc = selftest_sort<8>(130)) != NMOD_OK) return rc;
+  if ((rc = selftest_sort<16>(140)) != NMOD_OK) return rc;
+  if ((rc = selftest_sort<32>(150)) != NMOD_OK) return rc;
+  return NMOD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+// K2 (finalize) and K3 (window combine): one thread per genomic position, fp64.
+//
+// K2 turns K1's exact integers / moments into the (stat, p) pairs getKStest
+// returns (myDetect.py:327-343,363) following the scipy 1.2.1 formulas
+// (SURVEY.md §8a rows A1-A3).  K3 restates get_combin_pvalue
+// (myDetect.py:379-414) over the whole KS track.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "special_math.hpp"
+#include "../../include/nanomod_hip.h"
+
+namespace nmod {
+
+struct FinalizeArgs {
+  int64_t npos;
+  const int64_t* off0; const int64_t* off1;
+  int64_t stride0, stride1;
+  const uint32_t* ks_num; const uint64_t* mwu_s; const uint64_t* tie; const double* moments;
+  int32_t tests; int32_t want_mstd;
+  int64_t max_n0, max_n1;               // capacity of the largest size class launched
+  nmod_out out;
+};
+
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.npos) return;
+  const int64_t n0 = a.stride0 > 0 ? a.stride0 : a.off0[p + 1] - a.off0[p];
+  const int64_t n1 = a.stride1 > 0 ? a.stride1 : a.off1[p + 1] - a.off1[p];
+  const double nan = __builtin_nan("");
+  unsigned status = 0;
+  const bool too_large = (n0 > a.max_n0 || n1 > a.max_n1);
+  const bool empty = (n0 <= 0 || n1 <= 0) || too_large;    // "empty": nothing was computed by K1
+  if (n0 <= 0 || n1 <= 0) status |= NMOD_STATUS_EMPTY;
+  if (too_large) status |= NMOD_STATUS_TOO_LARGE;
+  const double dn0 = (double)n0, dn1 = (double)n1;
+  const double prod = dn0 * dn1;
+
+  if (a.tests & NMOD_TEST_KS) {
+    double d = nan, pv = nan;
+    if (!empty) {
+      // ks_2samp (scipy 1.2.1): d = max|cdf1 - cdf2|; en = sqrt(n1*n2/float(n1+n2));
+      // prob = kstwobign.sf((en + 0.12 + 0.11/en) * d)
+      d = (double)a.ks_num[p] / prod;
+      double en = sqrt(prod / (double)(n0 + n1));
+      pv = kolmogorov_sf((en + 0.12 + 0.11 / en) * d);
+    }
+    if (a.out.ks_d) a.out.ks_d[p] = clamp_stat(d);
+    if (a.out.ks_p) a.out.ks_p[p] = clamp_p(pv);
+  }
+
+  if (a.tests & NMOD_TEST_MWU) {
+    double u = nan, pv = nan;
+    if (!empty) {
+      // mannwhitneyu(x, y, use_continuity=True, alternative=None) of scipy 1.2.1
+      double u1 = prod - 0.5 * (double)a.mwu_s[p];      // n1*n2 + n1(n1+1)/2 - sum(rank x)
+      double u2 = prod - u1;
+      double size = (double)(n0 + n1);
+      double T = (size < 2.0) ? 1.0 : 1.0 - (double)a.tie[p] / (size * size * size - size);
+      if (T == 0.0) {
+        status |= NMOD_STATUS_MWU_ALL_IDENTICAL;          // the reference raises here
+      } else {
+        double sd = sqrt(T * dn0 * dn1 * (double)(n0 + n1 + 1) / 12.0);
+        double meanrank = prod / 2.0 + 0.5;
+        double bigu = fmax(u1, u2);
+        double z = (bigu - meanrank) / sd;
+        pv = norm_sf(fabs(z));
+        u = fmin(u1, u2);
+      }
+    }
+    if (a.out.mwu_u) a.out.mwu_u[p] = clamp_stat(u);
+    if (a.out.mwu_p) a.out.mwu_p[p] = clamp_p(pv);
+  }
+
+  if ((a.tests & NMOD_TEST_WELCH) || a.want_mstd) {
+    const double* mo = a.moments + p * 4;
+    double mean0 = nan, m20 = nan, mean1 = nan, m21 = nan;
+    if (!empty) { mean0 = mo[0]; m20 = mo[1]; mean1 = mo[2]; m21 = mo[3]; }
+    if (a.tests & NMOD_TEST_WELCH) {
+      double t = nan, pv = nan;
+      if (!empty) {
+        // ttest_ind(equal_var=False): _unequal_var_ttest_denom + _ttest_finish
+        double v1 = m20 / (dn0 - 1.0), v2 = m21 / (dn1 - 1.0);
+        double vn1 = v1 / dn0, vn2 = v2 / dn1;
+        double df = (vn1 + vn2) * (vn1 + vn2) / (vn1 * vn1 / (dn0 - 1.0) + vn2 * vn2 / (dn1 - 1.0));
+        if (df != df) df = 1.0;
+        double denom = sqrt(vn1 + vn2);
+        t = (mean0 - mean1) / denom;
+        pv = student_t_two_sided(t, df);
+      }
+      if (pv != pv) status |= NMOD_STATUS_T_NAN;
+      if (a.out.t_t) a.out.t_t[p] = clamp_stat(t);
+      if (a.out.t_p) a.out.t_p[p] = clamp_p(pv);
+    }
+    if (a.want_mstd) {
+      if (a.out.mean0) a.out.mean0[p] = mean0;
+      if (a.out.std0) a.out.std0[p] = sqrt(m20 / dn0);      // np.std, ddof = 0
+      if (a.out.mean1) a.out.mean1[p] = mean1;
+      if (a.out.std1) a.out.std1[p] = sqrt(m21 / dn1);
+    }
+  }
+  if (a.out.status) a.out.status[p] = (uint8_t)status;
+}
+
+// ---------------------------------------------------------------------------
+constexpr int kCombineTile = 256;
+
+struct CombineArgs {
+  int64_t npos;
+  const double* ks_d; const double* ks_p; const int32_t* run_id;
+  double* comb_st; double* comb_p;
+  int32_t nb; int32_t method;
+  double wnorm;                         // ||w||_2
+  double w[2 * NMOD_MAX_NB + 1];        // Stouffer weights, w[nb] = 100 (myDetect.py:396-400)
+};
+
+__global__ __launch_bounds__(kCombineTile) void combine_kernel(CombineArgs a) {
+  // per-position transform of the KS p-value (z = isf(p) or ln p), tile + halo
+  __shared__ double tr[kCombineTile + 2 * NMOD_MAX_NB];
+  const int nb = a.nb;
+  const int64_t tile0 = (int64_t)blockIdx.x * kCombineTile;
+  const int t = threadIdx.x;
+  const bool stouffer = a.method == NMOD_METHOD_STOUFFER;
+  auto transform = [&](int64_t j) -> double {
+    double pj = a.ks_p[j];
+    return stouffer ? norm_isf(pj) : log(pj);
+  };
+  const int64_t p = tile0 + t;
+  if (nb == 0) {                                  // myDetect.py:413: the KS tuple itself
+    if (p < a.npos) { a.comb_st[p] = a.ks_d[p]; a.comb_p[p] = a.ks_p[p]; }
+    return;
+  }
+  if (p < a.npos) tr[nb + t] = transform(p);
+  if (t < 2 * nb) {
+    int64_t j = (t < nb) ? tile0 - nb + t : tile0 + kCombineTile + (t - nb);
+    int slot = (t < nb) ? t : kCombineTile + t;
+    if (j >= 0 && j < a.npos) tr[slot] = transform(j);
+  }
+  __syncthreads();
+  if (p >= a.npos) return;
+  const int32_t rid = a.run_id[p];
+  // window = [p_KS[j] if usable else 1.0]  (myDetect.py:383-389); isf(1) = -inf, ln(1) = 0
+  const double pad = stouffer ? -__builtin_inf() : 0.0;
+  double acc = 0.0;
+  for (int k = -nb; k <= nb; ++k) {
+    int64_t j = p + k;
+    bool ok = (j >= 0) && (j < a.npos);
+    if (ok) ok = (a.run_id[j] == rid);
+    double v = ok ? tr[nb + t + k] : pad;
+    acc += stouffer ? a.w[nb + k] * v : v;
+  }
+  double st, pv;
+  if (stouffer) {
+    st = acc / a.wnorm;                 // Z = dot(w, Zi) / ||w||
+    pv = norm_sf(st);
+  } else {
+    st = -2.0 * acc;                    // Xsq = -2 sum(log p)
+    pv = chi2_sf_even(st, 2 * nb + 1);
+  }
+  a.comb_p[p] = clamp_p(pv);
+  a.comb_st[p] = clamp_stat(st);
+}
+
+// ---------------------------------------------------------------------------
+// K5 synthetic two-group signal generator (include/nanomod_hip.h: nmod_synth_fill)
+__device__ __forceinline__ uint64_t synth_mix(uint64_t seed, int64_t pos, int32_t group, uint32_t read) {
+  uint64_t x = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(pos * 2 + group);
+  x ^= (uint64_t)read * 0xD1B54A32D192ED03ull;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+struct SynthArgs {
+  uint64_t seed; int64_t pos_begin; int64_t npos; int32_t group; int32_t n_per_pos;
+  int64_t plant_period; float plant_shift; int32_t dtype; void* out;
+};
+
+__global__ __launch_bounds__(256) void synth_kernel(SynthArgs a) {
+  const int64_t total = a.npos * (int64_t)a.n_per_pos;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    int64_t rel = idx / a.n_per_pos;
+    uint32_t read = (uint32_t)(idx - rel * a.n_per_pos);
+    int64_t pos = a.pos_begin + rel;
+    uint64_t h = synth_mix(a.seed, pos, a.group, read);
+    int s = (int)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + (h >> 48));
+    float x = __fmul_rn((float)(s - 131070), 2.6428997e-05f);
+    if (a.group == 1 && a.plant_period > 0) {
+      int64_t m = pos % a.plant_period;
+      if (m == 0 || m == 1 || m == a.plant_period - 1) x = __fadd_rn(x, a.plant_shift);
+    }
+    if (a.dtype == NMOD_DTYPE_F32) reinterpret_cast<float*>(a.out)[idx] = x;
+    else reinterpret_cast<int16_t*>(a.out)[idx] = (int16_t)rintf(__fmul_rn(x, 1000.0f));
+  }
+}
+
+}  // namespace nmod

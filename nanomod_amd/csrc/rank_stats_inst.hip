@@ -1,0 +1,66 @@
+// Instantiates K1 for every (R0, R1) size class of one (dtype, tests) pair.
+// Built four times by the Makefile: -DNMOD_INST_DTYPE={0,1} -DNMOD_INST_ALL={0,1}.
+#include "rank_stats.hpp"
+#include "rank_stats_launch.hpp"
+
+#ifndef NMOD_INST_DTYPE
+#error "define NMOD_INST_DTYPE and NMOD_INST_ALL"
+#endif
+
+namespace nmod {
+
+namespace {
+constexpr int DT = NMOD_INST_DTYPE;
+constexpr bool ALL = NMOD_INST_ALL != 0;
+using KernelFn = void (*)(RankStatsArgs);
+
+template <int C0, int C1>
+constexpr KernelFn kernel_of() { return rank_stats_kernel<(1 << C0), (1 << C1), DT, ALL, ALL>; }
+
+template <int C0>
+KernelFn pick1(int c1) {
+  switch (c1) {
+    case 0: return kernel_of<C0, 0>();
+    case 1: return kernel_of<C0, 1>();
+    case 2: return kernel_of<C0, 2>();
+    case 3: return kernel_of<C0, 3>();
+    case 4: return kernel_of<C0, 4>();
+    default: return kernel_of<C0, 5>();
+  }
+}
+KernelFn pick(int c0, int c1) {
+  switch (c0) {
+    case 0: return pick1<0>(c1);
+    case 1: return pick1<1>(c1);
+    case 2: return pick1<2>(c1);
+    case 3: return pick1<3>(c1);
+    case 4: return pick1<4>(c1);
+    default: return pick1<5>(c1);
+  }
+}
+}  // namespace
+
+#define NMOD_CAT2(a, b) a##b
+#define NMOD_CAT(a, b) NMOD_CAT2(a, b)
+#define NMOD_LAUNCH_NAME NMOD_CAT(NMOD_CAT(launch_rank_stats_d, NMOD_INST_DTYPE), NMOD_CAT(_a, NMOD_INST_ALL))
+
+hipError_t NMOD_LAUNCH_NAME(int c0, int c1, int num_cus, int64_t work_items, hipStream_t stream,
+                            const RankStatsArgs& args) {
+  KernelFn fn = pick(c0, c1);
+  const size_t lds = rank_stats_lds_bytes(c0, c1, ALL);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  int per_cu = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kWavesPerBlock, lds);
+  if (e != hipSuccess) return e;
+  if (per_cu < 1) per_cu = 1;
+  int64_t blocks = (work_items + kWavesPerBlock - 1) / kWavesPerBlock;
+  int64_t cap = (int64_t)num_cus * per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream, args);
+  return hipGetLastError();
+}
+
+}  // namespace nmod

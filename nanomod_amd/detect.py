@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Same names, argument meaning and error behaviour as
+/root/reference/bin/scripts/myDetect.py:301-545 — `mfilter_coverage`,
+`m_min_float`, `m_max_float`, `getKStest`, `pos_check`, `combin_pvalues`,
+`get_combin_pvalue`, `mtest2`, `save_test` — so a caller holding the reference's
+`moptions` dict can switch modules.  The arithmetic runs in the HIP library
+(nanomod_amd/libnanomod_hip.so) through the C ABI; there is no CPU fallback.
+
+`moptions` keys read (as the reference): 'ds2', <dataset>['norm_mean'|'base'|
+'basedict'][(chrom,strand)][pos], 'MinCoverage', 'neighborPvalues',
+'WeightsDif', 'testMethod', 'rankUse', 'SaveTest', 'outFolder', 'FileID',
+'mstd', 'coverages', 'RegionRankbyST', 'outLevel'.
+Keys written: 'sign_test', 'sorted_sign_test', optionally 'sign_test_mstd',
+plus 'sign_test_arrays' (the same numbers as numpy arrays, an addition).
+"""
+from __future__ import annotations
+
+import sys
+import time
+
+import numpy as np
+
+from . import _lib as L
+from . import engine
+
+OUTPUT_DEBUG, OUTPUT_INFO, OUTPUT_WARNING, OUTPUT_ERROR = 0, 1, 2, 3   # myCom.py:5-8
+
+
+# myDetect.py:317-325
+def m_min_float(fv):
+    if fv < sys.float_info.min:
+        return sys.float_info.min
+    return fv
+
+
+def m_max_float(fv):
+    if fv > sys.float_info.max:
+        return sys.float_info.max
+    return fv
+
+
+# myDetect.py:301-314
+def mfilter_coverage(moptions):
+    for dsn in moptions['ds2']:
+        curds = moptions[dsn]['norm_mean']
+        for sk in sorted(curds.keys()):
+            for pk in sorted(curds[sk].keys()):
+                if len(curds[sk][pk]) < moptions['MinCoverage']:
+                    del curds[sk][pk]
+                    del moptions[dsn]['base'][sk][pk]
+            if len(curds[sk]) == 0:
+                del curds[sk]
+                del moptions[dsn]['base'][sk]
+
+
+# ---------------------------------------------------------------------------
+def encode_signals(values):
+    """Pick the device dtype for a float64 sample vector without changing a
+    single value the reference would see: float32 if every value is
+    float32-exact, else int16 milli-units if every value is k/1000.0 (NanoMod's
+    Events are 3-dp rounded, myRefBaseSignalAnnotation.py:1108)."""
+    v = np.asarray(values, dtype=np.float64)
+    f32 = v.astype(np.float32)
+    if np.array_equal(f32.astype(np.float64), v):
+        return f32
+    k = np.rint(v * 1000.0)
+    if np.all(np.abs(k) <= 32767) and np.array_equal(k / 1000.0, v):
+        return k.astype(np.int16)
+    raise ValueError('signal values are neither float32-exact nor on the 0.001 grid; '
+                     'the fp64-key path is not implemented (DESIGN.md, out of scope)')
+
+
+def _coverage_threshold(moptions, m_str):
+    cov = moptions.get('coverages', (0, 0))
+    return int(cov[0 if m_str == '+' else 1])
+
+
+# myDetect.py:327-363
+def getKStest(moptions, a, b, m_str):
+    cov = _coverage_threshold(moptions, m_str)
+    if not (cov <= 0 or (len(a) <= cov and len(b) <= cov)):
+        raise NotImplementedError('the unseeded down-sampling branch (myDetect.py:345-361) is outside '
+                                  'the parity contract (SURVEY.md §8a row A3\')')
+    both = encode_signals(np.concatenate([np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)]))
+    sig0, sig1 = both[:len(a)], both[len(a):]
+    off0 = np.array([0, len(a)], dtype=np.int64)
+    off1 = np.array([0, len(b)], dtype=np.int64)
+    r = engine.detect_host(sig0, off0, sig1, off1, np.zeros(1, np.int32), method='ks',
+                           device=moptions.get('nmod_device', 0))
+    if r['status'][0] & L.STATUS_MWU_ALL_IDENTICAL:
+        raise ValueError('All numbers are identical in mannwhitneyu')      # scipy 1.2.1 behaviour
+    return [(float(r['mwu_u'][0]), float(r['mwu_p'][0])), (float(r['t_t'][0]), float(r['t_p'][0])),
+            (float(r['ks_d'][0]), float(r['ks_p'][0]))]
+
+
+# myDetect.py:366-371
+def pos_check(mlist, i, j):
+    if j < 0 or j > len(mlist) - 1:
+        return False
+    if i == j or (mlist[i][0][0] == mlist[j][0][0] and mlist[i][0][1] == mlist[j][0][1]
+                  and i - j == mlist[i][0][2] - mlist[j][0][2]):
+        return True
+    return False
+
+
+def run_ids(chroms, strands, positions):
+    """run_id[i] == run_id[j]  <=>  pos_check holds for every pair between i and j:
+    same chrom, same strand, consecutive positions."""
+    n = len(positions)
+    rid = np.zeros(n, dtype=np.int32)
+    if n == 0:
+        return rid
+    pos = np.asarray(positions, dtype=np.int64)
+    brk = np.ones(n, dtype=bool)
+    same = (pos[1:] - pos[:-1] == 1)
+    chroms = np.asarray(chroms)
+    strands = np.asarray(strands)
+    same &= (chroms[1:] == chroms[:-1]) & (strands[1:] == strands[:-1])
+    brk[1:] = ~same
+    return (np.cumsum(brk) - 1).astype(np.int32)
+
+
+def _sign_test_track(moptions):
+    st = moptions['sign_test']
+    ks_d = np.array([r[1][2][0] for r in st], dtype=np.float64)
+    ks_p = np.array([r[1][2][1] for r in st], dtype=np.float64)
+    rid = run_ids([r[0][0] for r in st], [r[0][1] for r in st], [r[0][2] for r in st])
+    return ks_d, ks_p, rid
+
+
+# myDetect.py:379-414
+def get_combin_pvalue(moptions, i):
+    if moptions['neighborPvalues'] > 0 and len(moptions['sign_test']) > 0:
+        if moptions['testMethod'] not in ('fisher', 'stouffer'):
+            raise UnboundLocalError("local variable 'comb_p_p' referenced before assignment")   # as the reference
+        nb = moptions['neighborPvalues']
+        st = moptions['sign_test']
+        # window = [p_KS[j] if usable else 1.0]  (myDetect.py:383-389), sent as one tiny track
+        win = [st[j][1][2][1] if (0 <= j <= len(st) - 1 and pos_check(st, i, j)) else 1.0
+               for j in range(i - nb, i + nb + 1)]
+        cst, cp = engine.combine_host(np.zeros(len(win)), np.array(win), np.zeros(len(win), np.int32), nb=nb,
+                                      weights_dif=moptions['WeightsDif'], method=moptions['testMethod'],
+                                      device=moptions.get('nmod_device', 0))
+        return (float(cst[nb]), float(cp[nb]))
+    if moptions['neighborPvalues'] == 0:
+        return moptions['sign_test'][i][1][2]
+    return None
+
+
+# myDetect.py:373-377 (whole track in one launch instead of one call per position)
+def combin_pvalues(moptions):
+    st = moptions['sign_test']
+    if len(st) == 0:
+        return
+    nb = moptions['neighborPvalues']
+    if nb == 0:
+        for r in st:
+            r[1].append(r[1][2])
+        return
+    if nb < 0:
+        return
+    ks_d, ks_p, rid = _sign_test_track(moptions)
+    cst, cp = engine.combine_host(ks_d, ks_p, rid, nb=nb, weights_dif=moptions['WeightsDif'],
+                                  method=moptions['testMethod'], device=moptions.get('nmod_device', 0))
+    for r, s, p in zip(st, cst.tolist(), cp.tolist()):
+        r[1].append((s, p))
+
+
+# ---------------------------------------------------------------------------
+def build_csr(moptions):
+    """The tested-position set and order of mtest2 (myDetect.py:421,427-431) as CSR arrays."""
+    ds0 = moptions[moptions['ds2'][0]]
+    ds1 = moptions[moptions['ds2'][1]]
+    meta = []
+    chunks0, chunks1 = [], []
+    for sk in sorted(ds0['norm_mean'].keys()):
+        if sk not in ds1['norm_mean']:
+            continue
+        d0, d1 = ds0['norm_mean'][sk], ds1['norm_mean'][sk]
+        for pk in sorted(d0.keys()):
+            if pk not in d1:
+                continue
+            b1, b0 = ds1['base'][sk][pk], ds0['base'][sk][pk]
+            if not b1 == b0 and moptions.get('outLevel', OUTPUT_ERROR) <= OUTPUT_ERROR:
+                print('Error not equal', sk, pk, b1, b0)
+            a, b = d0[pk], d1[pk]
+            meta.append((sk[0], sk[1], pk, b1, len(a), len(b)))
+            chunks0.append(np.asarray(a, dtype=np.float64))
+            chunks1.append(np.asarray(b, dtype=np.float64))
+    npos = len(meta)
+    off0 = np.zeros(npos + 1, dtype=np.int64)
+    off1 = np.zeros(npos + 1, dtype=np.int64)
+    if npos:
+        off0[1:] = np.cumsum([m[4] for m in meta])
+        off1[1:] = np.cumsum([m[5] for m in meta])
+        both = encode_signals(np.concatenate(chunks0 + chunks1))
+        sig0, sig1 = both[:off0[-1]], both[off0[-1]:]
+    else:
+        sig0 = sig1 = np.zeros(0, dtype=np.float32)
+    rid = run_ids([m[0] for m in meta], [m[1] for m in meta], [m[2] for m in meta])
+    return meta, sig0, off0, sig1, off1, rid
+
+
+# myDetect.py:416-462
+def mtest2(moptions):
+    if moptions.get('RegionRankbyST', 0) != 0:
+        raise NotImplementedError('RegionRankbyST ranking (myDetect.py:463-515) is a "next" row (SURVEY.md §8f)')
+    cov = moptions.get('coverages', (0, 0))
+    if int(cov[0]) > 0 or int(cov[1]) > 0:
+        raise NotImplementedError('down-sampling KS (myDetect.py:345-361) is outside the parity contract')
+    print("Start sorting")
+    meta, sig0, off0, sig1, off1, rid = build_csr(moptions)
+    method = moptions['testMethod']
+    nb = moptions['neighborPvalues']
+    want_mstd = not moptions.get('mstd', 0) == 0
+    start_time = time.time()
+    # the combine is skipped for 'ks' (myDetect.py:443); for nb == 0 it returns the KS tuple (:413)
+    dev_method = method if (method in ('stouffer', 'fisher') and nb > 0) else 'ks'
+    if method not in ('ks', 'stouffer', 'fisher') and nb > 0 and len(meta) > 0:
+        raise UnboundLocalError("local variable 'comb_p_p' referenced before assignment")       # as the reference
+    res = engine.detect_host(sig0, off0, sig1, off1, rid, nb=max(nb, 0), weights_dif=moptions.get('WeightsDif', 2.0),
+                             method=dev_method, want_mstd=want_mstd, device=moptions.get('nmod_device', 0))
+    if len(meta) and np.any(res['status'] & L.STATUS_MWU_ALL_IDENTICAL):
+        raise ValueError('All numbers are identical in mannwhitneyu')                             # scipy 1.2.1, uncaught in the reference
+    cols = [res[k].tolist() for k in ('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p')]
+    sign_test = [(m, [(u, pu), (t, pt), (d, pk)]) for m, u, pu, t, pt, d, pk in zip(meta, *cols)]
+    moptions['sign_test'] = sign_test
+    if want_mstd:
+        moptions['sign_test_mstd'] = {
+            (m[0], m[1], m[2]): [[m0, s0], [m1, s1]]
+            for m, m0, s0, m1, s1 in zip(meta, res['mean0'].tolist(), res['std0'].tolist(),
+                                         res['mean1'].tolist(), res['std1'].tolist())}
+    end_time = time.time()
+    if moptions.get('outLevel', OUTPUT_ERROR) <= OUTPUT_INFO:
+        print("Producing pvalues: consuming time %d" % (end_time - start_time))
+
+    if not method == "ks":
+        if nb > 0:
+            for r, s, p in zip(sign_test, res['comb_st'].tolist(), res['comb_p'].tolist()):
+                r[1].append((s, p))
+        elif nb == 0:
+            for r in sign_test:
+                r[1].append(r[1][2])
+    moptions['sign_test_arrays'] = res
+
+    use_pind = 1 if moptions.get('rankUse', 'pv') == 'pv' else 0
+    sorted_ind = 2 if method == "ks" else 3
+    save_test(moptions)
+    if method != 'ks' and nb < 0:
+        raise IndexError('list index out of range')            # the reference indexes mpv[1][3] here
+    moptions['sorted_sign_test'] = sorted(
+        sign_test, key=lambda mpv: (mpv[1][sorted_ind][use_pind], mpv[1][2][use_pind], mpv[1][0][use_pind]))
+    if use_pind == 0:
+        moptions['sorted_sign_test'] = moptions['sorted_sign_test'][::-1]
+
+
+# myDetect.py:522-545
+def save_test(moptions):
+    print('SaveTest', moptions['SaveTest'])
+    if moptions['SaveTest'] == 0:
+        return
+    print('Finish SaveTest')
+    txtfile = moptions['outFolder'] + '/' + moptions["FileID"] + '_sign_test.txt'
+    if moptions.get('outLevel', OUTPUT_ERROR) <= OUTPUT_ERROR:
+        print('Test data is saved in', txtfile)
+    with_comb = moptions["neighborPvalues"] > 0 and (not moptions["testMethod"] == "ks")
+    with open(txtfile, 'w') as txtwriter:
+        for mostp in moptions['sign_test']:
+            line = '%s %s %d %s %d %d %.3f %.3E %.3f %.3E %.3f %.3E' % (
+                mostp[0][0], mostp[0][1], mostp[0][2] + 1, mostp[0][3], mostp[0][4], mostp[0][5],
+                mostp[1][0][0], mostp[1][0][1], mostp[1][1][0], mostp[1][1][1], mostp[1][2][0], mostp[1][2][1])
+            if with_comb:
+                line += ' %.3f %.3E\n' % (mostp[1][3][0], mostp[1][3][1])
+            else:
+                line += '\n'
+            txtwriter.write(line)
+    if not moptions.get('mstd', 0) == 0:
+        with open(moptions['outFolder'] + '/' + moptions["FileID"] + '_meanstd.cvs', 'w') as mw:
+            for mostp in moptions['sign_test']:
+                _t_k = (mostp[0][0], mostp[0][1], mostp[0][2])
+                ms = moptions['sign_test_mstd'][_t_k]
+                mw.write("%s %s %d %s %.3f %.3f %.3f %.3f\n" % (
+                    mostp[0][0], mostp[0][1], mostp[0][2], mostp[0][3], ms[0][0], ms[0][1], ms[1][0], ms[1][1]))

@@ -1,0 +1,215 @@
+"""Batch entry points over the C ABI.
+
+`detect_host`   — numpy arrays in host memory (the drop-in `mtest2` path uses it).
+`detect_device` — torch tensors already resident in HBM (bench / sharded path);
+                  torch is used only for device memory and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _check_csr(off, npos, name):
+    if off is None:
+        return
+    if off.dtype != np.int64 or off.ndim != 1 or off.shape[0] != npos + 1:
+        raise ValueError('%s must be int64[npos+1]' % name)
+
+
+def detect_host(sig0, off0, sig1, off1, run_id, *, nb=2, weights_dif=2.0, method='stouffer',
+                tests=L.TEST_ALL, want_mstd=False, device=0, stride0=0, stride1=0):
+    """Run the hot path on host-resident CSR inputs; returns a dict of numpy arrays.
+
+    sig0/sig1: float32 (canonical) or int16 (milli-units) 1-D arrays; off0/off1:
+    int64[npos+1] (or None with a fixed stride); run_id: int32[npos]."""
+    lib = L.load()
+    sig0 = np.ascontiguousarray(sig0)
+    sig1 = np.ascontiguousarray(sig1)
+    if sig0.dtype != sig1.dtype or sig0.dtype not in (np.float32, np.int16):
+        raise ValueError('sig0/sig1 must both be float32 or both int16 (milli-units)')
+    dtype = L.DTYPE_F32 if sig0.dtype == np.float32 else L.DTYPE_I16_MILLI
+    if off0 is not None:
+        npos = len(off0) - 1
+    elif off1 is not None:
+        npos = len(off1) - 1
+    else:
+        npos = sig0.shape[0] // stride0
+    off0 = None if off0 is None else np.ascontiguousarray(off0, dtype=np.int64)
+    off1 = None if off1 is None else np.ascontiguousarray(off1, dtype=np.int64)
+    _check_csr(off0, npos, 'off0')
+    _check_csr(off1, npos, 'off1')
+    method_id = L.METHOD_BY_NAME[method] if isinstance(method, str) else method
+    run = None
+    if run_id is not None:
+        run = np.ascontiguousarray(run_id, dtype=np.int32)
+        if run.shape[0] != npos:
+            raise ValueError('run_id must be int32[npos]')
+    prm = L.make_params(device=device, memspace=L.MEM_HOST, dtype=dtype, tests=tests, method=method_id,
+                        nb=nb, weights_dif=weights_dif, want_mstd=int(bool(want_mstd)),
+                        stride0=stride0 if off0 is None else 0, stride1=stride1 if off1 is None else 0)
+    res = {}
+    out = L.NmodOut()
+    wanted = []
+    if tests & L.TEST_MWU:
+        wanted += ['mwu_u', 'mwu_p']
+    if tests & L.TEST_WELCH:
+        wanted += ['t_t', 't_p']
+    if (tests & L.TEST_KS) or method_id != L.METHOD_KS:
+        wanted += ['ks_d', 'ks_p']
+    if method_id != L.METHOD_KS:
+        wanted += ['comb_st', 'comb_p']
+    if want_mstd:
+        wanted += ['mean0', 'std0', 'mean1', 'std1']
+    for name in wanted:
+        res[name] = np.full(npos, np.nan, dtype=np.float64)
+        setattr(out, name, _np_ptr(res[name]))
+    res['status'] = np.zeros(npos, dtype=np.uint8)
+    out.status = _np_ptr(res['status'])
+    rc = lib.nmod_detect_batch(C.byref(prm), npos, _np_ptr(sig0), _np_ptr(off0), _np_ptr(sig1), _np_ptr(off1),
+                               _np_ptr(run), None, 0, C.byref(out))
+    L.check(rc, 'nmod_detect_batch')
+    return res
+
+
+def combine_host(ks_d, ks_p, run_id, *, nb=2, weights_dif=2.0, method='stouffer', device=0):
+    lib = L.load()
+    ks_p = np.ascontiguousarray(ks_p, dtype=np.float64)
+    ks_d = np.ascontiguousarray(ks_d, dtype=np.float64)
+    run = np.ascontiguousarray(run_id, dtype=np.int32)
+    npos = ks_p.shape[0]
+    method_id = L.METHOD_BY_NAME[method] if isinstance(method, str) else method
+    prm = L.make_params(device=device, memspace=L.MEM_HOST, method=method_id, nb=nb, weights_dif=weights_dif)
+    st = np.empty(npos, dtype=np.float64)
+    pv = np.empty(npos, dtype=np.float64)
+    rc = lib.nmod_combine_track(C.byref(prm), npos, _np_ptr(ks_d), _np_ptr(ks_p), _np_ptr(run), _np_ptr(st), _np_ptr(pv))
+    L.check(rc, 'nmod_combine_track')
+    return st, pv
+
+
+class EventTimer:
+    """HIP-event timer handle (nmod_evtimer_*): per-kernel elapsed ms measured on the launch stream."""
+
+    def __init__(self, capacity=4096):
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        L.check(self._lib.nmod_evtimer_create(capacity, C.byref(self._h)), 'nmod_evtimer_create')
+
+    @property
+    def handle(self):
+        return self._h
+
+    def reset(self):
+        L.check(self._lib.nmod_evtimer_reset(self._h), 'nmod_evtimer_reset')
+
+    def read(self, kernel):
+        ms = C.c_double()
+        n = C.c_int32()
+        L.check(self._lib.nmod_evtimer_read(self._h, kernel, C.byref(ms), C.byref(n)), 'nmod_evtimer_read')
+        return ms.value, n.value
+
+    def close(self):
+        if self._h:
+            self._lib.nmod_evtimer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceDetector:
+    """Device-resident form: inputs and outputs are torch CUDA tensors; nothing is copied
+    and nothing synchronises unless max_n0/max_n1 are unknown for CSR inputs."""
+
+    def __init__(self, device=0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_ALL, want_mstd=False):
+        import torch
+        self.torch = torch
+        self.lib = L.load()
+        self.device = device
+        self.nb = nb
+        self.weights_dif = weights_dif
+        self.method = L.METHOD_BY_NAME[method] if isinstance(method, str) else method
+        self.tests = tests
+        self.want_mstd = bool(want_mstd)
+        self._ws = None
+        self.timer = None
+
+    def _params(self, dtype, stride0, stride1, max_n0, max_n1):
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        return L.make_params(device=self.device, stream=stream, memspace=L.MEM_DEVICE, dtype=dtype,
+                             tests=self.tests, method=self.method, nb=self.nb, weights_dif=self.weights_dif,
+                             want_mstd=int(self.want_mstd), stride0=stride0, stride1=stride1,
+                             max_n0=max_n0, max_n1=max_n1,
+                             timer=self.timer.handle if self.timer is not None else None)
+
+    def _dtype_of(self, t):
+        torch = self.torch
+        if t.dtype == torch.float32:
+            return L.DTYPE_F32
+        if t.dtype == torch.int16:
+            return L.DTYPE_I16_MILLI
+        raise ValueError('signals must be float32 or int16 (milli-units)')
+
+    def workspace(self, prm, npos):
+        need = self.lib.nmod_workspace_bytes(C.byref(prm), npos)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = self.torch.empty(need, dtype=self.torch.uint8, device='cuda:%d' % self.device)
+        return self._ws, need
+
+    def alloc_outputs(self, npos):
+        torch = self.torch
+        dev = 'cuda:%d' % self.device
+        names = []
+        if self.tests & L.TEST_MWU:
+            names += ['mwu_u', 'mwu_p']
+        if self.tests & L.TEST_WELCH:
+            names += ['t_t', 't_p']
+        if (self.tests & L.TEST_KS) or self.method != L.METHOD_KS:
+            names += ['ks_d', 'ks_p']
+        if self.method != L.METHOD_KS:
+            names += ['comb_st', 'comb_p']
+        if self.want_mstd:
+            names += ['mean0', 'std0', 'mean1', 'std1']
+        res = {n: torch.empty(npos, dtype=torch.float64, device=dev) for n in names}
+        res['status'] = torch.empty(npos, dtype=torch.uint8, device=dev)
+        return res
+
+    def run(self, sig0, sig1, run_id, *, off0=None, off1=None, stride0=0, stride1=0, npos=None,
+            max_n0=0, max_n1=0, out=None):
+        """Enqueue the hot path on the current stream.  Either CSR offsets (int64 CUDA tensors)
+        or fixed strides describe the rows.  Returns the dict of output tensors."""
+        dtype = self._dtype_of(sig0)
+        if self._dtype_of(sig1) != dtype:
+            raise ValueError('sig0 and sig1 must share a dtype')
+        if npos is None:
+            npos = (off0.numel() - 1) if off0 is not None else sig0.numel() // stride0
+        prm = self._params(dtype, stride0 if off0 is None else 0, stride1 if off1 is None else 0, max_n0, max_n1)
+        ws, need = self.workspace(prm, npos)
+        res = out if out is not None else self.alloc_outputs(npos)
+        o = L.NmodOut()
+        for name in L.OUT_FIELDS:
+            if name in res:
+                setattr(o, name, res[name].data_ptr())
+        o.status = res['status'].data_ptr()
+        ptr = lambda t: (t.data_ptr() if t is not None else None)
+        rc = self.lib.nmod_detect_batch(C.byref(prm), npos, ptr(sig0), ptr(off0), ptr(sig1), ptr(off1),
+                                        ptr(run_id), ws.data_ptr(), need, C.byref(o))
+        L.check(rc, 'nmod_detect_batch')
+        return res
+
+    def synth_fill(self, out, seed, pos_begin, npos, group, n_per_pos, plant_period=0, plant_shift=0.0):
+        prm = self._params(self._dtype_of(out), 0, 0, 0, 0)
+        rc = self.lib.nmod_synth_fill(C.byref(prm), seed, pos_begin, npos, group, n_per_pos,
+                                      plant_period, plant_shift, out.data_ptr())
+        L.check(rc, 'nmod_synth_fill')
+        return out

@@ -1,0 +1,107 @@
+"""Shared test helpers: fixture loading, the reference-shaped `moptions`, comparisons, and the
+numpy restatement of the device synthetic generator (include/nanomod_hip.h: nmod_synth_fill)."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_inputs(name):
+    return dict(np.load(os.path.join(GOLDEN, name + '_inputs.npz')))
+
+
+def load_expected(name):
+    exp = dict(np.load(os.path.join(GOLDEN, name + '_expected.npz')))
+    with open(os.path.join(GOLDEN, name + '_sign_test.txt')) as f:
+        table = f.read()
+    return exp, table
+
+
+def build_moptions(fx, outdir, file_id, nb, wdif, method, min_cov=5, mstd=0):
+    """The in-memory structure the reference's ReadAllFast5 builds (myDetect.py:562-572,124)."""
+    mo = {'ds2': ['grpA', 'grpB'], 'outLevel': 3, 'mstd': mstd, 'coverages': [0, 0],
+          'downsampling': 100, 'downsampling_quantile': 0.25, 'neighborPvalues': nb, 'WeightsDif': wdif,
+          'testMethod': method, 'rankUse': 'pv', 'SaveTest': 1, 'RegionRankbyST': 0,
+          'outFolder': outdir, 'FileID': file_id, 'MinCoverage': min_cov}
+    for g, ds in enumerate(mo['ds2']):
+        d = {'norm_mean': {}, 'base': {}, 'basedict': {}}
+        sig = fx['sig%d' % g].astype(np.float64)
+        off = fx['off%d' % g]
+        for i in range(len(off) - 1):
+            if off[i + 1] == off[i]:
+                continue
+            sk = (str(fx['chrom'][i]), str(fx['strand'][i]))
+            pk = int(fx['pos'][i])
+            d['norm_mean'].setdefault(sk, {})[pk] = [np.float64(v) for v in sig[off[i]:off[i + 1]]]
+            d['base'].setdefault(sk, {})[pk] = str(fx['base%d' % g][i])
+            d['basedict'].setdefault(sk, {})[pk] = {str(fx['base%d' % g][i]): 1}
+        mo[ds] = d
+    return mo
+
+
+def assert_close_p(got, exp, rel=1e-9, name='p'):
+    got = np.asarray(got, dtype=np.float64)
+    exp = np.asarray(exp, dtype=np.float64)
+    assert got.shape == exp.shape, (name, got.shape, exp.shape)
+    nan_g, nan_e = np.isnan(got), np.isnan(exp)
+    assert np.array_equal(nan_g, nan_e), '%s: NaN pattern differs' % name
+    inf_e = np.isinf(exp)
+    assert np.array_equal(got[inf_e], exp[inf_e]), '%s: infinities differ' % name
+    m = ~(nan_e | inf_e)
+    err = np.abs(got[m] - exp[m])
+    tol = rel * np.abs(exp[m]) + 1e-300
+    bad = err > tol
+    assert not bad.any(), '%s: %d of %d beyond rel %g; worst %g at %d (got %r exp %r)' % (
+        name, bad.sum(), m.sum(), rel, (err / np.maximum(np.abs(exp[m]), 1e-300)).max(),
+        int(np.argmax(err / np.maximum(np.abs(exp[m]), 1e-300))),
+        got[m][np.argmax(err / np.maximum(np.abs(exp[m]), 1e-300))],
+        exp[m][np.argmax(err / np.maximum(np.abs(exp[m]), 1e-300))])
+    # the north-star bar: 1e-6 absolute
+    assert (err <= 1e-6).all()
+
+
+def assert_close_stat(got, exp, rel=1e-12, abs_=4e-16, name='stat'):
+    got = np.asarray(got, dtype=np.float64)
+    exp = np.asarray(exp, dtype=np.float64)
+    nan_e = np.isnan(exp)
+    assert np.array_equal(np.isnan(got), nan_e), '%s: NaN pattern differs' % name
+    inf_e = np.isinf(exp)
+    assert np.array_equal(got[inf_e], exp[inf_e]), '%s: infinities differ' % name
+    m = ~(nan_e | inf_e)
+    err = np.abs(got[m] - exp[m])
+    assert (err <= rel * np.abs(exp[m]) + abs_).all(), '%s: worst abs err %g' % (name, err.max())
+
+
+def compare_outputs(got, exp, with_comb=True, p_rel=1e-9):
+    assert np.array_equal(np.asarray(got['mwu_u']), np.asarray(exp['mwu_u'])), 'MWU U must be exact'
+    assert_close_p(got['mwu_p'], exp['mwu_p'], p_rel, 'mwu_p')
+    assert_close_stat(got['t_t'], exp['t_t'], 1e-11, 1e-15, 't_t')
+    assert_close_p(got['t_p'], exp['t_p'], p_rel, 't_p')
+    assert_close_stat(got['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+    assert_close_p(got['ks_p'], exp['ks_p'], p_rel, 'ks_p')
+    if with_comb:
+        assert_close_stat(got['comb_st'], exp['comb_st'], 1e-9, 1e-12, 'comb_st')
+        assert_close_p(got['comb_p'], exp['comb_p'], p_rel, 'comb_p')
+
+
+# ---- numpy restatement of the device synthetic generator
+def synth_ref(seed, pos_begin, npos, group, n_per_pos, plant_period=0, plant_shift=0.0, dtype='f32'):
+    with np.errstate(over='ignore'):
+        pos = (np.arange(npos, dtype=np.int64) + pos_begin)[:, None]
+        read = np.arange(n_per_pos, dtype=np.uint64)[None, :]
+        x = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (pos * 2 + group).astype(np.uint64)
+        x = x ^ (read * np.uint64(0xD1B54A32D192ED03))
+        x = x ^ (x >> np.uint64(30)); x = x * np.uint64(0xBF58476D1CE4E5B9)
+        x = x ^ (x >> np.uint64(27)); x = x * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    m = np.uint64(0xffff)
+    s = ((x & m) + ((x >> np.uint64(16)) & m) + ((x >> np.uint64(32)) & m) + (x >> np.uint64(48))).astype(np.int64)
+    v = (s - 131070).astype(np.float32) * np.float32(2.6428997e-05)
+    if group == 1 and plant_period > 0:
+        mm = (pos % plant_period)
+        planted = ((mm == 0) | (mm == 1) | (mm == plant_period - 1))
+        v = np.where(planted, v + np.float32(plant_shift), v).astype(np.float32)
+    if dtype == 'i16':
+        return np.rint(v * np.float32(1000.0)).astype(np.int16).reshape(-1)
+    return v.reshape(-1)

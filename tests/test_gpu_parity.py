@@ -1,0 +1,205 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle and the golden fixtures."""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def nm():
+    import nanomod_amd
+    return nanomod_amd
+
+
+def test_selftest_wave_primitives(nm):
+    assert nm._lib.load().nmod_selftest(0) == 0
+
+
+def test_known_answer_anchors(nm):
+    with open(os.path.join(H.GOLDEN, 'kat.json')) as f:
+        kat = json.load(f)
+    mo = {'coverages': [0, 0]}
+    for key in ('KAT-1', 'KAT-2'):
+        got = nm.getKStest(mo, kat[key]['a'], kat[key]['b'], '+')
+        exp = kat[key]['out']
+        assert got[0][0] == exp[0][0]
+        for g, e in zip(got, exp):
+            assert abs(g[0] - e[0]) <= 1e-12 * abs(e[0]) + 4e-16
+            assert abs(g[1] - e[1]) <= 1e-12 * abs(e[1])
+    for method in ('stouffer', 'fisher'):
+        k = kat['KAT-3-' + method]
+        mo = {'neighborPvalues': k['nb'], 'WeightsDif': k['dif'], 'testMethod': method,
+              'sign_test': [(('c', '+', 10 + i, 'A', 5, 5), [(0, 1), (0, 1), (0.1 * i, p)]) for i, p in enumerate(k['ks_p'])]}
+        for i, e in enumerate(k['out']):
+            g = nm.get_combin_pvalue(mo, i)
+            e = [float(v) for v in e]
+            if np.isinf(e[0]):
+                assert g[0] == e[0] and g[1] == e[1]
+            else:
+                assert abs(g[0] - e[0]) <= 1e-12 * abs(e[0]) and abs(g[1] - e[1]) <= 1e-11 * e[1]
+    # all-identical: the reference raises (scipy 1.2.1 mannwhitneyu)
+    with pytest.raises(ValueError, match='All numbers are identical'):
+        nm.getKStest({'coverages': [0, 0]}, [0.25] * 6, [0.25] * 6, '+')
+
+
+CASES = [('g50', 'g50_stouffer', 2, 2.0, 'stouffer'), ('g50', 'g50_fisher', 2, 2.0, 'fisher'),
+         ('g50', 'g50_ks', 2, 2.0, 'ks'), ('ragged', 'ragged_stouffer', 2, 2.0, 'stouffer'),
+         ('ragged', 'ragged_fisher', 2, 2.0, 'fisher'), ('ties', 'ties_stouffer', 2, 2.0, 'stouffer')]
+CASES += [('sweep', 'sweep_nb%d_w%g_%s' % (nb, w, m), nb, w, m)
+          for nb in (0, 1, 2, 3) for w in (1.0, 2.0, 3.0) for m in ('stouffer', 'fisher')
+          if not (m == 'fisher' and w != 2.0)]
+
+
+@pytest.mark.parametrize('inp,name,nb,wdif,method', CASES)
+def test_golden_tables_through_mtest2(nm, inp, name, nb, wdif, method):
+    """mfilter_coverage + mtest2 + save_test on the reference-shaped moptions: same position
+    set and order, same numbers, byte-identical `_sign_test.txt`, same ranking."""
+    fx = H.load_inputs(inp)
+    exp, table = H.load_expected(name)
+    with tempfile.TemporaryDirectory() as out:
+        mo = H.build_moptions(fx, out, name, nb, wdif, method)
+        nm.mfilter_coverage(mo)
+        nm.mtest2(mo)
+        with open(os.path.join(out, name + '_sign_test.txt')) as f:
+            got_table = f.read()
+    st = mo['sign_test']
+    assert [r[0][0] for r in st] == list(exp['chrom']) and [r[0][1] for r in st] == list(exp['strand'])
+    assert [r[0][2] for r in st] == list(exp['pos']) and [r[0][3] for r in st] == list(exp['base'])
+    assert [r[0][4] for r in st] == list(exp['n0']) and [r[0][5] for r in st] == list(exp['n1'])
+    got = {'mwu_u': [r[1][0][0] for r in st], 'mwu_p': [r[1][0][1] for r in st],
+           't_t': [r[1][1][0] for r in st], 't_p': [r[1][1][1] for r in st],
+           'ks_d': [r[1][2][0] for r in st], 'ks_p': [r[1][2][1] for r in st]}
+    with_comb = 'comb_st' in exp
+    if with_comb:
+        got['comb_st'] = [r[1][3][0] for r in st]
+        got['comb_p'] = [r[1][3][1] for r in st]
+    H.compare_outputs(got, exp, with_comb)
+    assert got_table == table
+    index_of = {id(r): i for i, r in enumerate(st)}
+    assert [index_of[id(r)] for r in mo['sorted_sign_test']] == list(exp['sorted_index'])
+
+
+def _random_batch(rng, npos, lo0, hi0, lo1, hi1, grid=False, shift_every=7):
+    ca, cb = [], []
+    for i in range(npos):
+        n0 = int(rng.integers(lo0, hi0 + 1))
+        n1 = int(rng.integers(lo1, hi1 + 1))
+        a = rng.normal(0, 1, n0)
+        b = rng.normal(0.7 if i % shift_every == 0 else 0.0, 1.3, n1)
+        if grid:
+            a, b = np.round(a, 2), np.round(b, 2)
+        ca.append(a.astype(np.float32))
+        cb.append(b.astype(np.float32))
+    off0 = np.zeros(npos + 1, np.int64); off0[1:] = np.cumsum([len(c) for c in ca])
+    off1 = np.zeros(npos + 1, np.int64); off1[1:] = np.cumsum([len(c) for c in cb])
+    rid = (np.arange(npos) // 11).astype(np.int32)
+    return np.concatenate(ca), off0, np.concatenate(cb), off1, rid
+
+
+@pytest.mark.parametrize('sizes', [(5, 64, 5, 64), (65, 128, 3, 30), (129, 256, 129, 256), (300, 512, 20, 256),
+                                   (513, 1024, 40, 70), (1025, 2048, 1025, 2048), (3, 2048, 3, 2048)])
+@pytest.mark.parametrize('grid', [False, True])
+def test_random_batches_vs_oracle(nm, sizes, grid):
+    """every size class (and mixed classes in one batch), continuous and tie-heavy data"""
+    import nanomod_oracle as orc
+    rng = np.random.default_rng(hash((sizes, grid)) % (2 ** 32))
+    npos = 60 if sizes[1] > 1024 else 150
+    sig0, off0, sig1, off1, rid = _random_batch(rng, npos, *sizes, grid=grid)
+    for method in ('stouffer', 'fisher'):
+        got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method=method)
+        exp = orc.detect_batch(sig0, off0, sig1, off1, rid, 2, 2.0,
+                               orc.METHOD_STOUFFER if method == 'stouffer' else orc.METHOD_FISHER)
+        H.compare_outputs(got, exp, True)
+        assert np.array_equal(got['status'], exp['status'])
+
+
+def test_int16_milli_path_matches_float_path(nm):
+    import nanomod_oracle as orc
+    rng = np.random.default_rng(99)
+    sig0, off0, sig1, off1, rid = _random_batch(rng, 200, 5, 300, 5, 300)
+    k0 = np.rint(sig0.astype(np.float64) * 1000).astype(np.int16)
+    k1 = np.rint(sig1.astype(np.float64) * 1000).astype(np.int16)
+    got = nm.detect_host(k0, off0, k1, off1, rid, want_mstd=True)
+    exp = orc.detect_batch(k0 / 1000.0, off0, k1 / 1000.0, off1, rid)
+    H.compare_outputs(got, exp, True)
+    m0 = np.array([np.mean(k0[off0[i]:off0[i + 1]] / 1000.0) for i in range(200)])
+    s1 = np.array([np.std(k1[off1[i]:off1[i + 1]] / 1000.0) for i in range(200)])
+    assert np.allclose(got['mean0'], m0, rtol=1e-12, atol=1e-15) and np.allclose(got['std1'], s1, rtol=1e-12)
+
+
+def test_edge_statuses(nm):
+    L = nm._lib
+    # position 0: all identical; 1: zero variance in both groups but different means; 2: normal; 3: empty group
+    sig0 = np.array([0.5] * 6 + [1.0] * 5 + [0.1, 0.2, 0.3, 0.4, 0.5], dtype=np.float32)
+    off0 = np.array([0, 6, 11, 16, 16], dtype=np.int64)
+    sig1 = np.array([0.5] * 7 + [2.0] * 5 + [0.3, 0.1, 0.9, 0.7, 0.2] + [1.0, 2.0, 3.0], dtype=np.float32)
+    off1 = np.array([0, 7, 12, 17, 20], dtype=np.int64)
+    r = nm.detect_host(sig0, off0, sig1, off1, np.zeros(4, np.int32), method='ks')
+    assert r['status'][0] & L.STATUS_MWU_ALL_IDENTICAL and np.isnan(r['mwu_p'][0])
+    assert r['ks_d'][0] == 0.0 and r['ks_p'][0] == 1.0
+    assert np.isnan(r['t_t'][0]) and np.isnan(r['t_p'][0]) and (r['status'][0] & L.STATUS_T_NAN)
+    assert r['t_t'][1] == -np.inf and r['t_p'][1] == 2.2250738585072014e-308      # m_min_float clamp
+    assert r['ks_d'][1] == 1.0
+    assert r['status'][2] == 0
+    assert r['status'][3] & L.STATUS_EMPTY
+    # more samples than NMOD_MAX_GROUP
+    big = np.zeros(2049, np.float32)
+    with pytest.raises(L.NanomodLibraryError, match='more samples'):
+        nm.detect_host(big, np.array([0, 2049]), big, np.array([0, 2049]), np.zeros(1, np.int32))
+    # empty batch
+    r = nm.detect_host(np.zeros(0, np.float32), np.zeros(1, np.int64), np.zeros(0, np.float32), np.zeros(1, np.int64),
+                       np.zeros(0, np.int32))
+    assert r['ks_p'].shape == (0,)
+
+
+def test_device_resident_path_and_synth(nm):
+    """torch-resident CSR/stride inputs, the device generator against its numpy restatement,
+    the HIP-event timer, and size-independent properties at a larger size."""
+    import torch
+    import nanomod_oracle as orc
+    L = nm._lib
+    dev = 'cuda:0'
+    npos, n = 20000, 200
+    det = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    det.timer = nm.EventTimer(64)
+    sig0 = torch.empty(npos * n, dtype=torch.float32, device=dev)
+    sig1 = torch.empty(npos * n, dtype=torch.float32, device=dev)
+    det.synth_fill(sig0, 20240601, 1000, npos, 0, n, 10000, 0.8)
+    det.synth_fill(sig1, 20240601, 1000, npos, 1, n, 10000, 0.8)
+    torch.cuda.synchronize()
+    assert np.array_equal(sig0.cpu().numpy(), H.synth_ref(20240601, 1000, npos, 0, n, 10000, 0.8))
+    assert np.array_equal(sig1.cpu().numpy(), H.synth_ref(20240601, 1000, npos, 1, n, 10000, 0.8))
+    rid = torch.zeros(npos, dtype=torch.int32, device=dev)
+    res = det.run(sig0, sig1, rid, stride0=n, stride1=n, npos=npos)
+    torch.cuda.synchronize()
+    ms, launches = det.timer.read(L.KERNEL_RANK_STATS)
+    assert launches == 1 and ms > 0
+    # oracle on a sample of positions, including the planted ones (9999, 10000, 10001 -> index 8999..9001)
+    idx = np.r_[0:40, 8990:9010, npos - 40:npos]
+    a = sig0.cpu().numpy().reshape(npos, n)
+    b = sig1.cpu().numpy().reshape(npos, n)
+    ksp = res['ks_p'].cpu().numpy(); ksd = res['ks_d'].cpu().numpy()
+    for i in idx:
+        d, p = orc.ks_2samp(a[i], b[i])
+        assert abs(ksd[i] - d) <= 4.5e-16 and abs(ksp[i] - max(p, 2.2250738585072014e-308)) <= 1e-9 * p
+    assert ksp[8999:9002].max() < 1e-6                      # the planted shift is found
+    st, pv = orc.combine_track(ksd, ksp, np.zeros(npos, np.int32), 2, 2.0, orc.METHOD_STOUFFER)
+    H.assert_close_p(res['comb_p'].cpu().numpy()[idx], pv[idx], 1e-9, 'comb_p')
+    # same data through the CSR entry (binned launch) gives identical bits
+    off = torch.arange(0, (npos + 1) * n, n, dtype=torch.int64, device=dev)
+    res2 = det.run(sig0, sig1, rid, off0=off, off1=off, max_n0=n, max_n1=n)
+    torch.cuda.synchronize()
+    assert torch.equal(res['ks_p'], res2['ks_p']) and torch.equal(res['comb_st'].nan_to_num(neginf=-1e300), res2['comb_st'].nan_to_num(neginf=-1e300))
+    # swap symmetry of D (|F0 - F1| is symmetric) and permutation invariance inside a position
+    res3 = det.run(sig1, sig0, rid, stride0=n, stride1=n, npos=npos)
+    perm = torch.randperm(n, device=dev)
+    sig0p = sig0.view(npos, n)[:, perm].contiguous().view(-1)
+    res4 = det.run(sig0p, sig1, rid, stride0=n, stride1=n, npos=npos)
+    torch.cuda.synchronize()
+    assert torch.equal(res['ks_d'], res3['ks_d']) and torch.equal(res['ks_p'], res4['ks_p'])

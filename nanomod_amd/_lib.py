@@ -74,6 +74,14 @@ def load():
         raise NanomodLibraryError(
             'libnanomod_hip.so not found at %s. Build it with `python -c "import __graft_entry__ as g; '
             'g.build()"` or `make -C nanomod_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and the package
+    # uses torch for device memory and streams, so let torch load its copy first; the loader then
+    # binds our DT_NEEDED libamdhip64.so.7 to that already-loaded object (same SONAME).  Loading in
+    # the other order leaves two runtimes in the process and torch then sees no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete

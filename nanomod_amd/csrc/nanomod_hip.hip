@@ -44,7 +44,7 @@ struct ScopedKernelTimer {
 // ---------------------------------------------------------------- workspace
 struct Workspace {
   uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments;
-  double* tmp_ks_d; double* tmp_ks_p;
+  double* tmp_ks_d; double* tmp_ks_p; double* ks_d_ref;
   int32_t* order; uint8_t* cls; int32_t* meta;     // meta: [0..35] counts, [36..71] offsets, [72..107] cursors, [108..109] max n0/n1
   int64_t bytes;
 };
@@ -64,6 +64,7 @@ static Workspace carve(void* base, int64_t npos) {
   w.moments = (double*)take(32 * npos);
   w.tmp_ks_d = (double*)take(8 * npos);
   w.tmp_ks_p = (double*)take(8 * npos);
+  w.ks_d_ref = (double*)take(8 * npos);
   w.order = (int32_t*)take(4 * npos);
   w.cls = (uint8_t*)take(npos);
   w.meta = (int32_t*)take(kMetaInts * 4);
@@ -238,7 +239,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   memset(&ra, 0, sizeof(ra));
   ra.sig0 = sig0; ra.sig1 = sig1; ra.off0 = off0; ra.off1 = off1;
   ra.stride0 = prm->stride0 > 0 ? prm->stride0 : 0; ra.stride1 = prm->stride1 > 0 ? prm->stride1 : 0;
-  ra.npos = npos; ra.ks_num = ws.ks_num; ra.mwu_s = ws.mwu_s; ra.tie = ws.tie; ra.moments = ws.moments;
+  ra.npos = npos; ra.ks_num = ws.ks_num; ra.mwu_s = ws.mwu_s; ra.tie = ws.tie; ra.moments = ws.moments; ra.ks_d_ref = ws.ks_d_ref;
 
   auto launch = [&](int c0, int c1, int64_t work) -> hipError_t {
     if (prm->dtype == NMOD_DTYPE_F32)
@@ -273,7 +274,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   FinalizeArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.npos = npos; fa.off0 = off0; fa.off1 = off1; fa.stride0 = ra.stride0; fa.stride1 = ra.stride1;
-  fa.ks_num = ws.ks_num; fa.mwu_s = ws.mwu_s; fa.tie = ws.tie; fa.moments = ws.moments;
+  fa.ks_num = ws.ks_num; fa.mwu_s = ws.mwu_s; fa.tie = ws.tie; fa.moments = ws.moments; fa.ks_d_ref = all ? ws.ks_d_ref : nullptr;
   fa.tests = tests; fa.want_mstd = prm->want_mstd; fa.out = *out;
   fa.max_n0 = 64LL << cmax0; fa.max_n1 = 64LL << cmax1;
   if (want_comb) {                       // the combine needs the KS track even if the caller does not

@@ -17,6 +17,7 @@ struct FinalizeArgs {
   const int64_t* off0; const int64_t* off1;
   int64_t stride0, stride1;
   const uint32_t* ks_num; const uint64_t* mwu_s; const uint64_t* tie; const double* moments;
+  const double* ks_d_ref;               // non-null in all-tests mode: the reference's float form of D
   int32_t tests; int32_t want_mstd;
   int64_t max_n0, max_n1;               // capacity of the largest size class launched
   nmod_out out;
@@ -41,7 +42,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     if (!empty) {
       // ks_2samp (scipy 1.2.1): d = max|cdf1 - cdf2|; en = sqrt(n1*n2/float(n1+n2));
       // prob = kstwobign.sf((en + 0.12 + 0.11/en) * d)
-      d = (double)a.ks_num[p] / prod;
+      // KS-only mode: the exact rational, correctly rounded (<= 1 ulp from the float-CDF form)
+      d = a.ks_d_ref ? a.ks_d_ref[p] : (double)a.ks_num[p] / prod;
       double en = sqrt(prod / (double)(n0 + n1));
       pv = kolmogorov_sf((en + 0.12 + 0.11 / en) * d);
     }

@@ -43,6 +43,7 @@ struct RankStatsArgs {
   uint64_t* mwu_s;                             // [npos]  (MWU)
   uint64_t* tie;                               // [npos]  (MWU)
   double* moments;                             // [npos][4] mean0, M2_0, mean1, M2_1 (WELCH)
+  double* ks_d_ref;                            // [npos] max |fl(c0/n0) - fl(c1/n1)| exactly as ks_2samp forms it (all-tests mode)
 };
 
 template <int R>
@@ -313,6 +314,10 @@ void rank_stats_kernel(RankStatsArgs args) {
     float la = (i > 0) ? keysA[i - 1] : __builtin_nanf("");
     int num = i * n1 - j * n0;
     unsigned best = 0, s_lane = 0, tie_lane = 0;
+    // all-tests mode also reproduces ks_2samp's float expression bit for bit: remember which steps
+    // took group 1 (amask) and which steps tie the lane's running maximum (tmask)
+    const int i_start = i;
+    unsigned long long amask = 0, tmask = 0;
 #pragma unroll 1
     for (int s = 0; s < per; ++s) {
       const bool act = (d0 + s) < d1;
@@ -341,9 +346,36 @@ void rank_stats_kernel(RankStatsArgs args) {
       b = (act && !takeA) ? nv : b;
       const bool run_end = fminf(a, b) != v;
       unsigned mag = (unsigned)abs(num);
-      best = (act && run_end) ? max(best, mag) : best;
+      if constexpr (MWU) {
+        const unsigned long long bit = 1ull << s;
+        const bool cand = act && run_end;
+        const unsigned magc = cand ? mag : 0u;
+        amask |= (act && takeA) ? bit : 0ull;
+        tmask = (magc > best) ? bit : ((cand && magc == best) ? (tmask | bit) : tmask);
+        best = max(best, magc);
+      } else {
+        best = (act && run_end) ? max(best, mag) : best;
+      }
     }
+    const unsigned lane_best = best;
     best = wave_max_u32(best);
+    if constexpr (MWU) {
+      // D = max over the pooled points that attain the integer maximum of |fl(c0/n0) - fl(c1/n1)|
+      // (scipy 1.2.1 ks_2samp: cdf = searchsorted(...)/(1.0*n); d = max(|cdf1 - cdf2|))
+      unsigned long long tm = (lane_best == best && best > 0) ? tmask : 0ull;
+      double dmax = 0.0;
+      while (__ballot(tm != 0ull)) {
+        if (tm != 0ull) {
+          const int st = __ffsll((long long)tm) - 1;
+          tm &= tm - 1ull;
+          const int c0 = i_start + __popcll(amask & ((2ull << st) - 1ull));
+          const int c1 = (d0 + st + 1) - c0;
+          dmax = fmax(dmax, fabs((double)c0 / (double)n0 - (double)c1 / (double)n1));
+        }
+      }
+      dmax = wave_max_f64(dmax);
+      if (lane == 0) args.ks_d_ref[pos] = dmax;
+    }
     if constexpr (MWU) {
       unsigned long long S = wave_sum_u64((unsigned long long)s_lane);
       unsigned long long T = wave_sum_u64((unsigned long long)tie_lane);

@@ -116,6 +116,29 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return r;
 }
 
+__device__ __forceinline__ double wave_max_f64(double v) {
+  auto step = [](double x, auto tag) {
+    constexpr int C = decltype(tag)::value;
+    long long b = __double_as_longlong(x);
+    int lo = dpp_i<C>(0, (int)(unsigned)b);
+    int hi = dpp_i<C>(0, (int)(unsigned)((unsigned long long)b >> 32));
+    return fmax(x, __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo)));
+  };
+  v = step(v, std::integral_constant<int, NMOD_QP(1, 0, 3, 2)>{});
+  v = step(v, std::integral_constant<int, NMOD_QP(2, 3, 0, 1)>{});
+  v = step(v, std::integral_constant<int, kDppRowHalfMirror>{});
+  v = step(v, std::integral_constant<int, kDppRowMirror>{});
+  double r = 0.0;
+#pragma unroll
+  for (int row = 0; row < 4; ++row) {
+    long long b = __double_as_longlong(v);
+    unsigned lo = __builtin_amdgcn_readlane((unsigned)b, row * 16);
+    unsigned hi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)b >> 32), row * 16);
+    r = fmax(r, __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)));
+  }
+  return r;
+}
+
 // inclusive max-scan over lanes (lane l gets max over lanes 0..l), ints >= 0
 __device__ __forceinline__ int wave_scan_max_i32(int v) {
   v = max(v, dpp_i<kDppRowShr + 1>(0, v));        // invalid source lanes keep old = 0

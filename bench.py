@@ -30,34 +30,29 @@ ALGO_BYTES_PER_POS = 4 * (N0 + N1) + 16 + 4 + 16 * 2 + 8
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(sample_positions, threads):
-    """The oracle timed on this box's host cores on a bounded sample of the same workload."""
+def cpu_baseline(a, b, threads, target_seconds=15.0, max_positions=1_000_000):
+    """The oracle (C restatement, OpenMP over positions) timed on this box's host cores on a bounded
+    sample of the same workload: the first positions of this rank's device-resident input, copied
+    back.  `a`, `b`: float32 [positions, n] views."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import numpy as np
-    from helpers import synth_ref
-    a = synth_ref(SEED, 0, sample_positions, 0, N0, PLANT_PERIOD, PLANT_SHIFT)
-    b = synth_ref(SEED, 0, sample_positions, 1, N1, PLANT_PERIOD, PLANT_SHIFT)
-    off0 = np.arange(0, (sample_positions + 1) * N0, N0, dtype=np.int64)
-    off1 = np.arange(0, (sample_positions + 1) * N1, N1, dtype=np.int64)
-    rid = np.zeros(sample_positions, np.int32)
-    try:
-        import oracle_c
+    import oracle_c
+
+    def run(npos):
+        off0 = np.arange(0, (npos + 1) * N0, N0, dtype=np.int64)
+        off1 = np.arange(0, (npos + 1) * N1, N1, dtype=np.int64)
         t0 = time.perf_counter()
-        oracle_c.detect_batch(a, off0, b, off1, rid, NB, WDIF, 'stouffer', tests=1, threads=threads)
-        dt = time.perf_counter() - t0
-        kind_note = 'oracle/nanomod_oracle.c (C restatement, OpenMP)'
-        cores = threads
-    except ImportError:
-        import nanomod_oracle as orc
-        t0 = time.perf_counter()
-        for i in range(sample_positions):
-            orc.ks_2samp(a[off0[i]:off0[i + 1]], b[off1[i]:off1[i + 1]])
-        dt = time.perf_counter() - t0
-        kind_note = 'oracle/nanomod_oracle.py (numpy + scipy.special restatement, KS only)'
-        cores = 1
-    return {'value': sample_positions / dt, 'unit': 'positions/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d positions of the same 200 v 200 workload, %s, %.1f s' % (sample_positions, kind_note, dt)}
+        oracle_c.detect_batch(a[:npos].reshape(-1), off0, b[:npos].reshape(-1), off1, np.zeros(npos, np.int32),
+                              NB, WDIF, 'stouffer', tests=1, threads=threads)
+        return time.perf_counter() - t0
+    run(2000)                                    # thread-pool warm-up
+    probe = min(20000, a.shape[0])
+    rate = probe / run(probe)
+    sample = int(min(max_positions, a.shape[0], max(probe, rate * target_seconds)))
+    dt = run(sample)
+    return {'value': sample / dt, 'unit': 'positions/s', 'cores': threads, 'kind': 'port',
+            'sample': 'first %d positions of the same workload (200 v 200, KS + Stouffer window 5), '
+                      'oracle/nanomod_oracle.c with OpenMP on %d threads, %.1f s' % (sample, threads, dt)}
 
 
 def main():
@@ -66,7 +61,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--positions', type=int, default=P_ECOLI, help='positions per GPU (default: E. coli 4.6 M)')
-    ap.add_argument('--cpu-sample', type=int, default=0, help='positions for the CPU baseline (0 = auto)')
+    ap.add_argument('--cpu-sample', type=int, default=0, help='cap on positions for the CPU baseline (0 = 1 M)')
     ap.add_argument('--no-cpu', action='store_true')
     args = ap.parse_args()
 
@@ -156,9 +151,12 @@ def main():
                          'other_kernels_avg_ms': {'finalize': k2_ms / max(k1_n, 1), 'combine': k3_ms / max(k1_n, 1)}},
         }
         if not args.no_cpu:
-            threads = os.cpu_count() or 1
-            sample = args.cpu_sample or 4000
-            line['cpu_baseline'] = cpu_baseline(sample, threads)
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+            cap = args.cpu_sample or 1_000_000
+            cap = min(cap, n_local)
+            a = sig0[:cap * N0].cpu().numpy().reshape(cap, N0)
+            b = sig1[:cap * N1].cpu().numpy().reshape(cap, N1)
+            line['cpu_baseline'] = cpu_baseline(a, b, threads, max_positions=cap)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

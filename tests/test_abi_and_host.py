@@ -1,0 +1,126 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nanomod_hip.h declares (no compute
+without a GPU), struct layouts match the header, and the host-side logic mirrors the reference."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'nanomod_hip.h')
+
+
+def test_library_exports_every_declared_symbol():
+    import nanomod_amd._lib as L
+    lib = L.load()
+    with open(HEADER) as f:
+        text = f.read()
+    declared = set(re.findall(r'\b(nmod_[a-z_]+)\s*\(', text))
+    assert declared == set(L._SIGNATURES), declared ^ set(L._SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.nmod_abi_version() == 1
+    assert b'invalid' in lib.nmod_strerror(-1) and b'2048' in lib.nmod_strerror(-3)
+
+
+def test_struct_layout_matches_header():
+    import nanomod_amd._lib as L
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu", sizeof(nmod_params), ' \
+          'offsetof(nmod_params, weights_dif), offsetof(nmod_params, max_n0), offsetof(nmod_params, timer), sizeof(nmod_out));return 0;}' % HEADER
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, 't.c')
+        open(c, 'w').write(src)
+        subprocess.check_call(['gcc', c, '-o', os.path.join(d, 't')])
+        got = [int(x) for x in subprocess.check_output([os.path.join(d, 't')]).split()]
+    assert got == [C.sizeof(L.NmodParams), L.NmodParams.weights_dif.offset, L.NmodParams.max_n0.offset,
+                   L.NmodParams.timer.offset, C.sizeof(L.NmodOut)]
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    import nanomod_amd as nm
+    L = nm._lib
+    if L.load().nmod_device_count() > 0:
+        pytest.skip('GPU present')
+    with pytest.raises(L.NanomodLibraryError, match='no HIP device'):
+        nm.detect_host(np.zeros(10, np.float32), np.array([0, 5, 10]), np.zeros(10, np.float32), np.array([0, 5, 10]),
+                       np.zeros(2, np.int32))
+    with pytest.raises(L.NanomodLibraryError):
+        nm.getKStest({'coverages': [0, 0]}, [0.1, 0.2, 0.3], [0.2, 0.3, 0.4], '+')
+    # invalid arguments are rejected before any device work
+    prm = L.make_params(nb=1000)
+    assert L.load().nmod_detect_batch(C.byref(prm), 1, None, None, None, None, None, None, 0, None) == -1
+
+
+def test_missing_library_error(monkeypatch):
+    import nanomod_amd._lib as L
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'LIB_PATH', '/nonexistent/libnanomod_hip.so')
+    with pytest.raises(L.NanomodLibraryError, match='no CPU fallback'):
+        L.load()
+
+
+def test_run_ids_equal_pos_check():
+    import nanomod_amd.detect as D
+    rng = np.random.default_rng(0)
+    chrom = np.array(['a'] * 40 + ['b'] * 30); strand = np.array((['+'] * 20 + ['-'] * 20) + ['+'] * 30)
+    pos = np.cumsum(rng.choice([1, 1, 1, 2], 70))
+    rid = D.run_ids(chrom, strand, pos)
+    mlist = [((chrom[i], strand[i], int(pos[i]), 'A', 5, 5), []) for i in range(70)]
+    for i in range(70):
+        for j in range(max(0, i - 4), min(70, i + 5)):
+            assert D.pos_check(mlist, i, j) == (rid[i] == rid[j]), (i, j)
+    assert not D.pos_check(mlist, 0, -1) and not D.pos_check(mlist, 0, 70)
+
+
+def test_encode_signals():
+    import nanomod_amd.detect as D
+    assert D.encode_signals([0.5, 0.25, -1.75]).dtype == np.float32
+    v = np.round(np.random.default_rng(1).normal(0, 1, 1000), 3)
+    k = D.encode_signals(v)
+    assert k.dtype == np.int16 and np.array_equal(k / 1000.0, v)
+    with pytest.raises(ValueError):
+        D.encode_signals([0.1234567])
+    assert D.m_min_float(0.0) == 2.2250738585072014e-308 and D.m_max_float(float('inf')) == 1.7976931348623157e308
+    assert np.isnan(D.m_min_float(float('nan')))
+
+
+def test_filter_order_and_table_format_without_gpu():
+    """mfilter_coverage + build_csr give the reference's position set and order; save_test formats like it"""
+    import nanomod_amd.detect as D
+    fx = H.load_inputs('ragged')
+    exp, table = H.load_expected('ragged_stouffer')
+    with tempfile.TemporaryDirectory() as out:
+        mo = H.build_moptions(fx, out, 'x', 2, 2.0, 'stouffer')
+        D.mfilter_coverage(mo)
+        meta, sig0, off0, sig1, off1, rid = D.build_csr(mo)
+        assert [(m[0], m[1], m[2], m[3], m[4], m[5]) for m in meta] == list(zip(
+            exp['chrom'], exp['strand'], exp['pos'], exp['base'], exp['n0'], exp['n1']))
+        assert sig0.dtype == np.float32 and off0[-1] == sig0.shape[0]
+        mo['sign_test'] = [(m, [(exp['mwu_u'][i], exp['mwu_p'][i]), (exp['t_t'][i], exp['t_p'][i]),
+                                (exp['ks_d'][i], exp['ks_p'][i]), (exp['comb_st'][i], exp['comb_p'][i])])
+                           for i, m in enumerate(meta)]
+        D.save_test(mo)
+        assert open(os.path.join(out, 'x_sign_test.txt')).read() == table
+
+
+def test_shard_bounds_cover_exactly():
+    from nanomod_amd import sharding
+    for npos in (0, 1, 7, 64, 1000, 4600000):
+        for world in (1, 2, 3, 8):
+            got = [sharding.shard_bounds(npos, world, r) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == npos
+            assert all(got[i][1] == got[i + 1][0] for i in range(world - 1))
+    assert sharding.halo_bounds(10, 20, 2, 100) == (8, 22) and sharding.halo_bounds(0, 20, 2, 21) == (0, 21)
+
+
+def test_synth_generator_restatement_is_standard_normal_like():
+    v = H.synth_ref(20240601, 0, 2000, 0, 200)
+    assert abs(v.mean()) < 0.01 and abs(v.std() - 1.0) < 0.01 and v.dtype == np.float32
+    b = H.synth_ref(20240601, 0, 20001, 1, 50, 10000, 0.8).reshape(20001, 50)
+    assert abs(b[10000].mean() - 0.8) < 0.5 and abs(b[5000].mean()) < 0.5
+    assert np.array_equal(H.synth_ref(1, 5, 10, 1, 7), H.synth_ref(1, 0, 15, 1, 7)[35:])      # counter-based

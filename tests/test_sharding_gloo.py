@@ -1,0 +1,63 @@
+"""CPU, world_size 2 over gloo: the position partition + halo + all-gather reassembly reproduces the
+unsharded tracks bit for bit.  The compute is injected (the C oracle as checker): the production
+engine is the HIP path, which needs a GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+oracle_c = pytest.importorskip('oracle_c', reason='make -C oracle')
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _make(npos, seed):
+    rng = np.random.default_rng(seed)
+    n0 = rng.integers(5, 40, npos); n1 = rng.integers(5, 40, npos)
+    off0 = np.zeros(npos + 1, np.int64); off0[1:] = np.cumsum(n0)
+    off1 = np.zeros(npos + 1, np.int64); off1[1:] = np.cumsum(n1)
+    sig0 = rng.normal(0, 1, off0[-1]).astype(np.float32); sig1 = rng.normal(0.2, 1, off1[-1]).astype(np.float32)
+    rid = np.cumsum(rng.random(npos) < 0.05).astype(np.int32)      # runs break independently of the shard cut
+    return sig0, off0, sig1, off1, rid
+
+
+def _worker(rank, world, port, npos, nb, method, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nanomod_amd import sharding
+    sig0, off0, sig1, off1, rid = _make(npos, 42)
+
+    def compute(lo, hi):
+        o0 = off0[lo:hi + 1] - off0[lo]; o1 = off1[lo:hi + 1] - off1[lo]
+        r = oracle_c.detect_batch(sig0[off0[lo]:off0[hi]], o0, sig1[off1[lo]:off1[hi]], o1, rid[lo:hi], nb, 2.0, method, threads=1)
+        return {k: torch.from_numpy(v) for k, v in r.items() if k != 'status'}
+    out = sharding.sharded_detect(compute, npos, nb, tracks=('ks_p', 'comb_p', 'comb_st'))
+    q.put((rank, {k: v.numpy().copy() for k, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('npos,nb,method', [(501, 2, 'stouffer'), (64, 3, 'fisher'), (3, 2, 'stouffer')])
+def test_sharded_equals_unsharded(npos, nb, method):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, npos, nb, method, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sig0, off0, sig1, off1, rid = _make(npos, 42)
+    full = oracle_c.detect_batch(sig0, off0, sig1, off1, rid, nb, 2.0, method, threads=1)
+    for r in range(world):
+        for k in ('ks_p', 'comb_p', 'comb_st'):
+            assert np.array_equal(results[r][k], full[k], equal_nan=True), (r, k)

@@ -45,11 +45,12 @@ struct ScopedKernelTimer {
 struct Workspace {
   uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments;
   double* tmp_ks_d; double* tmp_ks_p; double* ks_d_ref;
-  int32_t* order; uint8_t* cls; int32_t* meta;     // meta: [0..35] counts, [36..71] offsets, [72..107] cursors, [108..109] max n0/n1
+  int32_t* order; uint8_t* cls; int32_t* meta;     // meta: [c] counts, [48 + c] offsets, [96 + c] cursors, [144..145] max n0/n1
   int64_t bytes;
 };
-constexpr int kMetaInts = 128;
-constexpr int kNumPairs = kNumSizeClasses * kNumSizeClasses;
+constexpr int kMetaInts = 160;
+constexpr int kMetaMax = 3 * kClassStride;
+constexpr int kNumPairs = kNumClasses;
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -78,11 +79,6 @@ struct BinArgs {
   int cmax0, cmax1; uint8_t* cls; int32_t* meta; int32_t* order;
 };
 
-__device__ __forceinline__ int dev_class_of(int64_t n) {
-  int c = 0;
-  while (c < kNumSizeClasses && n > (64LL << c)) ++c;
-  return c;   // == kNumSizeClasses when too large
-}
 
 __global__ __launch_bounds__(256) void max_n_kernel(int64_t npos, const int64_t* off0, const int64_t* off1, int32_t* meta) {
   __shared__ int m0s, m1s;
@@ -95,7 +91,7 @@ __global__ __launch_bounds__(256) void max_n_kernel(int64_t npos, const int64_t*
   }
   atomicMax(&m0s, m0); atomicMax(&m1s, m1);
   __syncthreads();
-  if (threadIdx.x == 0) { atomicMax(&meta[108], m0s); atomicMax(&meta[109], m1s); }
+  if (threadIdx.x == 0) { atomicMax(&meta[kMetaMax], m0s); atomicMax(&meta[kMetaMax + 1], m1s); }
 }
 
 __global__ __launch_bounds__(256) void classify_kernel(BinArgs a) {
@@ -105,8 +101,8 @@ __global__ __launch_bounds__(256) void classify_kernel(BinArgs a) {
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.npos; p += (int64_t)gridDim.x * 256) {
     int64_t n0 = a.stride0 > 0 ? a.stride0 : a.off0[p + 1] - a.off0[p];
     int64_t n1 = a.stride1 > 0 ? a.stride1 : a.off1[p + 1] - a.off1[p];
-    int c0 = dev_class_of(n0), c1 = dev_class_of(n1);
-    int cid = (c0 > a.cmax0 || c1 > a.cmax1 || n0 <= 0 || n1 <= 0) ? 255 : c0 * kNumSizeClasses + c1;
+    int c0 = size_class_of(n0), c1 = size_class_of(n1);
+    int cid = (c0 > a.cmax0 || c1 > a.cmax1 || n0 <= 0 || n1 <= 0) ? 255 : launch_class_of(c0, c1);
     a.cls[p] = (uint8_t)cid;
     if (cid != 255) atomicAdd(&hist[cid], 1);
   }
@@ -117,7 +113,7 @@ __global__ __launch_bounds__(256) void classify_kernel(BinArgs a) {
 __global__ void class_offsets_kernel(int32_t* meta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int acc = 0;
-    for (int i = 0; i < kNumPairs; ++i) { meta[36 + i] = acc; meta[72 + i] = 0; acc += meta[i]; }
+    for (int i = 0; i < kNumPairs; ++i) { meta[kClassStride + i] = acc; meta[2 * kClassStride + i] = 0; acc += meta[i]; }
   }
 }
 
@@ -147,10 +143,10 @@ __global__ __launch_bounds__(256) void scatter_kernel(BinArgs a) {
     if (threadIdx.x < kNumPairs) {
       int c = threadIdx.x;
       int tot = wave_cnt[0][c] + wave_cnt[1][c] + wave_cnt[2][c] + wave_cnt[3][c];
-      base[c] = tot ? atomicAdd(&a.meta[72 + c], tot) : 0;
+      base[c] = tot ? atomicAdd(&a.meta[2 * kClassStride + c], tot) : 0;
     }
     __syncthreads();
-    if (cid != 255) a.order[a.meta[36 + cid] + base[cid] + rank] = (int32_t)p;
+    if (cid != 255) a.order[a.meta[kClassStride + cid] + base[cid] + rank] = (int32_t)p;
     __syncthreads();
   }
 }
@@ -227,13 +223,13 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
                        prm->stride0 > 0 ? nullptr : off0, prm->stride1 > 0 ? nullptr : off1, ws.meta);
     NMOD_HIP(hipGetLastError());
     int32_t mx[2];
-    NMOD_HIP(hipMemcpyAsync(mx, ws.meta + 108, 8, hipMemcpyDeviceToHost, stream));
+    NMOD_HIP(hipMemcpyAsync(mx, ws.meta + kMetaMax, 8, hipMemcpyDeviceToHost, stream));
     NMOD_HIP(hipStreamSynchronize(stream));
     if (max0 <= 0) max0 = mx[0];
     if (max1 <= 0) max1 = mx[1];
   }
   int cmax0 = size_class_of(std::max<int64_t>(max0, 1)), cmax1 = size_class_of(std::max<int64_t>(max1, 1));
-  if (cmax0 < 0 || cmax1 < 0) return NMOD_ERR_TOO_LARGE;
+  if (cmax0 >= kNumSizeClasses || cmax1 >= kNumSizeClasses) return NMOD_ERR_TOO_LARGE;
 
   RankStatsArgs ra;
   memset(&ra, 0, sizeof(ra));
@@ -241,17 +237,17 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   ra.stride0 = prm->stride0 > 0 ? prm->stride0 : 0; ra.stride1 = prm->stride1 > 0 ? prm->stride1 : 0;
   ra.npos = npos; ra.ks_num = ws.ks_num; ra.mwu_s = ws.mwu_s; ra.tie = ws.tie; ra.moments = ws.moments; ra.ks_d_ref = ws.ks_d_ref;
 
-  auto launch = [&](int c0, int c1, int64_t work) -> hipError_t {
+  auto launch = [&](int cls, int64_t work) -> hipError_t {
     if (prm->dtype == NMOD_DTYPE_F32)
-      return all ? launch_rank_stats_d0_a1(c0, c1, num_cus, work, stream, ra)
-                 : launch_rank_stats_d0_a0(c0, c1, num_cus, work, stream, ra);
-    return all ? launch_rank_stats_d1_a1(c0, c1, num_cus, work, stream, ra)
-               : launch_rank_stats_d1_a0(c0, c1, num_cus, work, stream, ra);
+      return all ? launch_rank_stats_d0_a1(cls, num_cus, work, stream, ra)
+                 : launch_rank_stats_d0_a0(cls, num_cus, work, stream, ra);
+    return all ? launch_rank_stats_d1_a1(cls, num_cus, work, stream, ra)
+               : launch_rank_stats_d1_a0(cls, num_cus, work, stream, ra);
   };
 
   if (uniform) {
     ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
-    NMOD_HIP(launch(cmax0, cmax1, npos));
+    NMOD_HIP(launch(launch_class_of(cmax0, cmax1), npos));
   } else {
     BinArgs ba;
     ba.npos = npos; ba.off0 = off0; ba.off1 = off1; ba.stride0 = ra.stride0; ba.stride1 = ra.stride1;
@@ -262,12 +258,14 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), 0, stream, ba);
     NMOD_HIP(hipGetLastError());
     ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
+    bool wanted[kNumClasses] = {false};
     for (int c0 = 0; c0 <= cmax0; ++c0)
-      for (int c1 = 0; c1 <= cmax1; ++c1) {
-        int cid = c0 * kNumSizeClasses + c1;
-        ra.pos_list = ws.order; ra.class_meta = ws.meta; ra.class_id = cid;
-        NMOD_HIP(launch(c0, c1, npos));
-      }
+      for (int c1 = 0; c1 <= cmax1; ++c1) wanted[launch_class_of(c0, c1)] = true;
+    for (int cls = 0; cls < kNumClasses; ++cls) {
+      if (!wanted[cls]) continue;
+      ra.pos_list = ws.order; ra.class_meta = ws.meta; ra.class_id = cls;
+      NMOD_HIP(launch(cls, npos));
+    }
   }
 
   // ---- p-values

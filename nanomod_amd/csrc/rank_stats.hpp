@@ -30,6 +30,7 @@ namespace nmod {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kLdsPad = 4;   // +inf sentinels after each sorted group
+constexpr int kClassStride = 48;   // class_meta: [c] count, [kClassStride + c] offset, [2*kClassStride + c] cursor
 
 struct RankStatsArgs {
   const void* sig0; const void* sig1;
@@ -37,8 +38,8 @@ struct RankStatsArgs {
   int64_t stride0, stride1;
   int64_t npos;
   const int32_t* pos_list;                     // ragged batches: positions grouped by size class (null: all of [0, npos))
-  const int32_t* class_meta;                   // device ints: [c] = count of class c, [36 + c] = its offset into pos_list
-  int32_t class_id;                            // c0 * 6 + c1 of this launch
+  const int32_t* class_meta;                   // device ints: [c] = count of class c, [kClassStride + c] = its offset into pos_list
+  int32_t class_id;                            // size class of this launch (rank_stats_launch.hpp)
   uint32_t* ks_num;                            // [npos]
   uint64_t* mwu_s;                             // [npos]  (MWU)
   uint64_t* tie;                               // [npos]  (MWU)
@@ -249,7 +250,7 @@ void rank_stats_kernel(RankStatsArgs args) {
   const int32_t* list = nullptr;
   if (args.pos_list) {
     count = args.class_meta[args.class_id];
-    list = args.pos_list + args.class_meta[36 + args.class_id];
+    list = args.pos_list + args.class_meta[kClassStride + args.class_id];
   }
   const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;

@@ -1,6 +1,7 @@
 // Instantiates K1 for every (R0, R1) size class of one (dtype, tests) pair.
 // Built four times by the Makefile: -DNMOD_INST_DTYPE={0,1} -DNMOD_INST_ALL={0,1}.
 #include "rank_stats.hpp"
+#include "rank_stats_packed.hpp"
 #include "rank_stats_launch.hpp"
 
 #ifndef NMOD_INST_DTYPE
@@ -38,16 +39,30 @@ KernelFn pick(int c0, int c1) {
     default: return pick1<5>(c1);
   }
 }
+KernelFn pick_packed(int cm) {
+  switch (cm) {
+    case 0: return rank_stats_packed_kernel<4, 16, DT, ALL>;
+    case 1: return rank_stats_packed_kernel<8, 16, DT, ALL>;
+    case 2: return rank_stats_packed_kernel<16, 16, DT, ALL>;
+    case 3: return rank_stats_packed_kernel<32, 16, DT, ALL>;
+    default: return rank_stats_packed_kernel<32, 32, DT, ALL>;
+  }
+}
 }  // namespace
 
 #define NMOD_CAT2(a, b) a##b
 #define NMOD_CAT(a, b) NMOD_CAT2(a, b)
 #define NMOD_LAUNCH_NAME NMOD_CAT(NMOD_CAT(launch_rank_stats_d, NMOD_INST_DTYPE), NMOD_CAT(_a, NMOD_INST_ALL))
 
-hipError_t NMOD_LAUNCH_NAME(int c0, int c1, int num_cus, int64_t work_items, hipStream_t stream,
+hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_t stream,
                             const RankStatsArgs& args) {
-  KernelFn fn = pick(c0, c1);
-  const size_t lds = rank_stats_lds_bytes(c0, c1, ALL);
+  const bool packed = cls >= kNumGeneralClasses;
+  KernelFn fn = packed ? pick_packed(cls - kNumGeneralClasses) : pick(cls / kNumSizeClasses, cls % kNumSizeClasses);
+  const size_t lds = rank_stats_lds_bytes(cls, ALL);
+  if (packed) {
+    const int pw = packed_positions_per_wave(cls - kNumGeneralClasses);
+    work_items = (work_items + pw - 1) / pw;
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -1,4 +1,10 @@
 // Host-side launch interface of K1 (one translation unit per dtype x tests pair).
+//
+// Size classes.  A group of n samples needs capacity 64 << c (c = 0..5: 64 .. 2048).
+//   general class  c0 * 6 + c1      (0..35): rank_stats_kernel<1<<c0, 1<<c1>, 64 lanes per group;
+//   packed class   36 + cm          (36..40): rank_stats_packed_kernel, both groups in capacity 64 << cm,
+//                  used when max(c0,c1) = cm <= 4 and min(c0,c1) >= cm - 1:
+//                  cm 0..3 -> (R, LG) = (4,16) (8,16) (16,16) (32,16): two positions per wave; cm 4 -> (32,32).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -7,19 +13,36 @@ namespace nmod {
 
 struct RankStatsArgs;
 
-constexpr int kNumSizeClasses = 6;                 // R = 1, 2, 4, 8, 16, 32 registers per lane per group
-inline int size_class_of(int64_t n) {              // smallest class with 64 * R >= n; -1 if too large
-  for (int c = 0; c < kNumSizeClasses; ++c) if (n <= (64LL << c)) return c;
-  return -1;
+constexpr int kNumSizeClasses = 6;                 // capacities 64, 128, ..., 2048
+constexpr int kNumGeneralClasses = kNumSizeClasses * kNumSizeClasses;
+constexpr int kNumPackedClasses = 5;
+constexpr int kNumClasses = kNumGeneralClasses + kNumPackedClasses;   // <= kClassStride (48)
+
+__host__ __device__ inline int size_class_of(int64_t n) {   // smallest class with 64 << c >= n; 6 if too large
+  int c = 0;
+  while (c < kNumSizeClasses && n > (64LL << c)) ++c;
+  return c;
 }
-inline size_t rank_stats_lds_bytes(int c0, int c1, bool all) {
-  size_t keys = (64u << c0) + 4 + (64u << c1) + 4;  // words per wave (kLdsPad = 4)
-  return (all ? 2 : 1) * keys * 4 /*bytes*/ * 4 /*waves per block*/;
+__host__ __device__ inline int launch_class_of(int c0, int c1) {
+  int cm = c0 > c1 ? c0 : c1, cl = c0 > c1 ? c1 : c0;
+  if (cm <= 4 && cl >= cm - 1) return kNumGeneralClasses + cm;
+  return c0 * kNumSizeClasses + c1;
+}
+inline int packed_positions_per_wave(int cm) { return cm <= 3 ? 2 : 1; }
+inline size_t rank_stats_lds_bytes(int cls, bool all) {
+  size_t words;
+  if (cls >= kNumGeneralClasses) {
+    int cm = cls - kNumGeneralClasses;
+    words = (size_t)packed_positions_per_wave(cm) * 2 * ((64u << cm) + 4);
+  } else {
+    words = (64u << (cls / kNumSizeClasses)) + 4 + (64u << (cls % kNumSizeClasses)) + 4;   // kLdsPad = 4
+  }
+  return (all ? 2 : 1) * words * 4 /*bytes*/ * 4 /*waves per block*/;
 }
 
-hipError_t launch_rank_stats_d0_a0(int c0, int c1, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);
-hipError_t launch_rank_stats_d0_a1(int c0, int c1, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);
-hipError_t launch_rank_stats_d1_a0(int c0, int c1, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);
-hipError_t launch_rank_stats_d1_a1(int c0, int c1, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);
+hipError_t launch_rank_stats_d0_a0(int cls, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);
+hipError_t launch_rank_stats_d0_a1(int cls, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);
+hipError_t launch_rank_stats_d1_a0(int cls, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);
+hipError_t launch_rank_stats_d1_a1(int cls, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);
 
 }  // namespace nmod

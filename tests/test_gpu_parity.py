@@ -113,8 +113,11 @@ def _random_batch(rng, npos, lo0, hi0, lo1, hi1, grid=False, shift_every=7):
     return np.concatenate(ca), off0, np.concatenate(cb), off1, rid
 
 
-@pytest.mark.parametrize('sizes', [(5, 64, 5, 64), (65, 128, 3, 30), (129, 256, 129, 256), (300, 512, 20, 256),
-                                   (513, 1024, 40, 70), (1025, 2048, 1025, 2048), (3, 2048, 3, 2048)])
+# general (64 lanes per group) and packed (two positions per wave) kernels, every capacity class
+@pytest.mark.parametrize('sizes', [(5, 64, 5, 64), (65, 128, 3, 30), (65, 128, 65, 128), (129, 256, 129, 256),
+                                   (100, 128, 129, 220), (257, 512, 257, 512), (300, 512, 20, 256),
+                                   (513, 1024, 513, 1024), (513, 1024, 40, 70), (1025, 2048, 1025, 2048),
+                                   (3, 2048, 3, 2048)])
 @pytest.mark.parametrize('grid', [False, True])
 def test_random_batches_vs_oracle(nm, sizes, grid):
     """every size class (and mixed classes in one batch), continuous and tie-heavy data"""

@@ -55,24 +55,30 @@ __device__ __forceinline__ void ce(float& lo, float& hi) {
   lo = a; hi = b;
 }
 
-// full ascending sort of the R registers of one lane (bitonic, mirror form)
-template <int R>
-__device__ __forceinline__ void sort_in_lane(float (&x)[R]) {
+// full ascending sort of the R registers of one lane: Batcher's odd-even merge sort
+// (191 compare-exchanges for 32 keys against 240 for the bitonic network), indices all static
+template <int LO, int N, int RR, int R>
+__device__ __forceinline__ void oe_merge(float (&x)[R]) {
+  constexpr int M = RR * 2;
+  if constexpr (M < N) {
+    oe_merge<LO, N, M, R>(x);
+    oe_merge<LO + RR, N, M, R>(x);
 #pragma unroll
-  for (int k = 2; k <= R; k <<= 1) {
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      int p = i ^ (k - 1);
-      if (p > i) ce(x[i], x[p]);
-    }
-#pragma unroll
-    for (int j = k >> 2; j >= 1; j >>= 1) {
-#pragma unroll
-      for (int i = 0; i < R; ++i)
-        if ((i & j) == 0) ce(x[i], x[i | j]);
-    }
+    for (int i = LO + RR; i + RR < LO + N; i += M) ce(x[i], x[i + RR]);
+  } else {
+    ce(x[LO], x[LO + RR]);
   }
 }
+template <int LO, int N, int R>
+__device__ __forceinline__ void oe_sort(float (&x)[R]) {
+  if constexpr (N > 1) {
+    oe_sort<LO, N / 2, R>(x);
+    oe_sort<LO + N / 2, N / 2, R>(x);
+    oe_merge<LO, N, 1, R>(x);
+  }
+}
+template <int R>
+__device__ __forceinline__ void sort_in_lane(float (&x)[R]) { oe_sort<0, R, R>(x); }
 
 // half-cleaners between registers of one lane: distances R/2 .. 1
 template <int R>

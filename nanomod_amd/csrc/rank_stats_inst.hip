@@ -41,9 +41,9 @@ KernelFn pick(int c0, int c1) {
 }
 KernelFn pick_packed(int cm) {
   switch (cm) {
-    case 0: return rank_stats_packed_kernel<4, 16, DT, ALL>;
-    case 1: return rank_stats_packed_kernel<8, 16, DT, ALL>;
-    case 2: return rank_stats_packed_kernel<16, 16, DT, ALL>;
+    case 0: return rank_stats_packed_kernel<8, 8, DT, ALL>;
+    case 1: return rank_stats_packed_kernel<16, 8, DT, ALL>;
+    case 2: return rank_stats_packed_kernel<32, 8, DT, ALL>;
     case 3: return rank_stats_packed_kernel<32, 16, DT, ALL>;
     default: return rank_stats_packed_kernel<32, 32, DT, ALL>;
   }

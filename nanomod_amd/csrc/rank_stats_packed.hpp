@@ -1,8 +1,11 @@
 // K1, packed form — for positions whose two groups fall in the SAME size class.
 //
-// A group of C = R*LG samples lives in R registers of LG lanes (LG = 16: one DPP row, or 32).
-// One wavefront therefore holds 64/LG groups = 32/LG positions (LG = 16: two positions per
-// wave) and sorts all of them with ONE instruction stream.  Compared with the general kernel
+// A group of C = R*LG samples lives in R registers of LG lanes (LG = 8, 16 or 32).
+// One wavefront therefore holds 64/LG groups = 32/LG positions (LG = 8: four positions per
+// wave) and sorts all of them with ONE instruction stream.  Measured on gfx950 (tools/valu_rate.hip):
+// a compare-exchange between registers of a lane costs ~2 cycles per element (v_min / v_max),
+// between lanes ~8 (v_mov_b32_dpp ~4 + v_med3_f32 ~4), so the layout keeps as many stages of the
+// network inside a lane as the register file allows (R = 32).  Compared with the general kernel
 // (64 lanes per group) more of the bitonic network runs between registers of a lane
 // (v_min/v_max, 1 instruction per element per stage) and every cross-lane stage of the LG = 16
 // form is a single-row DPP move + v_med3_f32 — no ds_swizzle / ds_bpermute at all.
@@ -24,7 +27,8 @@ __device__ __forceinline__ float seg_mirror_f(float x) {
 }
 template <int LG>
 __device__ __forceinline__ int seg_mirror_i(int x) {
-  if constexpr (LG == 16) return dpp_i<kDppRowMirror>(x, x);
+  if constexpr (LG == 8) return dpp_i<kDppRowHalfMirror, 0xf, 0xf, true>(0, x);
+  else if constexpr (LG == 16) return dpp_i<kDppRowMirror, 0xf, 0xf, true>(0, x);
   else return __builtin_amdgcn_ds_swizzle(x, 0x7C1F);
 }
 
@@ -34,9 +38,9 @@ __device__ __forceinline__ int seg_scan_max_i32(int v) {
   v = max(v, dpp_i<kDppRowShr + 1>(0, v));
   v = max(v, dpp_i<kDppRowShr + 2>(0, v));
   v = max(v, dpp_i<kDppRowShr + 4>(0, v));
-  v = max(v, dpp_i<kDppRowShr + 8>(0, v));
+  if constexpr (LG >= 16) v = max(v, dpp_i<kDppRowShr + 8>(0, v));
   if constexpr (LG == 32) v = max(v, dpp_i<kDppRowBcast15, 0xA>(0, v));
-  return v;
+  return v;   // LG == 8: lanes 8..15 of a row also see lanes 0..7; callers bias the second group
 }
 
 // all lanes of a 16-lane row get the row's reduction
@@ -70,7 +74,8 @@ __device__ __forceinline__ double xor16_f64(double x) {
 // sum over the LG lanes of a group, result in every lane of the group
 template <int LG>
 __device__ __forceinline__ double seg_allsum_f64(double v) {
-  v += dpp_f64_row(v, 0); v += dpp_f64_row(v, 1); v += dpp_f64_row(v, 2); v += dpp_f64_row(v, 3);
+  v += dpp_f64_row(v, 0); v += dpp_f64_row(v, 1); v += dpp_f64_row(v, 2);
+  if constexpr (LG >= 16) v += dpp_f64_row(v, 3);
   if constexpr (LG == 32) v += xor16_f64(v);
   return v;
 }
@@ -79,6 +84,7 @@ __device__ __forceinline__ double seg_allsum_f64(double v) {
 template <int LG>
 __device__ __forceinline__ unsigned pos_max_u32(unsigned v, int lane) {
   v = row_allreduce_u32<unsigned>(v, [](unsigned a, unsigned b) { return max(a, b); });
+  if constexpr (LG == 8) return v;                 // a position is one 16-lane row
   unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
   unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
   if constexpr (LG == 16) return (lane < 32) ? max(r0, r1) : max(r2, r3);
@@ -88,6 +94,7 @@ template <int LG>
 __device__ __forceinline__ unsigned long long pos_sum_u32(unsigned v, int lane) {   // per-lane u32, exact u64 total
   // row totals fit in u32 only if each lane's value < 2^28; callers guarantee that
   v = row_allreduce_u32<unsigned>(v, [](unsigned a, unsigned b) { return a + b; });
+  if constexpr (LG == 8) return (unsigned long long)v;
   unsigned long long r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
   unsigned long long r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
   if constexpr (LG == 16) return (lane < 32) ? (r0 + r1) : (r2 + r3);
@@ -97,7 +104,7 @@ template <int LG>
 __device__ __forceinline__ double pos_max_f64(double v, int lane) {
   v = fmax(v, dpp_f64_row(v, 0)); v = fmax(v, dpp_f64_row(v, 1));
   v = fmax(v, dpp_f64_row(v, 2)); v = fmax(v, dpp_f64_row(v, 3));
-  v = fmax(v, xor16_f64(v));
+  if constexpr (LG >= 16) v = fmax(v, xor16_f64(v));
   if constexpr (LG == 32) {
     long long b = __double_as_longlong(v);
     unsigned lo0 = __builtin_amdgcn_readlane((unsigned)b, 0), hi0 = __builtin_amdgcn_readlane((unsigned)((unsigned long long)b >> 32), 0);
@@ -115,7 +122,7 @@ __device__ __forceinline__ void seg_sort(float (&x)[R], const LaneSel& sel, int 
   merge_lanes<R, 2>(x, sel, lane);
   merge_lanes<R, 4>(x, sel, lane);
   merge_lanes<R, 8>(x, sel, lane);
-  merge_lanes<R, 16>(x, sel, lane);
+  if constexpr (LG >= 16) merge_lanes<R, 16>(x, sel, lane);
   if constexpr (LG == 32) merge_lanes<R, 32>(x, sel, lane);
 }
 
@@ -175,43 +182,50 @@ __device__ __forceinline__ void seg_moments(const float (&x)[R], int n, double& 
 
 // run extents of equal keys inside each sorted group: (start | end << 16), indices inside the group
 template <int R, int LG>
-__device__ __forceinline__ void seg_store_runs(int* dst, const float (&x)[R], int gl) {
+__device__ __forceinline__ void seg_store_runs(int* dst, const float (&x)[R], int gl, bool is_b) {
   constexpr int N = R * LG;
+  // LG == 8: both groups of a position share one DPP row, so the second group's scan values are
+  // biased by N: whatever leaks in from the first group (< N) can never win a max
+  const int bias = (LG == 8 && is_b) ? N : 0;
   const float nanv = __builtin_nanf("");
   float prev_last = lane_prev(x[R - 1], nanv);
   float next_first = lane_next(x[0], nanv);
   prev_last = (gl == 0) ? nanv : prev_last;
   next_first = (gl == LG - 1) ? nanv : next_first;
-  int inc[R];
-  int run = 0;
+  // pass 1: per-lane totals only (keeping per-element arrays would cost 2*R registers)
+  int run = bias;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float p = (r == 0) ? prev_last : x[r - 1];
-    int e = gl * R + r;
-    run = (x[r] != p) ? e : run;
-    inc[r] = run;
+    run = (x[r] != p) ? (gl * R + r + bias) : run;
   }
   int carry = lane_prev_i(seg_scan_max_i32<LG>(run), 0);
-  carry = (gl == 0) ? 0 : carry;
-  int suf[R];
-  int acc = 0;
+  carry = (gl == 0) ? bias : carry;
+  int acc = bias;
 #pragma unroll
   for (int r = R - 1; r >= 0; --r) {
     float q = (r == R - 1) ? next_first : x[r + 1];
-    int e = gl * R + r;
-    acc = (x[r] != q) ? max(acc, N - (e + 1)) : acc;
-    suf[r] = acc;
+    acc = (x[r] != q) ? max(acc, N - (gl * R + r + 1) + bias) : acc;
   }
   int m = seg_mirror_i<LG>(acc);
   m = seg_scan_max_i32<LG>(m);
   m = seg_mirror_i<LG>(m);
   int carry_r = lane_next_i(m, 0);
-  carry_r = (gl == LG - 1) ? 0 : carry_r;
+  carry_r = (gl == LG - 1) ? bias : carry_r;
+  // pass 2: replay with the carries; starts go to LDS first, ends are OR-ed in on the way back
+  run = carry;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    int start = max(inc[r], carry);
-    int end = N - max(suf[r], carry_r);
-    dst[gl * R + r] = start | (end << 16);
+    float p = (r == 0) ? prev_last : x[r - 1];
+    run = (x[r] != p) ? (gl * R + r + bias) : run;
+    dst[gl * R + r] = run - bias;
+  }
+  acc = carry_r;
+#pragma unroll
+  for (int r = R - 1; r >= 0; --r) {
+    float q = (r == R - 1) ? next_first : x[r + 1];
+    acc = (x[r] != q) ? max(acc, N - (gl * R + r + 1) + bias) : acc;
+    dst[gl * R + r] |= (N - (acc - bias)) << 16;
   }
 }
 
@@ -219,6 +233,7 @@ __device__ __forceinline__ void seg_store_runs(int* dst, const float (&x)[R], in
 template <int R, int LG, int DTYPE, bool ALL>
 __global__ __launch_bounds__(64 * kWavesPerBlock)
 void rank_stats_packed_kernel(RankStatsArgs args) {
+  static_assert(LG == 8 || LG == 16 || LG == 32, "lanes per group");
   constexpr int C = R * LG;                       // capacity per group
   constexpr int LP = 2 * LG;                      // lanes per position
   constexpr int PW = 64 / LP;                     // positions per wave
@@ -288,7 +303,7 @@ void rank_stats_packed_kernel(RankStatsArgs args) {
 
     seg_sort<R, LG>(x, sel, lane);
     store_sorted<R>(my_keys, x, gl);
-    if constexpr (ALL) seg_store_runs<R, LG>(my_runs, x, gl);
+    if constexpr (ALL) seg_store_runs<R, LG>(my_runs, x, gl, is_b);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -298,7 +313,12 @@ void rank_stats_packed_kernel(RankStatsArgs args) {
     const int d0 = min(pl * per, total);
     const int my_steps = min(d0 + per, total) - d0;
     int steps_w = per, span = min(n0, n1);
-    if constexpr (PW == 2) {
+    if constexpr (PW == 4) {
+      steps_w = max(max(__builtin_amdgcn_readlane(per, 0), __builtin_amdgcn_readlane(per, 16)),
+                    max(__builtin_amdgcn_readlane(per, 32), __builtin_amdgcn_readlane(per, 48)));
+      span = max(max(__builtin_amdgcn_readlane(span, 0), __builtin_amdgcn_readlane(span, 16)),
+                 max(__builtin_amdgcn_readlane(span, 32), __builtin_amdgcn_readlane(span, 48)));
+    } else if constexpr (PW == 2) {
       steps_w = max(__builtin_amdgcn_readlane(per, 0), __builtin_amdgcn_readlane(per, 32));
       span = max(__builtin_amdgcn_readlane(span, 0), __builtin_amdgcn_readlane(span, 32));
     } else {
@@ -353,7 +373,7 @@ void rank_stats_packed_kernel(RankStatsArgs args) {
       b = tB ? nv : b;
       const bool run_end = (a != v) && (b != v);   // next pooled value differs (both heads are >= v)
       const bool cand = act && run_end;
-      const int num = __mad24(i, nn, -tn0);        // c0*n1 - c1*n0 with c0 = i, c0 + c1 = i + j (operands < 2^23)
+      const int num = __mul24(i, nn) - tn0;        // c0*n1 - c1*n0 with c0 = i, c0 + c1 = i + j (operands < 2^23)
       const unsigned mag = (unsigned)abs(num);
       const unsigned magc = cand ? mag : 0u;
       if constexpr (ALL) {

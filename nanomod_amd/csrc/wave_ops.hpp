@@ -27,14 +27,14 @@ __device__ __forceinline__ float dpp_f(float old, float src) {
 // value of lane (l ^ M) for M in {1,2,4,8,16}
 template <int M>
 __device__ __forceinline__ float lane_xor(float x) {
-  if constexpr (M == 1) return dpp_f<NMOD_QP(1, 0, 3, 2)>(x, x);
-  else if constexpr (M == 2) return dpp_f<NMOD_QP(2, 3, 0, 1)>(x, x);
+  // every lane has a valid source in these patterns, so bound_ctrl:1 with old = 0 lets the
+  // compiler emit the bare v_mov_b32_dpp (a tied `old` costs an extra v_mov per move)
+  if constexpr (M == 1) return dpp_f<NMOD_QP(1, 0, 3, 2), 0xf, 0xf, true>(0.0f, x);
+  else if constexpr (M == 2) return dpp_f<NMOD_QP(2, 3, 0, 1), 0xf, 0xf, true>(0.0f, x);
+  else if constexpr (M == 8) return dpp_f<0x120 + 8, 0xf, 0xf, true>(0.0f, x);   // row_ror:8 == xor 8 inside a row
   else if constexpr (M == 4) {
     float y = dpp_f<kDppRowShl + 4, 0xf, 0x5>(x, x);   // banks 0,2 read lane+4
     return dpp_f<kDppRowShr + 4, 0xf, 0xA>(y, x);      // banks 1,3 read lane-4
-  } else if constexpr (M == 8) {
-    float y = dpp_f<kDppRowShl + 8, 0xf, 0x3>(x, x);   // banks 0,1 read lane+8
-    return dpp_f<kDppRowShr + 8, 0xf, 0xC>(y, x);      // banks 2,3 read lane-8
   } else {
     static_assert(M == 16, "lane_xor: unsupported distance");
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));  // bit mode: xor 0x10
@@ -44,10 +44,10 @@ __device__ __forceinline__ float lane_xor(float x) {
 // value of lane (l ^ (G-1)): reversal inside aligned groups of G lanes
 template <int G>
 __device__ __forceinline__ float lane_mirror(float x, int lane) {
-  if constexpr (G == 2) return dpp_f<NMOD_QP(1, 0, 3, 2)>(x, x);
-  else if constexpr (G == 4) return dpp_f<NMOD_QP(3, 2, 1, 0)>(x, x);
-  else if constexpr (G == 8) return dpp_f<kDppRowHalfMirror>(x, x);
-  else if constexpr (G == 16) return dpp_f<kDppRowMirror>(x, x);
+  if constexpr (G == 2) return dpp_f<NMOD_QP(1, 0, 3, 2), 0xf, 0xf, true>(0.0f, x);
+  else if constexpr (G == 4) return dpp_f<NMOD_QP(3, 2, 1, 0), 0xf, 0xf, true>(0.0f, x);
+  else if constexpr (G == 8) return dpp_f<kDppRowHalfMirror, 0xf, 0xf, true>(0.0f, x);
+  else if constexpr (G == 16) return dpp_f<kDppRowMirror, 0xf, 0xf, true>(0.0f, x);
   else if constexpr (G == 32) return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x7C1F));  // xor 0x1f
   else {
     static_assert(G == 64, "lane_mirror: unsupported group");

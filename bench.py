@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--positions', type=int, default=P_ECOLI, help='positions per GPU (default: E. coli 4.6 M)')
     ap.add_argument('--cpu-sample', type=int, default=0, help='cap on positions for the CPU baseline (0 = 1 M)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--all-tests', action='store_true', help='BASELINE.json configs[2]: KS + MWU + Welch-t + Fisher (not the headline metric)')
     args = ap.parse_args()
 
     import torch
@@ -88,7 +89,8 @@ def main():
     lo_h, hi_h = sharding.halo_bounds(lo, hi, NB, total_positions)
     n_local = hi_h - lo_h
 
-    det = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method='stouffer', tests=L.TEST_KS)
+    det = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method='fisher' if args.all_tests else 'stouffer',
+                            tests=L.TEST_ALL if args.all_tests else L.TEST_KS)
     sig0 = torch.empty(n_local * N0, dtype=torch.float32, device=dev)
     sig1 = torch.empty(n_local * N1, dtype=torch.float32, device=dev)
     det.synth_fill(sig0, SEED, lo_h, n_local, 0, N0, PLANT_PERIOD, PLANT_SHIFT)
@@ -134,9 +136,10 @@ def main():
     if rank == 0:
         value = total_positions * args.steps / elapsed
         k1_avg_s = (k1_ms / max(k1_n, 1)) * 1e-3
-        achieved = ALGO_BYTES_PER_POS * n_local / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
+        algo_bytes = ALGO_BYTES_PER_POS + (32 if args.all_tests else 0)          # 16 B x 2 more (stat, p) pairs
+        achieved = algo_bytes * n_local / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
         line = {
-            'metric': 'genomic positions/sec (KS + Stouffer)', 'value': value, 'unit': 'positions/s',
+            'metric': 'genomic positions/sec (KS + MWU + Welch-t + Fisher)' if args.all_tests else 'genomic positions/sec (KS + Stouffer)', 'value': value, 'unit': 'positions/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32 keys / f64 p-values', 'data': 'synthetic',
@@ -147,10 +150,10 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                          'kernel': 'rank_stats_kernel<4,4,f32,KS>', 'kernel_avg_ms': k1_avg_s * 1e3,
-                         'algorithmic_bytes_per_position': ALGO_BYTES_PER_POS,
+                         'algorithmic_bytes_per_position': algo_bytes,
                          'other_kernels_avg_ms': {'finalize': k2_ms / max(k1_n, 1), 'combine': k3_ms / max(k1_n, 1)}},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and not args.all_tests:
             threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
             cap = args.cpu_sample or 1_000_000
             cap = min(cap, n_local)

@@ -169,12 +169,21 @@ __device__ __forceinline__ void seg_moments(const float (&x)[R], int n, double& 
   const float inf = __builtin_inff();
   double s = 0.0;
 #pragma unroll
-  for (int r = 0; r < R; ++r) s += (x[r] != inf) ? (double)x[r] : 0.0;
+  for (int r = 0; r < R; ++r) {
+    s += (x[r] != inf) ? (double)x[r] : 0.0;
+    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // do not convert all R keys to fp64 at once
+  }
   s = seg_allsum_f64<LG>(s);
   const double mu = s / (double)n;
   double q = 0.0;
 #pragma unroll
-  for (int r = 0; r < R; ++r) { double d = (double)x[r] - mu; q += (x[r] != inf) ? d * d : 0.0; }
+  for (int r = 0; r < R; ++r) {
+    float xr = x[r];
+    asm volatile("" : "+v"(xr));          // opaque copy: stops the compiler keeping R fp64 conversions live from pass 1
+    double d = (double)xr - mu;
+    q += (xr != inf) ? d * d : 0.0;
+    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
   q = seg_allsum_f64<LG>(q);
   if constexpr (DTYPE == 0) { mean = mu; m2 = q; }
   else { mean = s / 1000.0 / (double)n; m2 = q * 1e-6; }
@@ -182,50 +191,63 @@ __device__ __forceinline__ void seg_moments(const float (&x)[R], int n, double& 
 
 // run extents of equal keys inside each sorted group: (start | end << 16), indices inside the group
 template <int R, int LG>
-__device__ __forceinline__ void seg_store_runs(int* dst, const float (&x)[R], int gl, bool is_b) {
+__device__ __forceinline__ void seg_store_runs(int* dst, float (&y)[R], int gl, bool is_b) {   // clobbers y
   constexpr int N = R * LG;
   // LG == 8: both groups of a position share one DPP row, so the second group's scan values are
   // biased by N: whatever leaks in from the first group (< N) can never win a max
   const int bias = (LG == 8 && is_b) ? N : 0;
   const float nanv = __builtin_nanf("");
-  float prev_last = lane_prev(x[R - 1], nanv);
-  float next_first = lane_next(x[0], nanv);
+  float prev_last = lane_prev(y[R - 1], nanv);
+  float next_first = lane_next(y[0], nanv);
   prev_last = (gl == 0) ? nanv : prev_last;
   next_first = (gl == LG - 1) ? nanv : next_first;
+  // Each of the four sweeps below works on an opaque in-place copy of the keys (empty asm): without
+  // that the compiler shares the 2*R comparison masks between the sweeps and keeps them all alive,
+  // which costs ~90 VGPRs through SGPR spills.
+  auto launder = [&]() {
+#pragma unroll
+    for (int r = 0; r < R; ++r) asm volatile("" : "+v"(y[r]));
+  };
   // pass 1: per-lane totals only (keeping per-element arrays would cost 2*R registers)
   int run = bias;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    float p = (r == 0) ? prev_last : x[r - 1];
-    run = (x[r] != p) ? (gl * R + r + bias) : run;
+    float p = (r == 0) ? prev_last : y[r - 1];
+    run = (y[r] != p) ? (gl * R + r + bias) : run;
   }
   int carry = lane_prev_i(seg_scan_max_i32<LG>(run), 0);
   carry = (gl == 0) ? bias : carry;
+  launder();
   int acc = bias;
 #pragma unroll
   for (int r = R - 1; r >= 0; --r) {
-    float q = (r == R - 1) ? next_first : x[r + 1];
-    acc = (x[r] != q) ? max(acc, N - (gl * R + r + 1) + bias) : acc;
+    float q = (r == R - 1) ? next_first : y[r + 1];
+    acc = (y[r] != q) ? max(acc, N - (gl * R + r + 1) + bias) : acc;
   }
   int m = seg_mirror_i<LG>(acc);
   m = seg_scan_max_i32<LG>(m);
   m = seg_mirror_i<LG>(m);
   int carry_r = lane_next_i(m, 0);
   carry_r = (gl == LG - 1) ? bias : carry_r;
-  // pass 2: replay with the carries; starts go to LDS first, ends are OR-ed in on the way back
+  // pass 2: replay with the carries; start and end are the two 16-bit halves of one LDS word
+  unsigned short* dst16 = reinterpret_cast<unsigned short*>(dst);
+  launder();
   run = carry;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    float p = (r == 0) ? prev_last : x[r - 1];
-    run = (x[r] != p) ? (gl * R + r + bias) : run;
-    dst[gl * R + r] = run - bias;
+    float p = (r == 0) ? prev_last : y[r - 1];
+    run = (y[r] != p) ? (gl * R + r + bias) : run;
+    dst16[2 * (gl * R + r)] = (unsigned short)(run - bias);
+    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
+  launder();
   acc = carry_r;
 #pragma unroll
   for (int r = R - 1; r >= 0; --r) {
-    float q = (r == R - 1) ? next_first : x[r + 1];
-    acc = (x[r] != q) ? max(acc, N - (gl * R + r + 1) + bias) : acc;
-    dst[gl * R + r] |= (N - (acc - bias)) << 16;
+    float q = (r == R - 1) ? next_first : y[r + 1];
+    acc = (y[r] != q) ? max(acc, N - (gl * R + r + 1) + bias) : acc;
+    dst16[2 * (gl * R + r) + 1] = (unsigned short)(N - (acc - bias));
+    if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -1,0 +1,310 @@
+// K1, KS-only form (tests mask = KS: BASELINE.json configs[1], "KS + weighted Stouffer").
+//
+// ks_2samp (myDetect.py:341 -> scipy 1.2.1) needs D = max_v |F0(v) - F1(v)| over the pooled points.
+// D is symmetric in the two groups, so call the smaller one S (m samples) and the other Q (q samples):
+//   1. S is sorted in registers exactly like the packed kernel (R registers x LG lanes, bitonic
+//      network, DPP + v_med3 across lanes) and written to wave-private LDS;
+//   2. every sample x of Q finds L(x) = #{s < x} by a branchless 1+log2(C)-step binary search in LDS
+//      and, only when x ties with an S value, U(x) = #{s <= x} by a second search;
+//   3. one ds_add_u32 per sample builds the histograms of L and U (two 16-bit halves of a word);
+//   4. with cumL / cumU their prefix sums, the pooled points are
+//        v = an S value with upper rank k :  (#{x <= v}, #{s <= v}) = (cumL(k-1), k)
+//        v = largest Q sample with U = k   :                          (cumU(k),   k)
+//      (k restricted to run ends of S); every other pooled point is dominated by these two, so
+//        ks_num = max_k max(|cumL(k-1)*m - k*q|, |cumU(k)*m - k*q|)
+//      is the same exact integer max|c0*n1 - c1*n0| the merge-path kernels produce.
+//      Without ties cumL == cumU and the maximum collapses to max_{k<m} max(a_k, q - a_k),
+//      a_k = cumU(k)*m - k*q: five VALU instructions per histogram bin.
+// Against the two-sort + merge-path form this removes one sort and the whole sequential merge:
+// ~300 instead of ~500 VALU instructions per 200 v 200 position (rocprof SQ_INSTS_VALU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rank_stats_packed.hpp"
+
+namespace nmod {
+
+// LDS layout: sorted keys and histogram bins are skewed by 4 pad words per 32 (word(i) = i + 4*(i>>5)).
+// A power-of-two binary search probes indices == 2^j - 1 (mod 2^(j+1)); unskewed, every probe of the
+// first steps lands on one bank (rocprof: 85 % of the LDS cycles were bank conflicts).  With the skew
+// the probes of different 32-blocks fall on different banks, and because the search position is
+// always a multiple of the current step the skewed offsets are compile-time constants: no extra VALU.
+constexpr int kKsTail = 8;         // +inf sentinels / spare bins after the last skewed word
+
+__host__ __device__ constexpr int ks_skew(int i) { return i + ((i >> 5) << 2); }
+__device__ __forceinline__ int ks_skew_rt(int i) { return i + ((i >> 5) << 2); }
+__host__ __device__ constexpr int ks_region_words(int C) { return ks_skew(C) + kKsTail; }
+__host__ __device__ constexpr int ks_rank_pos_words(int C) {
+  // keys + histogram, padded so that consecutive positions start 8 banks apart
+  int w = 2 * ks_region_words(C);
+  while ((w & 31) != 8) w += 4;
+  return w;
+}
+
+template <int LG>
+__device__ __forceinline__ unsigned seg_allmax_u32(unsigned v) {
+  v = max(v, (unsigned)dpp_i<NMOD_QP(1, 0, 3, 2), 0xf, 0xf, true>(0, (int)v));
+  v = max(v, (unsigned)dpp_i<NMOD_QP(2, 3, 0, 1), 0xf, 0xf, true>(0, (int)v));
+  v = max(v, (unsigned)dpp_i<kDppRowHalfMirror, 0xf, 0xf, true>(0, (int)v));
+  if constexpr (LG >= 16) v = max(v, (unsigned)dpp_i<kDppRowMirror, 0xf, 0xf, true>(0, (int)v));
+  if constexpr (LG >= 32) v = max(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));
+  if constexpr (LG == 64) v = max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32));
+  return v;
+}
+
+// exclusive prefix sum over the LG lanes of a segment (values may be packed 16|16 counters)
+template <int LG>
+__device__ __forceinline__ unsigned seg_exscan_add_u32(unsigned v, int gl) {
+  unsigned inc = v;
+  auto step = [&](auto tag, int dist) {
+    constexpr int C = decltype(tag)::value;
+    unsigned t = (unsigned)dpp_i<C, 0xf, 0xf, true>(0, (int)inc);   // bound_ctrl: lanes without a source read 0
+    inc += (gl >= dist) ? t : 0u;                                     // do not cross into the previous segment
+  };
+  step(std::integral_constant<int, kDppRowShr + 1>{}, 1);
+  step(std::integral_constant<int, kDppRowShr + 2>{}, 2);
+  step(std::integral_constant<int, kDppRowShr + 4>{}, 4);
+  if constexpr (LG >= 16) step(std::integral_constant<int, kDppRowShr + 8>{}, 8);
+  if constexpr (LG >= 32) {
+    unsigned t = (unsigned)dpp_i<kDppRowBcast15, 0xA>(0, (int)inc);  // rows 1,3 <- lane 15 of rows 0,2
+    inc += ((gl & 16) != 0) ? t : 0u;
+  }
+  if constexpr (LG == 64) {
+    unsigned t = (unsigned)dpp_i<kDppRowBcast31, 0xC>(0, (int)inc);  // rows 2,3 <- lane 31
+    inc += (gl >= 32) ? t : 0u;
+  }
+  return inc - v;
+}
+
+template <int R, int LG>
+__device__ __forceinline__ void seg_sort_any(float (&x)[R], const LaneSel& sel, int lane) {
+  seg_sort<R, (LG == 64 ? 32 : LG)>(x, sel, lane);
+  if constexpr (LG == 64) merge_lanes<R, 64>(x, sel, lane);
+}
+
+// branchless binary search in the skewed key array: returns the pointer to skewed word L (LE = false:
+// L = #{s < x}) or U (LE = true: U = #{s <= x}); `base` points at key 0.
+template <int C, int STEPS, bool LE>
+__device__ __forceinline__ const float* ks_search(const float* base, float x) {
+  const float* p = base;
+  const float last = base[ks_skew(C - 1)];
+  const bool all = LE ? (last <= x) : (last < x);                 // rank C: every key is below x
+#pragma unroll
+  for (int st = STEPS - 1; st >= 0; --st) {
+    constexpr int dummy = 0; (void)dummy;
+    const int h = 1 << st;
+    const int hp = ks_skew(h);                                     // skewed step (p is a multiple of 2h)
+    const int probe = (h >= 32) ? hp - 5 : h - 1;                  // skewed offset of key p + h - 1
+    const float t = p[probe];
+    const bool right = LE ? (t <= x) : (t < x);
+    p = right ? p + hp : p;
+  }
+  return all ? base + ks_skew(C) : p;
+}
+
+template <int R, int LG, int DTYPE>
+__global__ __launch_bounds__(64 * kWavesPerBlock)
+void ks_rank_kernel(RankStatsArgs args) {
+  static_assert(LG == 8 || LG == 16 || LG == 32 || LG == 64, "lanes per sorted group");
+  static_assert(R >= 8 && R <= 32 && (R & (R - 1)) == 0, "registers per lane");
+  constexpr int C = R * LG;                    // capacity of the sorted group
+  constexpr int PW = 64 / LG;                  // positions per wave
+  constexpr int POS_WORDS = ks_rank_pos_words(C);
+  constexpr int HIST_OFF = ks_region_words(C); // words from key 0 to bin 0
+  constexpr int STEPS = (C == 64) ? 6 : (C == 128) ? 7 : (C == 256) ? 8 : (C == 512) ? 9 : (C == 1024) ? 10 : 11;
+  static_assert((1 << STEPS) == C, "capacity must be a power of two");
+  constexpr int QV = 8;                        // Q samples per lane per loop iteration (two 16-byte loads)
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gl = lane & (LG - 1);
+  const int slot = lane / LG;
+  float* keys = lds_all + (wave * PW + slot) * POS_WORDS;        // sorted S of this lane's position (skewed)
+  unsigned* hist = reinterpret_cast<unsigned*>(keys + HIST_OFF);    // skewed bin k: (#L == k) << 16 | (#U == k)
+  const int e0 = gl * R;                                             // first key / bin this lane owns
+  const int w0 = ks_skew_rt(e0);                                     // its skewed word (R consecutive words)
+  const int w_next = ks_skew_rt(e0 + R);                             // skewed word of key / bin e0 + R
+
+  const float inf = __builtin_inff();
+  LaneSel sel;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) sel.s[b] = ((lane >> b) & 1) ? inf : -inf;
+  if (gl < kKsTail) keys[ks_skew(C) + gl] = inf;
+
+  int64_t count = args.npos;
+  const int32_t* list = nullptr;
+  if (args.pos_list) {
+    count = args.class_meta[args.class_id];
+    list = args.pos_list + args.class_meta[kClassStride + args.class_id];
+  }
+  const int64_t items = (count + PW - 1) / PW;
+  const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
+
+  for (int64_t it = wave_global; it < items; it += wave_stride) {
+    const int64_t li = it * PW + slot;
+    const bool valid = li < count;
+    const int64_t pos = valid ? (list ? (int64_t)list[li] : li) : 0;
+    int64_t o0 = 0, o1 = 0; int n0 = 0, n1 = 0;
+    if (valid) {
+      if (args.stride0 > 0) { o0 = pos * args.stride0; n0 = (int)args.stride0; }
+      else { o0 = args.off0[pos]; n0 = (int)(args.off0[pos + 1] - o0); }
+      if (args.stride1 > 0) { o1 = pos * args.stride1; n1 = (int)args.stride1; }
+      else { o1 = args.off1[pos]; n1 = (int)(args.off1[pos + 1] - o1); }
+    }
+    // S = the smaller group (D is symmetric in the groups)
+    const bool swap = n1 < n0;
+    const int m = swap ? n1 : n0, q = swap ? n0 : n1;
+    const void* sig_s = swap ? args.sig1 : args.sig0;
+    const void* sig_q = swap ? args.sig0 : args.sig1;
+    const int64_t off_s = swap ? o1 : o0, off_q = swap ? o0 : o1;
+
+    float x[R];
+    load_packed<R, LG, DTYPE>(x, sig_s, off_s, m, gl);
+    seg_sort_any<R, LG>(x, sel, lane);
+    store_sorted<R>(keys + w0, x, 0);
+    // ties inside S (pads are +inf: excluded by the finite test on the upper element)
+    bool s_tie = false;
+    {
+      const float nxt = lane_next(x[0], inf);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float up = (r == R - 1) ? ((gl == LG - 1) ? inf : nxt) : x[r + 1];
+        s_tie = s_tie || (x[r] == up && up < inf);
+      }
+    }
+    // clear this lane's bins e0 .. e0 + R - 1; the last lane also clears bin C
+#pragma unroll
+    for (int r = 0; r < R; r += 4) *reinterpret_cast<uint4*>(hist + w0 + r) = make_uint4(0, 0, 0, 0);
+    if (gl == LG - 1) *reinterpret_cast<uint4*>(hist + ks_skew(C)) = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- rank every Q sample into S.  Slots past the end of Q carry FLT_MAX: they rank at L = U = m
+    // without ever tying, so the loop needs no validity masks; their count is taken out of bin m below.
+    const float big = 3.4028234663852886e38f;
+    const int chunks = (q + QV * LG - 1) / (QV * LG);
+    int chunks_w = chunks;
+    if constexpr (PW > 1) {
+      chunks_w = 0;
+#pragma unroll
+      for (int s = 0; s < PW; ++s) chunks_w = max(chunks_w, __builtin_amdgcn_readlane(chunks, s * LG));
+    } else {
+      chunks_w = __builtin_amdgcn_readfirstlane(chunks);
+    }
+    const bool q_vec = __ballot((off_q & 3) != 0) == 0ull;
+    bool any_tie = false;
+#pragma unroll 1
+    for (int c = 0; c < chunks_w; ++c) {
+      float xq[QV];
+#pragma unroll
+      for (int v = 0; v < QV / 4; ++v) {
+        const int idx = (c * (QV / 4) + v) * (4 * LG) + 4 * gl;
+        float a0 = big, a1 = big, a2 = big, a3 = big;
+        if (q_vec && idx + 3 < q) {
+          if constexpr (DTYPE == 0) {
+            float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sig_q) + off_q + idx);
+            a0 = t.x; a1 = t.y; a2 = t.z; a3 = t.w;
+          } else {
+            short4 t = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(sig_q) + off_q + idx);
+            a0 = (float)t.x; a1 = (float)t.y; a2 = (float)t.z; a3 = (float)t.w;
+          }
+        } else if (idx < q) {
+          a0 = load_sample<DTYPE>(sig_q, off_q + idx);
+          if (idx + 1 < q) a1 = load_sample<DTYPE>(sig_q, off_q + idx + 1);
+          if (idx + 2 < q) a2 = load_sample<DTYPE>(sig_q, off_q + idx + 2);
+          if (idx + 3 < q) a3 = load_sample<DTYPE>(sig_q, off_q + idx + 3);
+        }
+        xq[4 * v] = a0; xq[4 * v + 1] = a1; xq[4 * v + 2] = a2; xq[4 * v + 3] = a3;
+      }
+      const float* lp[QV];
+      bool tie_here = false;
+#pragma unroll
+      for (int e = 0; e < QV; ++e) lp[e] = ks_search<C, STEPS, false>(keys, xq[e]);
+#pragma unroll
+      for (int e = 0; e < QV; ++e) tie_here = tie_here || (*lp[e] == xq[e]);      // keys[skew(C)] is +inf
+      if (__ballot(tie_here) != 0ull) {          // rare for continuous data; the norm for 3-dp rounded signals
+        any_tie = true;
+#pragma unroll
+        for (int e = 0; e < QV; ++e) {
+          const float* up = ks_search<C, STEPS, true>(keys, xq[e]);
+          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, 0x10000u);
+          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up)) + HIST_OFF, 1u);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < QV; ++e)
+          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, 0x10001u);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (gl == 0) hist[ks_skew_rt(m)] -= (unsigned)(chunks_w * (QV * LG) - q) * 0x10001u;   // the FLT_MAX slots
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- prefix sums of the histograms and the KS numerator; lane gl owns bins e0 + 1 .. e0 + R
+    unsigned h[R];
+#pragma unroll
+    for (int r = 0; r < R; r += 4) {
+      uint4 t = *reinterpret_cast<const uint4*>(hist + w0 + r);         // bins e0 + r .. e0 + r + 3
+      if (r > 0) h[r - 1] = t.x;
+      h[r] = t.y; h[r + 1] = t.z; h[r + 2] = t.w;
+    }
+    h[R - 1] = hist[w_next];                                              // bin e0 + R
+    unsigned tot = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) tot += h[r];
+    const unsigned cum = seg_exscan_add_u32<LG>(tot, gl) + hist[0];      // both cumulative counts up to bin e0
+    unsigned best = 0;
+    const bool slow = __ballot(s_tie || any_tie) != 0ull;
+    if (!slow) {
+      // no ties in this wave: cumL == cumU; D_num = max_{k < m} max(a_k, q - a_k), a_k = cumU(k)*m - k*q.
+      // Q samples above every s sit in bin m; clamping k*q at (m-1)*q and the running count at
+      // cumU(m-1) makes every bin >= m repeat a_{m-1}.
+      const int kq_max = (m - 1) * q;
+      int kq = min(e0 * q, kq_max);
+      const int cmax = q - (int)(hist[ks_skew_rt(m)] & 0xffffu);         // cumU(m-1)
+      int c = min((int)(cum & 0xffffu), cmax);
+      int hi = __mul24(c, m) - kq, lo = hi;                              // bin e0 itself: a valid a_k
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        c = min(c + (int)(h[r] & 0xffffu), cmax);
+        kq = min(kq + q, kq_max);
+        const int a = __mul24(c, m) - kq;
+        hi = max(hi, a);
+        lo = min(lo, a);
+      }
+      best = (unsigned)max(hi, q - lo);
+    } else {
+      // general form with the run ends of S as masks
+      float s_own[R];
+#pragma unroll
+      for (int r = 0; r < R; r += 4) {
+        float4 t = *reinterpret_cast<const float4*>(keys + w0 + r);
+        s_own[r] = t.x; s_own[r + 1] = t.y; s_own[r + 2] = t.z; s_own[r + 3] = t.w;
+      }
+      const float s_next = keys[w_next];                 // key e0 + R (or the +inf sentinel)
+      unsigned cl = cum >> 16, cu = cum & 0xffffu;      // cumL(k-1), cumU(k-1) entering bin k = e0 + 1
+      if (gl == 0) best = cu * (unsigned)m;              // k = 0: (cumU(0), 0)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int k = e0 + r + 1;
+        const float up = (r == R - 1) ? s_next : s_own[r + 1];
+        const bool run_end = (k <= m) && (s_own[r] != up || k == m);
+        const int kq = k * q;
+        const unsigned cand_b = (unsigned)abs((int)cl * m - kq);          // v = the S value with upper rank k
+        cu += h[r] & 0xffffu;
+        cl += h[r] >> 16;
+        const unsigned cand_a = (unsigned)abs((int)cu * m - kq);          // v = largest Q sample with U = k
+        best = run_end ? max(best, max(cand_a, cand_b)) : best;
+      }
+    }
+    best = seg_allmax_u32<LG>(best);
+    if (valid && gl == 0) args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace nmod

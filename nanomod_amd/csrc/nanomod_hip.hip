@@ -76,7 +76,7 @@ static Workspace carve(void* base, int64_t npos) {
 // ---------------------------------------------------------------- binning kernels
 struct BinArgs {
   int64_t npos; const int64_t* off0; const int64_t* off1; int64_t stride0, stride1;
-  int cmax0, cmax1; uint8_t* cls; int32_t* meta; int32_t* order;
+  int cmax0, cmax1; int ks_only; uint8_t* cls; int32_t* meta; int32_t* order;
 };
 
 
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void classify_kernel(BinArgs a) {
     int64_t n0 = a.stride0 > 0 ? a.stride0 : a.off0[p + 1] - a.off0[p];
     int64_t n1 = a.stride1 > 0 ? a.stride1 : a.off1[p + 1] - a.off1[p];
     int c0 = size_class_of(n0), c1 = size_class_of(n1);
-    int cid = (c0 > a.cmax0 || c1 > a.cmax1 || n0 <= 0 || n1 <= 0) ? 255 : launch_class_of(c0, c1);
+    int cid = (c0 > a.cmax0 || c1 > a.cmax1 || n0 <= 0 || n1 <= 0) ? 255
+              : a.ks_only ? kKsClassBase + (c0 < c1 ? c0 : c1) : launch_class_of(c0, c1);
     a.cls[p] = (uint8_t)cid;
     if (cid != 255) atomicAdd(&hist[cid], 1);
   }
@@ -247,11 +248,11 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
 
   if (uniform) {
     ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
-    NMOD_HIP(launch(launch_class_of(cmax0, cmax1), npos));
+    NMOD_HIP(launch(all ? launch_class_of(cmax0, cmax1) : kKsClassBase + std::min(cmax0, cmax1), npos));
   } else {
     BinArgs ba;
     ba.npos = npos; ba.off0 = off0; ba.off1 = off1; ba.stride0 = ra.stride0; ba.stride1 = ra.stride1;
-    ba.cmax0 = cmax0; ba.cmax1 = cmax1; ba.cls = ws.cls; ba.meta = ws.meta; ba.order = ws.order;
+    ba.cmax0 = cmax0; ba.cmax1 = cmax1; ba.ks_only = all ? 0 : 1; ba.cls = ws.cls; ba.meta = ws.meta; ba.order = ws.order;
     unsigned blocks = (unsigned)std::min<int64_t>((npos + 255) / 256, 4096);
     hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, stream, ba);
     hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(64), 0, stream, ws.meta);
@@ -260,7 +261,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
     bool wanted[kNumClasses] = {false};
     for (int c0 = 0; c0 <= cmax0; ++c0)
-      for (int c1 = 0; c1 <= cmax1; ++c1) wanted[launch_class_of(c0, c1)] = true;
+      for (int c1 = 0; c1 <= cmax1; ++c1) wanted[all ? launch_class_of(c0, c1) : kKsClassBase + std::min(c0, c1)] = true;
     for (int cls = 0; cls < kNumClasses; ++cls) {
       if (!wanted[cls]) continue;
       ra.pos_list = ws.order; ra.class_meta = ws.meta; ra.class_id = cls;

@@ -2,6 +2,7 @@
 // Built four times by the Makefile: -DNMOD_INST_DTYPE={0,1} -DNMOD_INST_ALL={0,1}.
 #include "rank_stats.hpp"
 #include "rank_stats_packed.hpp"
+#include "ks_rank.hpp"
 #include "rank_stats_launch.hpp"
 
 #ifndef NMOD_INST_DTYPE
@@ -39,6 +40,16 @@ KernelFn pick(int c0, int c1) {
     default: return pick1<5>(c1);
   }
 }
+KernelFn pick_ks(int cs) {
+  switch (cs) {
+    case 0: return ks_rank_kernel<8, 8, DT>;
+    case 1: return ks_rank_kernel<16, 8, DT>;
+    case 2: return ks_rank_kernel<16, 16, DT>;
+    case 3: return ks_rank_kernel<32, 16, DT>;
+    case 4: return ks_rank_kernel<32, 32, DT>;
+    default: return ks_rank_kernel<32, 64, DT>;
+  }
+}
 KernelFn pick_packed(int cm) {
   switch (cm) {
     case 0: return rank_stats_packed_kernel<8, 8, DT, ALL>;
@@ -56,11 +67,13 @@ KernelFn pick_packed(int cm) {
 
 hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_t stream,
                             const RankStatsArgs& args) {
-  const bool packed = cls >= kNumGeneralClasses;
-  KernelFn fn = packed ? pick_packed(cls - kNumGeneralClasses) : pick(cls / kNumSizeClasses, cls % kNumSizeClasses);
+  const bool ks = cls >= kKsClassBase;
+  const bool packed = !ks && cls >= kNumGeneralClasses;
+  KernelFn fn = ks ? pick_ks(cls - kKsClassBase)
+                   : packed ? pick_packed(cls - kNumGeneralClasses) : pick(cls / kNumSizeClasses, cls % kNumSizeClasses);
   const size_t lds = rank_stats_lds_bytes(cls, ALL);
-  if (packed) {
-    const int pw = packed_positions_per_wave(cls - kNumGeneralClasses);
+  if (ks || packed) {
+    const int pw = ks ? ks_positions_per_wave(cls - kKsClassBase) : packed_positions_per_wave(cls - kNumGeneralClasses);
     work_items = (work_items + pw - 1) / pw;
   }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),

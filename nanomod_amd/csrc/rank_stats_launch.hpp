@@ -17,7 +17,9 @@ struct RankStatsArgs;
 constexpr int kNumSizeClasses = 6;                 // capacities 64, 128, ..., 2048
 constexpr int kNumGeneralClasses = kNumSizeClasses * kNumSizeClasses;
 constexpr int kNumPackedClasses = 5;
-constexpr int kNumClasses = kNumGeneralClasses + kNumPackedClasses;   // <= kClassStride (48)
+constexpr int kNumKsClasses = 6;                   // KS-only form (ks_rank.hpp): class of the SMALLER group
+constexpr int kKsClassBase = kNumGeneralClasses + kNumPackedClasses;    // 41
+constexpr int kNumClasses = kKsClassBase + kNumKsClasses;               // 47 <= kClassStride (48)
 
 __host__ __device__ inline int size_class_of(int64_t n) {   // smallest class with 64 << c >= n; 6 if too large
   int c = 0;
@@ -30,9 +32,18 @@ __host__ __device__ inline int launch_class_of(int c0, int c1) {
   return c0 * kNumSizeClasses + c1;
 }
 inline int packed_positions_per_wave(int cm) { return cm <= 2 ? 4 : (cm == 3 ? 2 : 1); }
+// KS-only classes: capacity 64 << cs sorted in (R, LG) = (8,8) (16,8) (16,16) (32,16) (32,32) (32,64)
+inline int ks_lanes_per_group(int cs) { return cs <= 1 ? 8 : (cs == 2 ? 16 : (8 << (cs - 2))); }
+inline int ks_positions_per_wave(int cs) { return 64 / ks_lanes_per_group(cs); }
 inline size_t rank_stats_lds_bytes(int cls, bool all) {
   size_t words;
-  if (cls >= kNumGeneralClasses) {
+  if (cls >= kKsClassBase) {
+    int cs = cls - kKsClassBase;
+    size_t C = 64u << cs;
+    size_t w = 2 * (C + C / 8 + 8);                                          // ks_rank_pos_words (ks_rank.hpp)
+    while ((w & 31) != 8) w += 4;
+    return (size_t)ks_positions_per_wave(cs) * w * 4 * 4;                   // bytes, 4 waves per block
+  } else if (cls >= kNumGeneralClasses) {
     int cm = cls - kNumGeneralClasses;
     words = (size_t)packed_positions_per_wave(cm) * 2 * ((64u << cm) + 4);
   } else {

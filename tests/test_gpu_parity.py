@@ -133,6 +133,34 @@ def test_random_batches_vs_oracle(nm, sizes, grid):
         assert np.array_equal(got['status'], exp['status'])
 
 
+@pytest.mark.parametrize('sizes', [(5, 64, 5, 64), (65, 128, 3, 30), (129, 256, 129, 256), (200, 200, 200, 200),
+                                   (257, 512, 100, 300), (513, 1024, 600, 1024), (1025, 2048, 1025, 2048),
+                                   (900, 1100, 30, 70), (3, 2048, 3, 2048), (64, 64, 256, 256), (1, 3, 1, 3)])
+@pytest.mark.parametrize('grid', [False, True])
+def test_ks_only_mode_vs_oracle(nm, sizes, grid):
+    """tests mask = KS (the benchmark configuration): the sort-one-group + rank-the-other kernel, every
+    capacity class of the smaller group, continuous and tie-heavy data, ragged batches"""
+    import nanomod_oracle as orc
+    L = nm._lib
+    rng = np.random.default_rng(hash((sizes, grid, 'ks')) % (2 ** 32))
+    npos = 60 if sizes[1] > 1024 else 203
+    sig0, off0, sig1, off1, rid = _random_batch(rng, npos, *sizes, grid=grid)
+    if grid:   # make some positions extremely tie-heavy, including identical groups
+        for i in range(0, npos, 9):
+            sig0[off0[i]:off0[i + 1]] = np.round(sig0[off0[i]:off0[i + 1]], 0)
+            sig1[off1[i]:off1[i + 1]] = np.round(sig1[off1[i]:off1[i + 1]], 0)
+    got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    ks = [orc.ks_2samp(sig0[off0[i]:off0[i + 1]], sig1[off1[i]:off1[i + 1]]) for i in range(npos)]
+    exp_d = np.array([k[0] for k in ks]); exp_p = np.maximum(np.array([k[1] for k in ks]), orc.DBL_MIN)
+    H.assert_close_stat(got['ks_d'], exp_d, 0, 4.5e-16, 'ks_d')
+    H.assert_close_p(got['ks_p'], exp_p, 1e-9, 'ks_p')
+    st, pv = orc.combine_track(exp_d, exp_p, rid, 2, 2.0, orc.METHOD_STOUFFER)
+    H.assert_close_p(got['comb_p'], pv, 1e-9, 'comb_p')
+    # and the exact integer numerator agrees with the all-tests kernels' D (bit-exact reference form)
+    full = nm.detect_host(sig0, off0, sig1, off1, rid, method='ks')
+    assert np.max(np.abs(full['ks_d'] - got['ks_d'])) <= 2.3e-16
+
+
 def test_int16_milli_path_matches_float_path(nm):
     import nanomod_oracle as orc
     rng = np.random.default_rng(99)

@@ -12,7 +12,7 @@ import csv,glob,collections
 for f in sorted(glob.glob('$OUT/*/*/*counter_collection.csv')):
     d=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'rank_stats' in r['Kernel_Name']:
+        if 'rank_stats' in r['Kernel_Name'] or 'ks_rank' in r['Kernel_Name']:
             d[r['Counter_Name']].append(float(r['Counter_Value'])); meta=(r['Kernel_Name'][:60],r['Grid_Size'],r['LDS_Block_Size'],r['VGPR_Count'])
     print(meta)
     for k,v in sorted(d.items()): print('  %-24s %.6g'%(k,sum(v)/len(v)))

@@ -85,7 +85,7 @@ __device__ __forceinline__ void seg_sort_any(float (&x)[R], const LaneSel& sel, 
 // branchless binary search in the skewed key array: returns the pointer to skewed word L (LE = false:
 // L = #{s < x}) or U (LE = true: U = #{s <= x}); `base` points at key 0.
 template <int C, int STEPS, bool LE>
-__device__ __forceinline__ const float* ks_search(const float* base, float x) {
+__device__ __forceinline__ const float* ks_search(const float* base, float x, const float** block_start = nullptr) {
   const float* p = base;
   const float last = base[ks_skew(C - 1)];
   const bool all = LE ? (last <= x) : (last < x);                 // rank C: every key is below x
@@ -98,12 +98,16 @@ __device__ __forceinline__ const float* ks_search(const float* base, float x) {
     const float t = p[probe];
     const bool right = LE ? (t <= x) : (t < x);
     p = right ? p + hp : p;
+    if (st == 5 && block_start) *block_start = p;                  // skewed word of the 32-block that holds rank L
   }
+  if (block_start && all) *block_start = base + ks_skew(C);
   return all ? base + ks_skew(C) : p;
 }
 
+// second launch-bound argument = minimum waves per SIMD: keeps the R <= 16 forms at <= 128 VGPRs
+// (the compiler otherwise spends 130+ registers on scheduling freedom and occupancy drops to 3)
 template <int R, int LG, int DTYPE>
-__global__ __launch_bounds__(64 * kWavesPerBlock)
+__global__ __launch_bounds__(64 * kWavesPerBlock, (R <= 16 ? 4 : 2))
 void ks_rank_kernel(RankStatsArgs args) {
   static_assert(LG == 8 || LG == 16 || LG == 32 || LG == 64, "lanes per sorted group");
   static_assert(R >= 8 && R <= 32 && (R & (R - 1)) == 0, "registers per lane");
@@ -219,18 +223,35 @@ void ks_rank_kernel(RankStatsArgs args) {
         xq[4 * v] = a0; xq[4 * v + 1] = a1; xq[4 * v + 2] = a2; xq[4 * v + 3] = a3;
       }
       const float* lp[QV];
+      const float* lb32[QV];
       bool tie_here = false;
 #pragma unroll
-      for (int e = 0; e < QV; ++e) lp[e] = ks_search<C, STEPS, false>(keys, xq[e]);
+      for (int e = 0; e < QV; ++e) lp[e] = ks_search<C, STEPS, false>(keys, xq[e], &lb32[e]);
 #pragma unroll
       for (int e = 0; e < QV; ++e) tie_here = tie_here || (*lp[e] == xq[e]);      // keys[skew(C)] is +inf
-      if (__ballot(tie_here) != 0ull) {          // rare for continuous data; the norm for 3-dp rounded signals
+      if (__ballot(tie_here) != 0ull) {          // ties with S: common for 3-dp rounded signals and the synthetic grid
         any_tie = true;
+        // a tied sample almost always ties with ONE key: U = L + 1 (the next skewed word is +1, or +5 when
+        // L is the last key of its 32-block); only if that next key ties again (duplicates inside S) fall
+        // back to the full upper-bound search
+        const float* up[QV];
+        bool again = false;
 #pragma unroll
         for (int e = 0; e < QV; ++e) {
-          const float* up = ks_search<C, STEPS, true>(keys, xq[e]);
+          const bool eq = (*lp[e] == xq[e]);
+          const int step = ((lp[e] - lb32[e]) == 31) ? 5 : 1;
+          up[e] = eq ? lp[e] + step : lp[e];
+        }
+#pragma unroll
+        for (int e = 0; e < QV; ++e) again = again || (*up[e] == xq[e]);
+        if (__ballot(again) != 0ull) {
+#pragma unroll
+          for (int e = 0; e < QV; ++e) up[e] = ks_search<C, STEPS, true>(keys, xq[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < QV; ++e) {
           atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, 0x10000u);
-          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up)) + HIST_OFF, 1u);
+          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up[e])) + HIST_OFF, 1u);
         }
       } else {
 #pragma unroll
@@ -286,20 +307,26 @@ void ks_rank_kernel(RankStatsArgs args) {
         s_own[r] = t.x; s_own[r + 1] = t.y; s_own[r + 2] = t.z; s_own[r + 3] = t.w;
       }
       const float s_next = keys[w_next];                 // key e0 + R (or the +inf sentinel)
-      unsigned cl = cum >> 16, cu = cum & 0xffffu;      // cumL(k-1), cumU(k-1) entering bin k = e0 + 1
-      if (gl == 0) best = cu * (unsigned)m;              // k = 0: (cumU(0), 0)
+      // Pads are +inf, so "s_{k-1} != s_k" alone marks the run ends: it holds at k = m and fails for k > m.
+      int cl = (int)(cum >> 16), cu = (int)(cum & 0xffffu);   // cumL(k-1), cumU(k-1) entering bin k = e0 + 1
+      int hi = (gl == 0) ? cu * m : 0, lo = 0;                  // k = 0: (cumU(0), 0)
+      int kq = e0 * q;
+      int clm = __mul24(cl, m);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const int k = e0 + r + 1;
         const float up = (r == R - 1) ? s_next : s_own[r + 1];
-        const bool run_end = (k <= m) && (s_own[r] != up || k == m);
-        const int kq = k * q;
-        const unsigned cand_b = (unsigned)abs((int)cl * m - kq);          // v = the S value with upper rank k
-        cu += h[r] & 0xffffu;
-        cl += h[r] >> 16;
-        const unsigned cand_a = (unsigned)abs((int)cu * m - kq);          // v = largest Q sample with U = k
-        best = run_end ? max(best, max(cand_a, cand_b)) : best;
+        const bool run_end = s_own[r] != up;
+        kq += q;
+        const int cand_b = clm - kq;                             // v = the S value with upper rank k: cumL(k-1)*m - k*q
+        cu += (int)(h[r] & 0xffffu);
+        cl += (int)(h[r] >> 16);
+        clm = __mul24(cl, m);
+        const int cand_a = __mul24(cu, m) - kq;                  // v = largest Q sample with U = k: cumU(k)*m - k*q
+        const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
+        hi = max(hi, max(ca, cb));
+        lo = min(lo, min(ca, cb));
       }
+      best = (unsigned)max(hi, -lo);
     }
     best = seg_allmax_u32<LG>(best);
     if (valid && gl == 0) args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;

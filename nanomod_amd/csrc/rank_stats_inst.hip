@@ -54,7 +54,7 @@ KernelFn pick_packed(int cm) {
   switch (cm) {
     case 0: return rank_stats_packed_kernel<8, 8, DT, ALL>;
     case 1: return rank_stats_packed_kernel<16, 8, DT, ALL>;
-    case 2: return rank_stats_packed_kernel<32, 8, DT, ALL>;
+    case 2: return rank_stats_packed_kernel<16, 16, DT, ALL>;
     case 3: return rank_stats_packed_kernel<32, 16, DT, ALL>;
     default: return rank_stats_packed_kernel<32, 32, DT, ALL>;
   }

@@ -4,7 +4,7 @@
 //   general class  c0 * 6 + c1      (0..35): rank_stats_kernel<1<<c0, 1<<c1>, 64 lanes per group;
 //   packed class   36 + cm          (36..40): rank_stats_packed_kernel, both groups in capacity 64 << cm,
 //                  used when max(c0,c1) = cm <= 4 and min(c0,c1) >= cm - 1:
-//                  cm 0..2 -> (R, LG) = (8,8) (16,8) (32,8): four positions per wave; cm 3 -> (32,16): two;
+//                  cm 0..1 -> (R, LG) = (8,8) (16,8): four positions per wave; cm 2..3 -> (16,16) (32,16): two;
 //                  cm 4 -> (32,32): one.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -31,7 +31,7 @@ __host__ __device__ inline int launch_class_of(int c0, int c1) {
   if (cm <= 4 && cl >= cm - 1) return kNumGeneralClasses + cm;
   return c0 * kNumSizeClasses + c1;
 }
-inline int packed_positions_per_wave(int cm) { return cm <= 2 ? 4 : (cm == 3 ? 2 : 1); }
+inline int packed_positions_per_wave(int cm) { return cm <= 1 ? 4 : (cm <= 3 ? 2 : 1); }
 // KS-only classes: capacity 64 << cs sorted in (R, LG) = (8,8) (16,8) (16,16) (32,16) (32,32) (32,64)
 inline int ks_lanes_per_group(int cs) { return cs <= 1 ? 8 : (cs == 2 ? 16 : (8 << (cs - 2))); }
 inline int ks_positions_per_wave(int cs) { return 64 / ks_lanes_per_group(cs); }

@@ -114,12 +114,13 @@ def main():
     if world > 1:
         gathered = {k: torch.empty(total_positions, dtype=torch.float64, device=dev) for k in ('ks_p', 'comb_p')}
 
+    def compute(lo_hh, hi_hh):                       # this rank's block + halo is resident: [lo_h, hi_h)
+        assert (lo_hh, hi_hh) == (lo_h, hi_h)
+        return det.run(sig0, sig1, rid, stride0=N0, stride1=N1, npos=n_local, out=out)
+
     def step():
-        res = det.run(sig0, sig1, rid, stride0=N0, stride1=N1, npos=n_local, out=out)
-        if world > 1:
-            for k in ('ks_p', 'comb_p'):
-                dist.all_gather_into_tensor(gathered[k], res[k][lo - lo_h: lo - lo_h + P])
-        return res
+        # partition + halo + one RCCL all-gather per track: the code path tests/test_sharding_gloo.py covers
+        return sharding.sharded_detect(compute, total_positions, NB, tracks=('ks_p', 'comb_p'), out=gathered)
 
     for _ in range(args.warmup):
         step()

@@ -145,6 +145,18 @@ int nmod_evtimer_reset(void* timer);
 int nmod_evtimer_read(void* timer, int32_t kernel, double* total_ms, int32_t* launches);
 int nmod_evtimer_destroy(void* timer);
 
+/* Replaces save_test's table loop (myDetect.py:522-538) for array-shaped results: writes one line per
+ * position, '%s %s %d %s %d %d %.3f %.3E %.3f %.3E %.3f %.3E' = chrom strand pos+1 base n0 n1 U pU t pt D pKS,
+ * then ' %.3f %.3E' with the combined pair iff with_comb, then '\n'; non-finite values print as Python
+ * prints them ('inf', '-inf', 'nan').  Host-only (no device work).  chrom_id[i] indexes chrom_names
+ * (NUL-separated, n_chroms entries); strand[i] and base[i] are single characters.  Returns NMOD_OK or
+ * NMOD_ERR_INVALID_ARG (also when the file cannot be opened). */
+int nmod_write_sign_test(const char* path, int64_t npos, const int32_t* chrom_id, const char* chrom_names,
+                         int32_t n_chroms, const char* strand, const int64_t* pos0, const char* base,
+                         const int32_t* n0, const int32_t* n1, const double* mwu_u, const double* mwu_p,
+                         const double* t_t, const double* t_p, const double* ks_d, const double* ks_p,
+                         const double* comb_st, const double* comb_p, int32_t with_comb);
+
 /* Lane-permutation self test of the wave primitives the sort is built from
  * (runs tiny kernels; returns NMOD_OK or the number of the first failing primitive). */
 int nmod_selftest(int32_t device);

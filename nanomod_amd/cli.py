@@ -1,0 +1,176 @@
+"""`detect`-compatible command line: the reference's `NanoMod.py detect` flags
+(NanoMod.py:344-393) over neutral `.npz` containers, array-native end to end: coverage filter and
+position intersection (myDetect.py:301-314,421-431) with numpy, the tests + combine on the GPU through
+the C ABI, `_sign_test.txt` through nmod_write_sign_test, ranking as myDetect.py:447-462.
+
+    python -m nanomod_amd.cli detect --wrkBase1 groupA.npz --wrkBase2 groupB.npz --FileID run1 --outFolder out/
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import _lib as L
+from . import container, detect, engine
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog='nanomod_amd', description='MI355X implementation of NanoMod detect (hot path only)')
+    sub = p.add_subparsers(dest='cmd')
+    d = sub.add_parser('detect', help='per-base KS / MWU / Welch-t tests + window combine')
+    d.add_argument('--outLevel', type=int, default=2, choices=[0, 1, 2, 3])           # NanoMod.py:348
+    d.add_argument('--wrkBase1', required=True, help='.npz container of read group 1 (reference: a FAST5 folder)')
+    d.add_argument('--wrkBase2', required=True, help='.npz container of read group 2')
+    d.add_argument('--FileID', default='mod')                                          # NanoMod.py:349
+    d.add_argument('--outFolder', default='mRes')                                      # NanoMod.py:350
+    d.add_argument('--MinCoverage', type=int, default=5)                               # NanoMod.py:354
+    d.add_argument('--topN', type=int, default=30)                                     # NanoMod.py:355
+    d.add_argument('--neighborPvalues', type=int, default=2)                           # NanoMod.py:357
+    d.add_argument('--WeightsDif', type=float, default=2.0)                            # NanoMod.py:358
+    d.add_argument('--testMethod', default='stouffer', choices=['fisher', 'stouffer', 'ks'])   # NanoMod.py:359
+    d.add_argument('--rankUse', default='pv', choices=['st', 'pv'])                    # NanoMod.py:361
+    d.add_argument('--SaveTest', type=int, default=1, choices=[0, 1])                  # NanoMod.py:362
+    d.add_argument('--mstd', type=int, default=0)                                      # NanoMod.py:378
+    d.add_argument('--device', type=int, default=0)
+    return p
+
+
+def validate(a):
+    """NanoMod.py:40-97 (mCommonParam): the checks that concern this path."""
+    errs = []
+    if a.MinCoverage < 3:
+        errs.append('Error: --MinCoverage should be not less than 3')                 # NanoMod.py:65-67
+    if a.topN < 1:
+        errs.append('Error: --topN should be larger than 0')
+    if a.neighborPvalues < 0:
+        errs.append('Error: --neighborPvalues should not be negative')
+    if a.neighborPvalues > L.MAX_NB:
+        errs.append('Error: --neighborPvalues larger than %d is not supported' % L.MAX_NB)
+    if a.WeightsDif < 1.0:                                                             # NanoMod.py:76-78: floor at 1.0
+        a.WeightsDif = 1.0
+    for f in (a.wrkBase1, a.wrkBase2):
+        if not os.path.isfile(f):
+            errs.append('Error: input container %s does not exist' % f)
+    return errs
+
+
+def _keys(g, chrom_ids):
+    cid = np.array([chrom_ids[c] for c in g['chrom']], dtype=np.int64) if len(g['chrom']) else np.zeros(0, np.int64)
+    sid = (g['strand'] == '-').astype(np.int64)                                       # '+' sorts before '-'
+    return (cid << 41) | (sid << 40) | g['pos'].astype(np.int64)
+
+
+def select_positions(g0, g1, min_coverage, out_level=detect.OUTPUT_ERROR, log=print):
+    """Coverage filter + intersection + ordering: the tested-position set of mtest2 as CSR arrays."""
+    # mfilter_coverage (myDetect.py:301-314): per group
+    keep0 = np.nonzero(np.diff(g0['off']) >= min_coverage)[0]
+    keep1 = np.nonzero(np.diff(g1['off']) >= min_coverage)[0]
+    names = sorted(set(g0['chrom'].tolist()) | set(g1['chrom'].tolist()))
+    chrom_ids = {c: i for i, c in enumerate(names)}
+    k0, k1 = _keys(g0, chrom_ids)[keep0], _keys(g1, chrom_ids)[keep1]
+    # positions present in both groups, in sorted (chrom, strand, pos) order (myDetect.py:421,427-431)
+    common, i0, i1 = np.intersect1d(k0, k1, assume_unique=True, return_indices=True)
+    rows0, rows1 = keep0[i0], keep1[i1]
+    sig0, off0 = container.gather_rows(g0['sig'], g0['off'], rows0)
+    sig1, off1 = container.gather_rows(g1['sig'], g1['off'], rows1)
+    npos = len(common)
+    chrom = g1['chrom'][rows1]; strand = g1['strand'][rows1]; pos = g1['pos'][rows1]; base = g1['base'][rows1]
+    mism = np.nonzero(g0['base'][rows0] != base)[0]
+    if out_level <= detect.OUTPUT_ERROR:
+        for i in mism[:20]:
+            log('Error not equal', (chrom[i], strand[i]), int(pos[i]), base[i], g0['base'][rows0][i])
+    both = detect.encode_signals(np.concatenate([sig0, sig1])) if npos else np.zeros(0, np.float32)
+    sig0, sig1 = both[:len(sig0)], both[len(sig0):]
+    rid = detect.run_ids(chrom, strand, pos)
+    n0 = np.diff(off0).astype(np.int32); n1 = np.diff(off1).astype(np.int32)
+    meta = dict(chrom=chrom, strand=strand, pos=pos, base=base, n0=n0, n1=n1, names=names,
+                chrom_id=np.array([chrom_ids[c] for c in chrom], dtype=np.int32) if npos else np.zeros(0, np.int32))
+    return meta, sig0, off0, sig1, off1, rid
+
+
+def run_detect(a, log=print):
+    g0, g1 = container.load_group(a.wrkBase1), container.load_group(a.wrkBase2)
+    t0 = time.time()
+    meta, sig0, off0, sig1, off1, rid = select_positions(g0, g1, a.MinCoverage, a.outLevel, log)
+    npos = len(rid)
+    chrom, strand, pos, base = meta['chrom'], meta['strand'], meta['pos'], meta['base']
+    method, nb = a.testMethod, a.neighborPvalues
+    dev_method = method if (method in ('stouffer', 'fisher') and nb > 0) else 'ks'
+    res = engine.detect_host(sig0, off0, sig1, off1, rid, nb=nb, weights_dif=a.WeightsDif, method=dev_method,
+                             want_mstd=a.mstd != 0, device=a.device)
+    if npos and np.any(res['status'] & L.STATUS_MWU_ALL_IDENTICAL):
+        raise ValueError('All numbers are identical in mannwhitneyu')                  # scipy 1.2.1, uncaught in the reference
+    if a.outLevel <= detect.OUTPUT_INFO:
+        log('Producing pvalues: consuming time %d' % (time.time() - t0))
+    if method != 'ks' and nb == 0:                                                     # myDetect.py:413
+        res['comb_st'], res['comb_p'] = res['ks_d'].copy(), res['ks_p'].copy()
+    os.makedirs(a.outFolder, exist_ok=True)
+    if a.SaveTest:
+        with_comb = nb > 0 and method != 'ks'                                          # myDetect.py:533
+        path = os.path.join(a.outFolder, a.FileID + '_sign_test.txt')
+        write_sign_test(path, meta, res, with_comb)
+        if a.outLevel <= detect.OUTPUT_ERROR:
+            log('Test data is saved in', path)
+        if a.mstd != 0:
+            with open(os.path.join(a.outFolder, a.FileID + '_meanstd.cvs'), 'w') as mw:   # myDetect.py:541-544
+                for i in range(npos):
+                    mw.write('%s %s %d %s %.3f %.3f %.3f %.3f\n' % (chrom[i], strand[i], pos[i], base[i], res['mean0'][i],
+                                                                    res['std0'][i], res['mean1'][i], res['std1'][i]))
+    order = rank_order(res, method, a.rankUse)
+    return meta, res, order
+
+
+def rank_order(res, method, rank_use):
+    """myDetect.py:447-462: stable ascending sort by (combined, KS, MWU) p-value (or statistic, reversed)."""
+    pind = 'p' if rank_use == 'pv' else 'st'
+    first = ('comb_p' if pind == 'p' else 'comb_st') if method != 'ks' else ('ks_p' if pind == 'p' else 'ks_d')
+    keys = (res['mwu_p' if pind == 'p' else 'mwu_u'], res['ks_p' if pind == 'p' else 'ks_d'], res[first])
+    order = np.lexsort(keys)                       # last key is the primary one; lexsort is stable
+    return order[::-1] if rank_use == 'st' else order
+
+
+def write_sign_test(path, meta, res, with_comb):
+    lib = L.load()
+    npos = len(meta['pos'])
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    cid = np.ascontiguousarray(meta['chrom_id'], dtype=np.int32)
+    names = b''.join(n.encode() + b'\0' for n in meta['names'])
+    strand = ''.join(meta['strand'].tolist()).encode()
+    base = ''.join(b[:1] if b else ' ' for b in meta['base'].tolist()).encode()
+    pos = np.ascontiguousarray(meta['pos'], dtype=np.int64)
+    n0 = np.ascontiguousarray(meta['n0'], dtype=np.int32); n1 = np.ascontiguousarray(meta['n1'], dtype=np.int32)
+    cols = [np.ascontiguousarray(res[k], dtype=np.float64) for k in ('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p')]
+    comb = [np.ascontiguousarray(res[k], dtype=np.float64) for k in ('comb_st', 'comb_p')] if with_comb else [None, None]
+    rc = lib.nmod_write_sign_test(path.encode(), npos, p(cid), names, len(meta['names']), strand, p(pos), base,
+                                  p(n0), p(n1), *[p(c) for c in cols],
+                                  *(p(c) if c is not None else None for c in comb), 1 if with_comb else 0)
+    L.check(rc, 'nmod_write_sign_test')
+
+
+def main(argv=None):
+    parser = build_parser()
+    a = parser.parse_args(argv)
+    if a.cmd != 'detect':
+        parser.print_help()
+        return 1
+    errs = validate(a)
+    if errs:
+        print('\n'.join(errs))
+        parser.parse_args(['detect', '-h']) if False else None
+        return 1
+    meta, res, order = run_detect(a)
+    top = order[:a.topN]
+    first = ('comb_p' if a.testMethod != 'ks' else 'ks_p')
+    for r, i in enumerate(top):
+        print('%d %s %s %d %s %.3E' % (r + 1, meta['chrom'][i], meta['strand'][i], meta['pos'][i] + 1, meta['base'][i],
+                                       res[first][i]))
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -7,6 +7,8 @@
 #include <math.h>
 #include <algorithm>
 #include <vector>
+#include <string>
+#include <stdio.h>
 
 #include "../../include/nanomod_hip.h"
 #include "rank_stats.hpp"
@@ -569,6 +571,53 @@ int nmod_evtimer_destroy(void* timer) {
     for (int i = 0; i < t->capacity; ++i) { hipEventDestroy(t->start[k][i]); hipEventDestroy(t->stop[k][i]); }
   delete t;
   return NMOD_OK;
+}
+
+// ---- save_test's table (myDetect.py:532-536), buffered
+static inline char* put_f3(char* p, double v) {          // '%.3f' as Python formats it
+  if (v != v) { memcpy(p, "nan", 3); return p + 3; }
+  if (v == INFINITY) { memcpy(p, "inf", 3); return p + 3; }
+  if (v == -INFINITY) { memcpy(p, "-inf", 4); return p + 4; }
+  return p + snprintf(p, 400, "%.3f", v);
+}
+static inline char* put_e3(char* p, double v) {          // '%.3E'
+  if (v != v) { memcpy(p, "NAN", 3); return p + 3; }      // Python upper-cases non-finite values under %E
+  if (v == INFINITY) { memcpy(p, "INF", 3); return p + 3; }
+  if (v == -INFINITY) { memcpy(p, "-INF", 4); return p + 4; }
+  return p + snprintf(p, 64, "%.3E", v);
+}
+
+int nmod_write_sign_test(const char* path, int64_t npos, const int32_t* chrom_id, const char* chrom_names,
+                         int32_t n_chroms, const char* strand, const int64_t* pos0, const char* base,
+                         const int32_t* n0, const int32_t* n1, const double* mwu_u, const double* mwu_p,
+                         const double* t_t, const double* t_p, const double* ks_d, const double* ks_p,
+                         const double* comb_st, const double* comb_p, int32_t with_comb) {
+  if (!path || npos < 0 || n_chroms < 0) return NMOD_ERR_INVALID_ARG;
+  if (npos > 0 && (!chrom_id || !chrom_names || !strand || !pos0 || !base || !n0 || !n1 || !mwu_u || !mwu_p || !t_t ||
+                   !t_p || !ks_d || !ks_p || (with_comb && (!comb_st || !comb_p)))) return NMOD_ERR_INVALID_ARG;
+  std::vector<const char*> names(n_chroms);
+  const char* q = chrom_names;
+  for (int i = 0; i < n_chroms; ++i) { names[i] = q; q += strlen(q) + 1; }
+  FILE* f = fopen(path, "w");
+  if (!f) return NMOD_ERR_INVALID_ARG;
+  std::vector<char> buf(1 << 22);
+  size_t used = 0;
+  for (int64_t i = 0; i < npos; ++i) {
+    if (chrom_id[i] < 0 || chrom_id[i] >= n_chroms) { fclose(f); return NMOD_ERR_INVALID_ARG; }
+    const char* cn = names[chrom_id[i]];
+    size_t need = strlen(cn) + 4096;
+    if (used + need > buf.size()) { fwrite(buf.data(), 1, used, f); used = 0; if (need > buf.size()) buf.resize(need); }
+    char* p = buf.data() + used;
+    p += snprintf(p, need - 3072, "%s %c %lld %c %d %d ", cn, strand[i], (long long)(pos0[i] + 1), base[i], n0[i], n1[i]);
+    p = put_f3(p, mwu_u[i]); *p++ = ' '; p = put_e3(p, mwu_p[i]); *p++ = ' ';
+    p = put_f3(p, t_t[i]); *p++ = ' '; p = put_e3(p, t_p[i]); *p++ = ' ';
+    p = put_f3(p, ks_d[i]); *p++ = ' '; p = put_e3(p, ks_p[i]);
+    if (with_comb) { *p++ = ' '; p = put_f3(p, comb_st[i]); *p++ = ' '; p = put_e3(p, comb_p[i]); }
+    *p++ = '\n';
+    used = p - buf.data();
+  }
+  if (used) fwrite(buf.data(), 1, used, f);
+  return fclose(f) == 0 ? NMOD_OK : NMOD_ERR_INVALID_ARG;
 }
 
 int nmod_selftest(int32_t device) {

@@ -21,11 +21,12 @@ def halo_bounds(lo, hi, nb, npos):
     return max(lo - nb, 0), min(hi + nb, npos)
 
 
-def sharded_detect(compute, npos, nb, tracks=('ks_p', 'comb_p'), group=None):
+def sharded_detect(compute, npos, nb, tracks=('ks_p', 'comb_p'), group=None, out=None):
     """Run `compute(lo_h, hi_h) -> {track: 1-D tensor over [lo_h, hi_h)}` on this rank's block
     (+ halo), drop the halo and all-gather every requested track.  Returns full-length tensors
     (identical on every rank).  `compute` is the HIP path in production; the world_size-2 CPU
-    tests inject a checker so the partition / halo / reassembly logic runs under gloo."""
+    tests inject a checker so the partition / halo / reassembly logic runs under gloo.
+    `out`: optional {track: tensor[per * world]} reused across calls (no allocation per step)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -34,23 +35,25 @@ def sharded_detect(compute, npos, nb, tracks=('ks_p', 'comb_p'), group=None):
     lo_h, hi_h = halo_bounds(lo, hi, nb, npos)
     local = compute(lo_h, hi_h) if hi > lo else {}
     per = (npos + world - 1) // world
-    out = {}
+    res = {}
     for name in tracks:
-        if hi > lo:
-            mine = local[name][lo - lo_h: lo - lo_h + (hi - lo)]
-            ref = mine
-        else:
-            ref = None
+        mine = local[name][lo - lo_h: lo - lo_h + (hi - lo)] if hi > lo else None
         if world == 1:
-            out[name] = mine
+            res[name] = mine
             continue
-        # equal-size blocks for the collective: pad the short (or empty) last blocks
-        dtype = ref.dtype if ref is not None else torch.float64
-        device = ref.device if ref is not None else torch.device('cpu')
-        buf = torch.zeros(per, dtype=dtype, device=device)
-        if ref is not None:
-            buf[: hi - lo] = mine
-        full = torch.empty(per * world, dtype=dtype, device=device)
-        dist.all_gather_into_tensor(full, buf, group=group)
-        out[name] = full[:npos]
-    return out
+        if out is not None:
+            full = out[name]
+            dtype, device = full.dtype, full.device
+        else:
+            dtype = mine.dtype if mine is not None else torch.float64
+            device = mine.device if mine is not None else torch.device('cpu')
+            full = torch.empty(per * world, dtype=dtype, device=device)
+        if mine is not None and hi - lo == per:
+            buf = mine                                   # equal blocks: gather straight from the result
+        else:                                            # short or empty last block: pad to the block size
+            buf = torch.zeros(per, dtype=dtype, device=device)
+            if mine is not None:
+                buf[: hi - lo] = mine
+        dist.all_gather_into_tensor(full, buf.contiguous(), group=group)
+        res[name] = full[:npos]
+    return res

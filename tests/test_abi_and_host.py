@@ -124,3 +124,47 @@ def test_synth_generator_restatement_is_standard_normal_like():
     b = H.synth_ref(20240601, 0, 20001, 1, 50, 10000, 0.8).reshape(20001, 50)
     assert abs(b[10000].mean() - 0.8) < 0.5 and abs(b[5000].mean()) < 0.5
     assert np.array_equal(H.synth_ref(1, 5, 10, 1, 7), H.synth_ref(1, 0, 15, 1, 7)[35:])      # counter-based
+
+
+def _fixture_containers(name, tmp):
+    """the golden fixture inputs as two per-group .npz containers (positions with no samples dropped)"""
+    from nanomod_amd import container
+    fx = H.load_inputs(name)
+    paths = []
+    for g in (0, 1):
+        off = fx['off%d' % g]
+        rows = np.nonzero(np.diff(off) > 0)[0]
+        sig, noff = container.gather_rows(fx['sig%d' % g], off, rows)
+        pth = os.path.join(tmp, 'g%d.npz' % g)
+        container.save_group(pth, fx['chrom'][rows], fx['strand'][rows], fx['pos'][rows], fx['base%d' % g][rows], noff, sig)
+        paths.append(pth)
+    return paths
+
+
+def test_cli_position_selection_and_table_writer_cpu():
+    """array-native coverage filter / intersection / order == the reference's (golden), and the C table writer
+    reproduces save_test's bytes (host-only entry point, no GPU needed)"""
+    from nanomod_amd import cli, container
+    for name, exp_name in (('ragged', 'ragged_stouffer'), ('g50', 'g50_fisher'), ('ties', 'ties_stouffer')):
+        exp, table = H.load_expected(exp_name)
+        with tempfile.TemporaryDirectory() as tmp:
+            p0, p1 = _fixture_containers(name, tmp)
+            meta, sig0, off0, sig1, off1, rid = cli.select_positions(container.load_group(p0), container.load_group(p1), 5,
+                                                                     log=lambda *a: None)
+            assert list(meta['chrom']) == list(exp['chrom']) and list(meta['pos']) == list(exp['pos'])
+            assert list(meta['strand']) == list(exp['strand']) and list(meta['base']) == list(exp['base'])
+            assert list(meta['n0']) == list(exp['n0']) and list(meta['n1']) == list(exp['n1'])
+            out = os.path.join(tmp, 't.txt')
+            cli.write_sign_test(out, meta, exp, True)
+            assert open(out).read() == table
+            order = cli.rank_order(exp, 'stouffer', 'pv')
+            assert np.array_equal(order, exp['sorted_index'])
+
+
+def test_cli_argument_validation():
+    from nanomod_amd import cli
+    a = cli.build_parser().parse_args(['detect', '--wrkBase1', '/nonexistent1', '--wrkBase2', '/nonexistent2',
+                                       '--MinCoverage', '2', '--WeightsDif', '0.5'])
+    errs = cli.validate(a)
+    assert any('MinCoverage' in e for e in errs) and sum('does not exist' in e for e in errs) == 2
+    assert a.WeightsDif == 1.0                      # floor, NanoMod.py:76-78

@@ -245,3 +245,20 @@ def test_device_resident_path_and_synth(nm):
     res4 = det.run(sig0p, sig1, rid, stride0=n, stride1=n, npos=npos)
     torch.cuda.synchronize()
     assert torch.equal(res['ks_d'], res3['ks_d']) and torch.equal(res['ks_p'], res4['ks_p'])
+
+
+@pytest.mark.parametrize('inp,name,method', [('ragged', 'ragged_stouffer', 'stouffer'), ('g50', 'g50_fisher', 'fisher'),
+                                             ('g50', 'g50_ks', 'ks'), ('ties', 'ties_stouffer', 'stouffer')])
+def test_cli_detect_end_to_end(nm, inp, name, method, capsys):
+    """python -m nanomod_amd.cli detect on .npz containers: same `_sign_test.txt` bytes as the reference run"""
+    from nanomod_amd import cli
+    from test_abi_and_host import _fixture_containers
+    exp, table = H.load_expected(name)
+    with tempfile.TemporaryDirectory() as tmp:
+        p0, p1 = _fixture_containers(inp, tmp)
+        rc = cli.main(['detect', '--wrkBase1', p0, '--wrkBase2', p1, '--FileID', 'x', '--outFolder', tmp,
+                       '--testMethod', method, '--topN', '5', '--outLevel', '3'])
+        assert rc == 0
+        assert open(os.path.join(tmp, 'x_sign_test.txt')).read() == table
+    lines = capsys.readouterr().out.strip().split('\n')
+    assert len(lines) >= 5

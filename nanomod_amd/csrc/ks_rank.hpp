@@ -117,7 +117,6 @@ void ks_rank_kernel(RankStatsArgs args) {
   constexpr int HIST_OFF = ks_region_words(C); // words from key 0 to bin 0
   constexpr int STEPS = (C == 64) ? 6 : (C == 128) ? 7 : (C == 256) ? 8 : (C == 512) ? 9 : (C == 1024) ? 10 : 11;
   static_assert((1 << STEPS) == C, "capacity must be a power of two");
-  constexpr int QV = 8;                        // Q samples per lane per loop iteration (two 16-byte loads)
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
 
   const int lane = threadIdx.x & 63;
@@ -188,80 +187,96 @@ void ks_rank_kernel(RankStatsArgs args) {
     // ---- rank every Q sample into S.  Slots past the end of Q carry FLT_MAX: they rank at L = U = m
     // without ever tying, so the loop needs no validity masks; their count is taken out of bin m below.
     const float big = 3.4028234663852886e38f;
-    const int chunks = (q + QV * LG - 1) / (QV * LG);
-    int chunks_w = chunks;
+    // full rounds of one 16-byte load per lane, then the remaining < 4*LG samples one per lane
+    const int full = q / (4 * LG);
+    const int tail = (q - full * (4 * LG) + LG - 1) / LG;
+    int full_w = full, tail_w = tail;
     if constexpr (PW > 1) {
-      chunks_w = 0;
+      full_w = 0; tail_w = 0;
 #pragma unroll
-      for (int s = 0; s < PW; ++s) chunks_w = max(chunks_w, __builtin_amdgcn_readlane(chunks, s * LG));
+      for (int s = 0; s < PW; ++s) {
+        full_w = max(full_w, __builtin_amdgcn_readlane(full, s * LG));
+        tail_w = max(tail_w, __builtin_amdgcn_readlane(tail, s * LG));
+      }
     } else {
-      chunks_w = __builtin_amdgcn_readfirstlane(chunks);
+      full_w = __builtin_amdgcn_readfirstlane(full);
+      tail_w = __builtin_amdgcn_readfirstlane(tail);
     }
     const bool q_vec = __ballot((off_q & 3) != 0) == 0ull;
     bool any_tie = false;
-#pragma unroll 1
-    for (int c = 0; c < chunks_w; ++c) {
-      float xq[QV];
-#pragma unroll
-      for (int v = 0; v < QV / 4; ++v) {
-        const int idx = (c * (QV / 4) + v) * (4 * LG) + 4 * gl;
-        float a0 = big, a1 = big, a2 = big, a3 = big;
-        if (q_vec && idx + 3 < q) {
-          if constexpr (DTYPE == 0) {
-            float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sig_q) + off_q + idx);
-            a0 = t.x; a1 = t.y; a2 = t.z; a3 = t.w;
-          } else {
-            short4 t = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(sig_q) + off_q + idx);
-            a0 = (float)t.x; a1 = (float)t.y; a2 = (float)t.z; a3 = (float)t.w;
-          }
-        } else if (idx < q) {
-          a0 = load_sample<DTYPE>(sig_q, off_q + idx);
-          if (idx + 1 < q) a1 = load_sample<DTYPE>(sig_q, off_q + idx + 1);
-          if (idx + 2 < q) a2 = load_sample<DTYPE>(sig_q, off_q + idx + 2);
-          if (idx + 3 < q) a3 = load_sample<DTYPE>(sig_q, off_q + idx + 3);
-        }
-        xq[4 * v] = a0; xq[4 * v + 1] = a1; xq[4 * v + 2] = a2; xq[4 * v + 3] = a3;
-      }
-      const float* lp[QV];
-      const float* lb32[QV];
+
+    // rank NV samples (xq) and add them to the histograms
+    auto rank_and_count = [&](auto nv_tag, const float* xq) {
+      constexpr int NV = decltype(nv_tag)::value;
+      const float* lp[NV];
+      const float* lb32[NV];
       bool tie_here = false;
 #pragma unroll
-      for (int e = 0; e < QV; ++e) lp[e] = ks_search<C, STEPS, false>(keys, xq[e], &lb32[e]);
+      for (int e = 0; e < NV; ++e) lp[e] = ks_search<C, STEPS, false>(keys, xq[e], &lb32[e]);
 #pragma unroll
-      for (int e = 0; e < QV; ++e) tie_here = tie_here || (*lp[e] == xq[e]);      // keys[skew(C)] is +inf
+      for (int e = 0; e < NV; ++e) tie_here = tie_here || (*lp[e] == xq[e]);      // keys[skew(C)] is +inf
       if (__ballot(tie_here) != 0ull) {          // ties with S: common for 3-dp rounded signals and the synthetic grid
         any_tie = true;
         // a tied sample almost always ties with ONE key: U = L + 1 (the next skewed word is +1, or +5 when
         // L is the last key of its 32-block); only if that next key ties again (duplicates inside S) fall
         // back to the full upper-bound search
-        const float* up[QV];
+        const float* up[NV];
         bool again = false;
 #pragma unroll
-        for (int e = 0; e < QV; ++e) {
+        for (int e = 0; e < NV; ++e) {
           const bool eq = (*lp[e] == xq[e]);
           const int step = ((lp[e] - lb32[e]) == 31) ? 5 : 1;
           up[e] = eq ? lp[e] + step : lp[e];
         }
 #pragma unroll
-        for (int e = 0; e < QV; ++e) again = again || (*up[e] == xq[e]);
+        for (int e = 0; e < NV; ++e) again = again || (*up[e] == xq[e]);
         if (__ballot(again) != 0ull) {
 #pragma unroll
-          for (int e = 0; e < QV; ++e) up[e] = ks_search<C, STEPS, true>(keys, xq[e]);
+          for (int e = 0; e < NV; ++e) up[e] = ks_search<C, STEPS, true>(keys, xq[e]);
         }
 #pragma unroll
-        for (int e = 0; e < QV; ++e) {
+        for (int e = 0; e < NV; ++e) {
           atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, 0x10000u);
           atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up[e])) + HIST_OFF, 1u);
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < QV; ++e)
+        for (int e = 0; e < NV; ++e)
           atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, 0x10001u);
       }
+    };
+
+#pragma unroll 1
+    for (int c = 0; c < full_w; ++c) {
+      const int idx = c * (4 * LG) + 4 * gl;
+      float xq[4] = {big, big, big, big};
+      if (c < full) {
+        if (q_vec) {
+          if constexpr (DTYPE == 0) {
+            float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sig_q) + off_q + idx);
+            xq[0] = t.x; xq[1] = t.y; xq[2] = t.z; xq[3] = t.w;
+          } else {
+            short4 t = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(sig_q) + off_q + idx);
+            xq[0] = (float)t.x; xq[1] = (float)t.y; xq[2] = (float)t.z; xq[3] = (float)t.w;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xq[e] = load_sample<DTYPE>(sig_q, off_q + idx + e);
+        }
+      }
+      rank_and_count(std::integral_constant<int, 4>{}, xq);
     }
+#pragma unroll 1
+    for (int c = 0; c < tail_w; ++c) {
+      const int idx = full * (4 * LG) + c * LG + gl;
+      float xq[1] = {big};
+      if (idx < q) xq[0] = load_sample<DTYPE>(sig_q, off_q + idx);
+      rank_and_count(std::integral_constant<int, 1>{}, xq);
+    }
+    const int slots = (full_w * 4 + tail_w) * LG;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (gl == 0) hist[ks_skew_rt(m)] -= (unsigned)(chunks_w * (QV * LG) - q) * 0x10001u;   // the FLT_MAX slots
+    if (gl == 0) hist[ks_skew_rt(m)] -= (unsigned)(slots - q) * 0x10001u;   // the FLT_MAX slots
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 

@@ -175,6 +175,20 @@ def test_int16_milli_path_matches_float_path(nm):
     assert np.allclose(got['mean0'], m0, rtol=1e-12, atol=1e-15) and np.allclose(got['std1'], s1, rtol=1e-12)
 
 
+def test_int16_ks_only_mode(nm):
+    """int16 milli-unit signals through the KS-only kernel (tie-heavy by construction), ragged"""
+    import nanomod_oracle as orc
+    L = nm._lib
+    rng = np.random.default_rng(123)
+    sig0, off0, sig1, off1, rid = _random_batch(rng, 300, 5, 700, 5, 300)
+    k0 = np.rint(sig0.astype(np.float64) * 1000).astype(np.int16)
+    k1 = np.rint(sig1.astype(np.float64) * 1000).astype(np.int16)
+    got = nm.detect_host(k0, off0, k1, off1, rid, tests=L.TEST_KS, method='fisher')
+    ks = [orc.ks_2samp(k0[off0[i]:off0[i + 1]] / 1000.0, k1[off1[i]:off1[i + 1]] / 1000.0) for i in range(300)]
+    H.assert_close_stat(got['ks_d'], np.array([k[0] for k in ks]), 0, 4.5e-16, 'ks_d')
+    H.assert_close_p(got['ks_p'], np.maximum(np.array([k[1] for k in ks]), orc.DBL_MIN), 1e-9, 'ks_p')
+
+
 def test_edge_statuses(nm):
     L = nm._lib
     # position 0: all identical; 1: zero variance in both groups but different means; 2: normal; 3: empty group

@@ -36,6 +36,11 @@ def build_parser():
     d.add_argument('--rankUse', default='pv', choices=['st', 'pv'])                    # NanoMod.py:361
     d.add_argument('--SaveTest', type=int, default=1, choices=[0, 1])                  # NanoMod.py:362
     d.add_argument('--mstd', type=int, default=0)                                      # NanoMod.py:378
+    d.add_argument('--window', type=int, default=21)                                   # NanoMod.py:351
+    d.add_argument('--RegionRankbyST', type=int, default=0, choices=[0, 1])            # NanoMod.py:363
+    d.add_argument('--percentile', type=float, default=0.1)                            # NanoMod.py:364
+    d.add_argument('--WindOvlp', type=int, default=0, choices=[0, 1])                  # NanoMod.py:365
+    d.add_argument('--NA', type=str, default='', choices=['', 'A', 'C', 'G', 'T'])     # NanoMod.py:366
     d.add_argument('--device', type=int, default=0)
     return p
 
@@ -53,6 +58,9 @@ def validate(a):
         errs.append('Error: --neighborPvalues larger than %d is not supported' % L.MAX_NB)
     if a.WeightsDif < 1.0:                                                             # NanoMod.py:76-78: floor at 1.0
         a.WeightsDif = 1.0
+    if (a.window - 1) // 2 < 1:                                                        # NanoMod.py:51-53
+        errs.append('Window size (%d) is too small' % a.window)
+    a.percentile = 0.0 if a.percentile < 0 else (0.99 if a.percentile >= 1 else a.percentile)   # NanoMod.py:91-92
     for f in (a.wrkBase1, a.wrkBase2):
         if not os.path.isfile(f):
             errs.append('Error: input container %s does not exist' % f)
@@ -121,7 +129,18 @@ def run_detect(a, log=print):
                 for i in range(npos):
                     mw.write('%s %s %d %s %.3f %.3f %.3f %.3f\n' % (chrom[i], strand[i], pos[i], base[i], res['mean0'][i],
                                                                     res['std0'][i], res['mean1'][i], res['std1'][i]))
-    order = rank_order(res, method, a.rankUse)
+    if a.RegionRankbyST == 0:
+        order = rank_order(res, method, a.rankUse)
+    else:                                                                              # myDetect.py:463-515
+        recs = []
+        for i in range(npos):
+            t = [(res['mwu_u'][i], res['mwu_p'][i]), (res['t_t'][i], res['t_p'][i]), (res['ks_d'][i], res['ks_p'][i])]
+            if method != 'ks':
+                t.append((res['comb_st'][i], res['comb_p'][i]))
+            recs.append(((str(chrom[i]), str(strand[i]), int(pos[i]), str(base[i]), int(meta['n0'][i]), int(meta['n1'][i]), i), t))
+        mo = {'sign_test': recs, 'window': (a.window - 1) // 2, 'WindOvlp': a.WindOvlp, 'percentile': a.percentile, 'NA': a.NA}
+        ranked = detect.region_rank(mo, 2 if method == 'ks' else 3, 1 if a.rankUse == 'pv' else 0)
+        order = np.array([r[0][6] for r in ranked], dtype=np.int64)
     return meta, res, order
 
 

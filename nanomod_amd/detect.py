@@ -10,7 +10,7 @@ Same names, argument meaning and error behaviour as
 `moptions` keys read (as the reference): 'ds2', <dataset>['norm_mean'|'base'|
 'basedict'][(chrom,strand)][pos], 'MinCoverage', 'neighborPvalues',
 'WeightsDif', 'testMethod', 'rankUse', 'SaveTest', 'outFolder', 'FileID',
-'mstd', 'coverages', 'RegionRankbyST', 'outLevel'.
+'mstd', 'coverages', 'RegionRankbyST' (+ 'window', 'WindOvlp', 'percentile', 'NA'), 'outLevel'.
 Keys written: 'sign_test', 'sorted_sign_test', optionally 'sign_test_mstd',
 plus 'sign_test_arrays' (the same numbers as numpy arrays, an addition).
 """
@@ -202,10 +202,64 @@ def build_csr(moptions):
     return meta, sig0, off0, sig1, off1, rid
 
 
+# myDetect.py:463-515 — ranking of windows instead of single positions (--RegionRankbyST 1)
+def region_rank(moptions, sorted_ind, use_pind):
+    """A window = the positions pk-w .. pk+w (w = moptions['window'] + 1: the reference increments the
+    option in place) that all exist on one (chrom, strand) and lie below the last tested position of
+    that strand; its key is the `percentile`-th smallest p (or statistic) of the window, ties broken by
+    the distance of the window minimum from the centre.  Only bases equal to moptions['NA'] contribute
+    when that option is set; windows with <= 5 contributing values are dropped.  With WindOvlp == 1 the
+    windows slide by one position and a window is suppressed when a better-ranked one on the same strand
+    lies closer than w.  Host-side: the p-value track comes from the GPU, this is a few passes over it."""
+    moptions['window'] = moptions['window'] + 1
+    w = moptions['window']
+    movesize = 1 if moptions['WindOvlp'] == 1 else w
+    na = moptions.get('NA', '')
+    pct = moptions['percentile']
+    by_strand = {}
+    order = []
+    for rec in moptions['sign_test']:
+        sk = (rec[0][0], rec[0][1])
+        if sk not in by_strand:
+            by_strand[sk] = {}
+            order.append(sk)
+        by_strand[sk][rec[0][2]] = rec
+    windseg = []
+    for sk in sorted(by_strand.keys()):
+        d = by_strand[sk]
+        pmax = None
+        for rec in moptions['sign_test']:           # the reference keeps the LAST position seen (= the largest: sorted input)
+            if (rec[0][0], rec[0][1]) == sk:
+                pmax = rec[0][2]
+        pmin = min(d.keys())
+        for pk in range(pmin, pmax, movesize):
+            vals = []
+            complete = True
+            for wind in range(-w, w + 1):
+                cur = pk + wind
+                if cur < 0 or cur >= pmax or cur not in d:
+                    complete = False
+                    break
+                rec = d[cur]
+                if (not na) or na == rec[0][3]:
+                    vals.append(rec[1][sorted_ind][use_pind])
+            if complete and len(vals) > 5:
+                windseg.append((d[pk], sorted(vals), vals))
+    windseg.sort(key=lambda ws: (ws[1][int(pct * (len(ws[1]) - 1) + 0.5)], abs(w - ws[2].index(ws[1][0]))))
+    ranked = []
+    kept = []
+    for ws in windseg:
+        key = ws[0][0]
+        if moptions['WindOvlp'] == 1:
+            if any(k[0] == key[0] and k[1] == key[1] and abs(k[2] - key[2]) < w for k in kept):
+                continue
+            kept.append(key)
+        ranked.append(ws[0])
+    return ranked
+
+
 # myDetect.py:416-462
 def mtest2(moptions):
-    if moptions.get('RegionRankbyST', 0) != 0:
-        raise NotImplementedError('RegionRankbyST ranking (myDetect.py:463-515) is a "next" row (SURVEY.md §8f)')
     cov = moptions.get('coverages', (0, 0))
     if int(cov[0]) > 0 or int(cov[1]) > 0:
         raise NotImplementedError('down-sampling KS (myDetect.py:345-361) is outside the parity contract')
@@ -249,10 +303,13 @@ def mtest2(moptions):
     save_test(moptions)
     if method != 'ks' and nb < 0:
         raise IndexError('list index out of range')            # the reference indexes mpv[1][3] here
-    moptions['sorted_sign_test'] = sorted(
-        sign_test, key=lambda mpv: (mpv[1][sorted_ind][use_pind], mpv[1][2][use_pind], mpv[1][0][use_pind]))
-    if use_pind == 0:
-        moptions['sorted_sign_test'] = moptions['sorted_sign_test'][::-1]
+    if moptions.get('RegionRankbyST', 0) == 0:
+        moptions['sorted_sign_test'] = sorted(
+            sign_test, key=lambda mpv: (mpv[1][sorted_ind][use_pind], mpv[1][2][use_pind], mpv[1][0][use_pind]))
+        if use_pind == 0:
+            moptions['sorted_sign_test'] = moptions['sorted_sign_test'][::-1]
+    else:
+        moptions['sorted_sign_test'] = region_rank(moptions, sorted_ind, use_pind)
 
 
 # myDetect.py:522-545

@@ -132,6 +132,21 @@ def build_moptions(fx, outdir, file_id, nb, wdif, method, min_cov=5, mstd=0):
     return mo
 
 
+def run_reference_region_rank(myDetect, fx, method, window, wind_ovlp, percentile, na, rank_use='pv'):
+    """mtest2 with RegionRankbyST=1 (myDetect.py:463-515): returns the ranked window centres."""
+    with tempfile.TemporaryDirectory() as outdir:
+        mo = build_moptions(fx, outdir, 'rr', 2, 2.0, method)
+        mo.update({'RegionRankbyST': 1, 'window': window, 'WindOvlp': wind_ovlp, 'percentile': percentile, 'NA': na,
+                   'rankUse': rank_use, 'SaveTest': 0})
+        with contextlib.redirect_stdout(io.StringIO()):
+            myDetect.mfilter_coverage(mo)
+            myDetect.mtest2(mo)
+    sst = mo['sorted_sign_test']
+    return {'chrom': np.array([r[0][0] for r in sst]), 'strand': np.array([r[0][1] for r in sst]),
+            'pos': np.array([r[0][2] for r in sst], dtype=np.int64), 'base': np.array([r[0][3] for r in sst]),
+            'window_after': np.int64(mo['window'])}
+
+
 def run_reference_table(myDetect, fx, nb, wdif, method, file_id, min_cov=5):
     with tempfile.TemporaryDirectory() as outdir:
         mo = build_moptions(fx, outdir, file_id, nb, wdif, method, min_cov)
@@ -315,6 +330,13 @@ def main():
         for method in ('stouffer', 'fisher', 'ks'):
             exp, table = run_reference_table(myDetect, fx, 2, 2.0, method, 'g50_' + method)
             save_expected('g50_' + method, exp, table)
+        # region ranking (RegionRankbyST=1) on the same inputs
+        for tag, method, window, ovlp, pct, na, ru in (('w10_o0', 'stouffer', 10, 0, 0.1, '', 'pv'), ('w10_o1', 'stouffer', 10, 1, 0.1, '', 'pv'),
+                                                       ('w3_o1_A', 'fisher', 3, 1, 0.3, 'A', 'pv'), ('w5_o0_ks', 'ks', 5, 0, 0.0, '', 'pv'),
+                                                       ('w4_o1_st', 'stouffer', 4, 1, 0.5, '', 'st')):
+            rr = run_reference_region_rank(myDetect, fx, method, window, ovlp, pct, na, ru)
+            np.savez_compressed(os.path.join(OUT, 'g50_regionrank_%s.npz' % tag), method=method, window=window,
+                                WindOvlp=ovlp, percentile=pct, NA=na, rankUse=ru, **rr)
         fx = make_ragged(rng)
         save_fixture('ragged', fx)
         for method in ('stouffer', 'fisher'):

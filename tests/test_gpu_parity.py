@@ -276,3 +276,23 @@ def test_cli_detect_end_to_end(nm, inp, name, method, capsys):
         assert open(os.path.join(tmp, 'x_sign_test.txt')).read() == table
     lines = capsys.readouterr().out.strip().split('\n')
     assert len(lines) >= 5
+
+
+def test_region_rank_through_mtest2_and_cli(nm, capsys):
+    """RegionRankbyST=1 end to end on the GPU numbers: mtest2 on moptions and the CLI give the reference's window order"""
+    from nanomod_amd import cli
+    from test_abi_and_host import _fixture_containers
+    z = np.load(os.path.join(H.GOLDEN, 'g50_regionrank_w10_o1.npz'))
+    fx = H.load_inputs('g50')
+    with tempfile.TemporaryDirectory() as tmp:
+        mo = H.build_moptions(fx, tmp, 'rr', 2, 2.0, 'stouffer')
+        mo.update({'RegionRankbyST': 1, 'window': 10, 'WindOvlp': 1, 'percentile': 0.1, 'NA': '', 'SaveTest': 0})
+        nm.mfilter_coverage(mo)
+        nm.mtest2(mo)
+        assert [r[0][2] for r in mo['sorted_sign_test']] == list(z['pos'])
+        p0, p1 = _fixture_containers('g50', tmp)
+        rc = cli.main(['detect', '--wrkBase1', p0, '--wrkBase2', p1, '--FileID', 'x', '--outFolder', tmp, '--RegionRankbyST', '1',
+                       '--WindOvlp', '1', '--window', '21', '--topN', '7', '--outLevel', '3'])
+        assert rc == 0
+    lines = [l for l in capsys.readouterr().out.strip().split('\n') if l and l[0].isdigit()]
+    assert [int(l.split()[3]) - 1 for l in lines[-7:]] == list(z['pos'][:7])

@@ -225,7 +225,9 @@ void ks_rank_kernel(RankStatsArgs args) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
           const bool eq = (*lp[e] == xq[e]);
-          const int step = ((lp[e] - lb32[e]) == 31) ? 5 : 1;
+          // (32-bit LDS offsets: a generic-pointer difference would be computed in 64 bits)
+          const unsigned dl = (unsigned)(uintptr_t)lp[e] - (unsigned)(uintptr_t)lb32[e];
+          const int step = (dl == 31u * 4u) ? 5 : 1;
           up[e] = eq ? lp[e] + step : lp[e];
         }
 #pragma unroll

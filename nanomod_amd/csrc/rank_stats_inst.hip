@@ -69,8 +69,15 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
                             const RankStatsArgs& args) {
   const bool ks = cls >= kKsClassBase;
   const bool packed = !ks && cls >= kNumGeneralClasses;
-  KernelFn fn = ks ? pick_ks(cls - kKsClassBase)
-                   : packed ? pick_packed(cls - kNumGeneralClasses) : pick(cls / kNumSizeClasses, cls % kNumSizeClasses);
+  // KS-only builds carry only the ks_rank kernels; the merge-path kernels are instantiated for all-tests mode
+  KernelFn fn = nullptr;
+  if constexpr (ALL) {
+    if (ks) return hipErrorInvalidValue;
+    fn = packed ? pick_packed(cls - kNumGeneralClasses) : pick(cls / kNumSizeClasses, cls % kNumSizeClasses);
+  } else {
+    if (!ks) return hipErrorInvalidValue;
+    fn = pick_ks(cls - kKsClassBase);
+  }
   const size_t lds = rank_stats_lds_bytes(cls, ALL);
   if (ks || packed) {
     const int pw = ks ? ks_positions_per_wave(cls - kKsClassBase) : packed_positions_per_wave(cls - kNumGeneralClasses);

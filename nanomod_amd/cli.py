@@ -24,8 +24,10 @@ def build_parser():
     sub = p.add_subparsers(dest='cmd')
     d = sub.add_parser('detect', help='per-base KS / MWU / Welch-t tests + window combine')
     d.add_argument('--outLevel', type=int, default=2, choices=[0, 1, 2, 3])           # NanoMod.py:348
-    d.add_argument('--wrkBase1', required=True, help='.npz container of read group 1 (reference: a FAST5 folder)')
-    d.add_argument('--wrkBase2', required=True, help='.npz container of read group 2')
+    d.add_argument('--wrkBase1', required=True, help='read group 1: a .npz container, or a FAST5 folder (needs h5py)')
+    d.add_argument('--wrkBase2', required=True, help='read group 2: a .npz container, or a FAST5 folder (needs h5py)')
+    d.add_argument('--min_lr', type=int, default=500)                                  # NanoMod.py:387
+    d.add_argument('--min_lr_nb', type=int, default=0)
     d.add_argument('--FileID', default='mod')                                          # NanoMod.py:349
     d.add_argument('--outFolder', default='mRes')                                      # NanoMod.py:350
     d.add_argument('--MinCoverage', type=int, default=5)                               # NanoMod.py:354
@@ -62,8 +64,8 @@ def validate(a):
         errs.append('Window size (%d) is too small' % a.window)
     a.percentile = 0.0 if a.percentile < 0 else (0.99 if a.percentile >= 1 else a.percentile)   # NanoMod.py:91-92
     for f in (a.wrkBase1, a.wrkBase2):
-        if not os.path.isfile(f):
-            errs.append('Error: input container %s does not exist' % f)
+        if not (os.path.isfile(f) or os.path.isdir(f)):
+            errs.append('Error: input %s does not exist' % f)
     return errs
 
 
@@ -101,8 +103,16 @@ def select_positions(g0, g1, min_coverage, out_level=detect.OUTPUT_ERROR, log=pr
     return meta, sig0, off0, sig1, off1, rid
 
 
+def load_input(path, a, log=print):
+    """A `.npz` container, or a folder of resquiggled FAST5 files read like ReadAllFast5 (myDetect.py:547-633)."""
+    if os.path.isdir(path):
+        from . import fast5_ingest
+        return fast5_ingest.ingest_folder(path, {'min_lr': a.min_lr, 'min_lr_nb': a.min_lr_nb}, log=log)
+    return container.load_group(path)
+
+
 def run_detect(a, log=print):
-    g0, g1 = container.load_group(a.wrkBase1), container.load_group(a.wrkBase2)
+    g0, g1 = load_input(a.wrkBase1, a, log), load_input(a.wrkBase2, a, log)
     t0 = time.time()
     meta, sig0, off0, sig1, off1, rid = select_positions(g0, g1, a.MinCoverage, a.outLevel, log)
     npos = len(rid)

@@ -132,6 +132,84 @@ def build_moptions(fx, outdir, file_id, nb, wdif, method, min_cov=5, mstd=0):
     return mo
 
 
+# ------------------------------------------------------------ FAST5 ingest through the reference's reader
+class _FakeH5File:
+    """What the reference touches of an h5py.File (myDetect.py:42-72, myFast5.py:92-126), served from a
+    placeholder file written by make_fast5_reads()."""
+    def __init__(self, fn, mode='r'):
+        z = np.load(fn, allow_pickle=False)
+        self._has_align = bool(z['has_align'])
+        ev = np.zeros(len(z['norm_mean']), dtype=[('norm_mean', '<f8'), ('norm_stdev', '<f8'), ('start', '<u4'),
+                                                 ('length', '<u4'), ('base', 'U1')])
+        ev['norm_mean'] = z['norm_mean']; ev['base'] = z['base']
+        self._events = types.SimpleNamespace(value=ev)
+        self._align = types.SimpleNamespace(attrs={'mapped_chrom': str(z['chrom']), 'mapped_start': int(z['start']),
+                                                   'mapped_strand': str(z['strand'])})
+    def __contains__(self, key):
+        return ('Alignment' in key and self._has_align) or key.endswith('/Events')
+    def __getitem__(self, key):
+        return self._align if key.endswith('/Alignment') else self._events
+
+
+def make_fast5_reads(rng):
+    """Synthetic resquiggled reads of two groups over two chromosomes / both strands; some too short
+    (min_lr filter), one without alignment, nested sub-folders and a 'mall' folder that must be skipped."""
+    reads = []
+    for g in (0, 1):
+        for k in range(60):
+            chrom = 'chrA' if k % 3 else 'chrB'
+            strand = '+' if k % 2 else '-'
+            start = int(rng.integers(0, 400))
+            n = int(rng.integers(20, 120)) if k % 10 == 0 else int(rng.integers(500, 700))
+            nm = np.round(rng.normal(0.3 * g if (k % 7 == 0) else 0.0, 1.0, n), 3)
+            ref = np.array(list('ACGT'))[(np.arange(start, start + n) * 7 + (1 if chrom == 'chrB' else 0)) % 4]
+            base = ref if strand == '+' else ref[::-1]
+            sub = '' if k % 4 else ('sub%d/' % (k % 3)) + ('deep/' if k % 8 == 0 else '')
+            if k == 13:
+                sub = 'mall/'
+            reads.append(dict(group=g, rel='%sread_%d_%d.fast5' % (sub, g, k), chrom=chrom, strand=strand, start=start,
+                              norm_mean=nm, base=base, has_align=(k != 21)))
+    return reads
+
+
+def write_fast5_placeholders(reads, root):
+    for r in reads:
+        path = os.path.join(root, 'grp%d' % r['group'], r['rel'])
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'wb') as f:
+            np.savez(f, chrom=r['chrom'], strand=r['strand'], start=r['start'], norm_mean=r['norm_mean'], base=r['base'],
+                     has_align=r['has_align'])
+
+
+def run_reference_ingest(myDetect, reads):
+    sys.modules['h5py'].File = _FakeH5File
+    myDetect.h5py = sys.modules['h5py']
+    import myFast5 as _unused  # noqa: F401  (stub module; the paths below are what the reference defines)
+    mf = sys.modules['myFast5']
+    mf.rawAlignment_full = '/Analyses/NanomoCorrected_000/BaseCalled_template/Alignment'
+    mf.ReadMapInfoInRef = lambda f5: [f5[mf.rawAlignment_full].attrs['mapped_chrom'], int(f5[mf.rawAlignment_full].attrs['mapped_start']),
+                                      f5[mf.rawAlignment_full].attrs['mapped_strand']]
+    mf.ReadNanoraw_events = lambda f5: f5['/Analyses/NanomoCorrected_000/BaseCalled_template/Events'].value
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        write_fast5_placeholders(reads, root)
+        mo = {'wrkBase1': os.path.join(root, 'grp0'), 'wrkBase2': os.path.join(root, 'grp1'), '.fast5': '.fast5',
+              'outLevel': 3, 'min_lr': 500, 'min_lr_nb': 0, 'window': 10}
+        with contextlib.redirect_stdout(io.StringIO()):
+            myDetect.ReadAllFast5(mo)
+        for g, key in enumerate(mo['ds2']):
+            ds = mo[key]
+            chrom, strand, pos, base, chunks = [], [], [], [], []
+            for sk in sorted(ds['norm_mean'].keys()):
+                for pk in sorted(ds['norm_mean'][sk].keys()):
+                    chrom.append(sk[0]); strand.append(sk[1]); pos.append(pk); base.append(ds['base'][sk][pk])
+                    chunks.append(np.sort(np.asarray(ds['norm_mean'][sk][pk], dtype=np.float64)))
+            off = np.zeros(len(pos) + 1, dtype=np.int64); off[1:] = np.cumsum([len(c) for c in chunks])
+            out[g] = dict(chrom=np.array(chrom), strand=np.array(strand), pos=np.array(pos, dtype=np.int64),
+                          base=np.array(base), off=off, sig=np.concatenate(chunks))
+    return out
+
+
 def run_reference_region_rank(myDetect, fx, method, window, wind_ovlp, percentile, na, rank_use='pv'):
     """mtest2 with RegionRankbyST=1 (myDetect.py:463-515): returns the ranked window centres."""
     with tempfile.TemporaryDirectory() as outdir:
@@ -337,6 +415,18 @@ def main():
             rr = run_reference_region_rank(myDetect, fx, method, window, ovlp, pct, na, ru)
             np.savez_compressed(os.path.join(OUT, 'g50_regionrank_%s.npz' % tag), method=method, window=window,
                                 WindOvlp=ovlp, percentile=pct, NA=na, rankUse=ru, **rr)
+        # FAST5 ingest: the reference's ReadAllFast5 over placeholder reads (stub h5py)
+        reads = make_fast5_reads(np.random.default_rng(77))
+        np.savez_compressed(os.path.join(OUT, 'fast5_reads.npz'),
+                            group=np.array([r['group'] for r in reads]), rel=np.array([r['rel'] for r in reads]),
+                            chrom=np.array([r['chrom'] for r in reads]), strand=np.array([r['strand'] for r in reads]),
+                            start=np.array([r['start'] for r in reads]), has_align=np.array([r['has_align'] for r in reads]),
+                            off=np.cumsum([0] + [len(r['norm_mean']) for r in reads]),
+                            norm_mean=np.concatenate([r['norm_mean'] for r in reads]),
+                            base=np.concatenate([r['base'] for r in reads]))
+        ing = run_reference_ingest(myDetect, reads)
+        for g in (0, 1):
+            np.savez_compressed(os.path.join(OUT, 'fast5_expected_g%d.npz' % g), **ing[g])
         fx = make_ragged(rng)
         save_fixture('ragged', fx)
         for method in ('stouffer', 'fisher'):

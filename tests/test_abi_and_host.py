@@ -191,3 +191,37 @@ def test_region_rank_matches_reference(tag):
     assert mo['window'] == int(z['window_after'])
     assert [r[0][2] for r in ranked] == list(z['pos'])
     assert [r[0][3] for r in ranked] == list(z['base'])
+
+
+def test_fast5_ingest_matches_reference_reader():
+    """The array-native FAST5 ingest (walk order, min_lr filter, strand-aware position mapping, last-read base)
+    builds what the reference's ReadAllFast5 builds from the same reads (golden, stub h5py); the HDF5 access
+    itself sits behind `reader`, so no h5py is needed here."""
+    from nanomod_amd import fast5_ingest
+    z = np.load(os.path.join(H.GOLDEN, 'fast5_reads.npz'))
+    with tempfile.TemporaryDirectory() as root:
+        for i in range(len(z['rel'])):
+            path = os.path.join(root, 'grp%d' % z['group'][i], str(z['rel'][i]))
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            a, b = z['off'][i], z['off'][i + 1]
+            with open(path, 'wb') as f:
+                np.savez(f, chrom=z['chrom'][i], strand=z['strand'][i], start=z['start'][i], norm_mean=z['norm_mean'][a:b],
+                         base=z['base'][a:b], has_align=z['has_align'][i])
+
+        def reader(path):
+            r = np.load(path)
+            if not bool(r['has_align']):
+                return None
+            return str(r['chrom']), int(r['start']), str(r['strand']), r['norm_mean'], r['base']
+        for g in (0, 1):
+            got = fast5_ingest.ingest_folder(os.path.join(root, 'grp%d' % g), {'min_lr': 500, 'min_lr_nb': 0}, reader,
+                                             log=lambda *a: None)
+            exp = np.load(os.path.join(H.GOLDEN, 'fast5_expected_g%d.npz' % g))
+            for k in ('chrom', 'strand', 'pos', 'base', 'off'):
+                assert np.array_equal(got[k], exp[k]), k
+            sig = np.concatenate([np.sort(got['sig'][got['off'][i]:got['off'][i + 1]]) for i in range(len(got['pos']))])
+            assert np.array_equal(sig, exp['sig'])            # per position: the same multiset of samples
+    # the filters
+    assert not fast5_ingest.read_passes_filters(100, 'c', 0, '+', {'min_lr': 500}, log=lambda *a: None)
+    assert fast5_ingest.read_passes_filters(600, 'c', 0, '+', {'min_lr': 500, 'Chr': 'c'})
+    assert not fast5_ingest.read_passes_filters(600, 'c', 0, '+', {'min_lr': 500, 'Chr': 'd'})

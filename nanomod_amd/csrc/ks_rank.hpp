@@ -104,10 +104,11 @@ __device__ __forceinline__ const float* ks_search(const float* base, float x, co
   return all ? base + ks_skew(C) : p;
 }
 
-// second launch-bound argument = minimum waves per SIMD: keeps the R <= 16 forms at <= 128 VGPRs
-// (the compiler otherwise spends 130+ registers on scheduling freedom and occupancy drops to 3)
+// second launch-bound argument = minimum waves per SIMD: keeps every form whose LDS footprint allows
+// four waves per SIMD at <= 128 VGPRs (the compiler otherwise spends 130-175 registers on scheduling
+// freedom and occupancy drops to 2-3); no spills result
 template <int R, int LG, int DTYPE>
-__global__ __launch_bounds__(64 * kWavesPerBlock, (R <= 16 ? 4 : 2))
+__global__ __launch_bounds__(64 * kWavesPerBlock, (LG <= 32 ? 4 : 2))
 void ks_rank_kernel(RankStatsArgs args) {
   static_assert(LG == 8 || LG == 16 || LG == 32 || LG == 64, "lanes per sorted group");
   static_assert(R >= 8 && R <= 32 && (R & (R - 1)) == 0, "registers per lane");

@@ -256,6 +256,7 @@ template <int R, int LG, int DTYPE, bool ALL>
 __global__ __launch_bounds__(64 * kWavesPerBlock)
 void rank_stats_packed_kernel(RankStatsArgs args) {
   static_assert(LG == 8 || LG == 16 || LG == 32, "lanes per group");
+  static_assert(R <= 32, "the per-lane step bitmasks of the merge loop are 32 bits wide");
   constexpr int C = R * LG;                       // capacity per group
   constexpr int LP = 2 * LG;                      // lanes per position
   constexpr int PW = 64 / LP;                     // positions per wave
@@ -368,7 +369,7 @@ void rank_stats_packed_kernel(RankStatsArgs args) {
     int tn0 = d0 * n0;                             // (i + j) * n0
     unsigned best = 0, s_lane = 0, tie_lane = 0;
     const int i_start = i;
-    unsigned long long amask = 0, tmask = 0;
+    unsigned amask = 0, tmask = 0;                 // one bit per step: per <= 2*C/LP = R <= 32
 #pragma unroll 1
     for (int s = 0; s < steps_w; ++s) {
       const bool act = s < my_steps;
@@ -384,7 +385,7 @@ void rank_stats_packed_kernel(RankStatsArgs args) {
         const int cross = takeA ? ((b == v) ? (rb_e - j) : 0) : ((la == v) ? (i - ra_s) : 0);
         const int t = ownlen + cross;
         s_lane += tA ? (unsigned)(2 * j + cross) : 0u;
-        tie_lane += act ? (unsigned)(t * t - 1) : 0u;
+        tie_lane += act ? (unsigned)(__mul24(t, t) - 1) : 0u;     // t <= 2*C <= 4096
         la = tA ? v : la;
       }
       i += tA ? 1 : 0;
@@ -399,8 +400,8 @@ void rank_stats_packed_kernel(RankStatsArgs args) {
       const unsigned mag = (unsigned)abs(num);
       const unsigned magc = cand ? mag : 0u;
       if constexpr (ALL) {
-        const unsigned long long bit = 1ull << s;
-        amask |= tA ? bit : 0ull;
+        const unsigned bit = 1u << s;
+        amask |= tA ? bit : 0u;
         tmask = (magc > best) ? bit : ((cand && magc == best) ? (tmask | bit) : tmask);
       }
       best = max(best, magc);
@@ -409,13 +410,13 @@ void rank_stats_packed_kernel(RankStatsArgs args) {
     best = pos_max_u32<LG>(best, lane);
     const bool writer = valid && pl == 0;
     if constexpr (ALL) {
-      unsigned long long tm = (lane_best == best && best > 0) ? tmask : 0ull;
+      unsigned tm = (lane_best == best && best > 0) ? tmask : 0u;
       double dmax = 0.0;
-      while (__ballot(tm != 0ull)) {
-        if (tm != 0ull) {
-          const int st = __ffsll((long long)tm) - 1;
-          tm &= tm - 1ull;
-          const int c0 = i_start + __popcll(amask & ((2ull << st) - 1ull));
+      while (__ballot(tm != 0u)) {
+        if (tm != 0u) {
+          const int st = __ffs((int)tm) - 1;
+          tm &= tm - 1u;
+          const int c0 = i_start + __popc(amask & (unsigned)((2ull << st) - 1ull));
           const int c1 = (d0 + st + 1) - c0;
           dmax = fmax(dmax, fabs((double)c0 / (double)n0 - (double)c1 / (double)n1));
         }

@@ -296,3 +296,38 @@ def test_region_rank_through_mtest2_and_cli(nm, capsys):
         assert rc == 0
     lines = [l for l in capsys.readouterr().out.strip().split('\n') if l and l[0].isdigit()]
     assert [int(l.split()[3]) - 1 for l in lines[-7:]] == list(z['pos'][:7])
+
+
+def test_device_path_unknown_max_side_stream_and_too_large_hint(nm):
+    """DEVICE mode corners: max_n unknown (library reduces the offsets and synchronises once), a non-default
+    stream, and a max_n hint smaller than a position (that position gets STATUS_TOO_LARGE and NaN, the rest is exact)"""
+    import torch
+    import nanomod_oracle as orc
+    L = nm._lib
+    rng = np.random.default_rng(8)
+    sig0, off0, sig1, off1, rid = _random_batch(rng, 400, 5, 300, 5, 120)
+    dev = 'cuda:0'
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d0, o0, d1, o1, r = t(sig0), t(off0), t(sig1), t(off1), t(rid)
+    exp = orc.detect_batch(sig0, off0, sig1, off1, rid, 2, 2.0, orc.METHOD_STOUFFER)
+    for tests in (L.TEST_ALL, L.TEST_KS):
+        det = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=tests)
+        res = det.run(d0, d1, r, off0=o0, off1=o1)                       # max_n0 = max_n1 = 0: unknown
+        torch.cuda.synchronize()
+        H.assert_close_p(res['ks_p'].cpu().numpy(), exp['ks_p'], 1e-9, 'ks_p')
+        H.assert_close_p(res['comb_p'].cpu().numpy(), exp['comb_p'], 1e-9, 'comb_p')
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            res2 = det.run(d0, d1, r, off0=o0, off1=o1, max_n0=300, max_n1=120)
+        side.synchronize()
+        assert torch.equal(res['ks_p'], res2['ks_p']) and torch.equal(res['comb_p'], res2['comb_p'])
+        # a hint that is too small for some positions
+        n0 = np.diff(off0)
+        res3 = det.run(d0, d1, r, off0=o0, off1=o1, max_n0=128, max_n1=128)
+        torch.cuda.synchronize()
+        st = res3['status'].cpu().numpy(); ksp = res3['ks_p'].cpu().numpy()
+        big = n0 > 128
+        assert big.any() and np.all((st[big] & L.STATUS_TOO_LARGE) != 0) and np.all(np.isnan(ksp[big]))
+        assert np.all(st[~big] & L.STATUS_TOO_LARGE == 0)
+        H.assert_close_p(ksp[~big], exp['ks_p'][~big], 1e-9, 'ks_p small')

@@ -78,7 +78,7 @@ static Workspace carve(void* base, int64_t npos) {
 // ---------------------------------------------------------------- binning kernels
 struct BinArgs {
   int64_t npos; const int64_t* off0; const int64_t* off1; int64_t stride0, stride1;
-  int cmax0, cmax1; int ks_only; uint8_t* cls; int32_t* meta; int32_t* order;
+  int cmax0, cmax1; int ks_only; int64_t lim0, lim1; uint8_t* cls; int32_t* meta; int32_t* order;
 };
 
 
@@ -104,7 +104,10 @@ __global__ __launch_bounds__(256) void classify_kernel(BinArgs a) {
     int64_t n0 = a.stride0 > 0 ? a.stride0 : a.off0[p + 1] - a.off0[p];
     int64_t n1 = a.stride1 > 0 ? a.stride1 : a.off1[p + 1] - a.off1[p];
     int c0 = size_class_of(n0), c1 = size_class_of(n1);
-    int cid = (c0 > a.cmax0 || c1 > a.cmax1 || n0 <= 0 || n1 <= 0) ? 255
+    // KS-only: only the smaller (sorted) group is capacity-bound; the other is bounded by the promised maxima
+    const bool over = a.ks_only ? ((c0 < c1 ? c0 : c1) >= kNumSizeClasses || n0 > a.lim0 || n1 > a.lim1)
+                                : (c0 > a.cmax0 || c1 > a.cmax1);
+    int cid = (over || n0 <= 0 || n1 <= 0) ? 255
               : a.ks_only ? kKsClassBase + (c0 < c1 ? c0 : c1) : launch_class_of(c0, c1);
     a.cls[p] = (uint8_t)cid;
     if (cid != 255) atomicAdd(&hist[cid], 1);
@@ -232,7 +235,16 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     if (max1 <= 0) max1 = mx[1];
   }
   int cmax0 = size_class_of(std::max<int64_t>(max0, 1)), cmax1 = size_class_of(std::max<int64_t>(max1, 1));
-  if (cmax0 >= kNumSizeClasses || cmax1 >= kNumSizeClasses) return NMOD_ERR_TOO_LARGE;
+  if (all) {
+    if (cmax0 >= kNumSizeClasses || cmax1 >= kNumSizeClasses) return NMOD_ERR_TOO_LARGE;
+  } else {
+    // KS-only: the smaller group of a position is sorted (<= NMOD_MAX_GROUP), the other is only ranked
+    // (a position whose smaller group exceeds the capacity gets NMOD_STATUS_TOO_LARGE from the classifier;
+    //  the maxima alone cannot tell, because they may come from different positions)
+    if (std::max(max0, max1) > NMOD_MAX_RANKED) return NMOD_ERR_TOO_LARGE;
+    if (uniform && std::min(max0, max1) > NMOD_MAX_GROUP) return NMOD_ERR_TOO_LARGE;
+    cmax0 = std::min(cmax0, kNumSizeClasses - 1); cmax1 = std::min(cmax1, kNumSizeClasses - 1);
+  }
 
   RankStatsArgs ra;
   memset(&ra, 0, sizeof(ra));
@@ -254,7 +266,8 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   } else {
     BinArgs ba;
     ba.npos = npos; ba.off0 = off0; ba.off1 = off1; ba.stride0 = ra.stride0; ba.stride1 = ra.stride1;
-    ba.cmax0 = cmax0; ba.cmax1 = cmax1; ba.ks_only = all ? 0 : 1; ba.cls = ws.cls; ba.meta = ws.meta; ba.order = ws.order;
+    ba.cmax0 = cmax0; ba.cmax1 = cmax1; ba.ks_only = all ? 0 : 1; ba.lim0 = std::max<int64_t>(max0, 1); ba.lim1 = std::max<int64_t>(max1, 1);
+    ba.cls = ws.cls; ba.meta = ws.meta; ba.order = ws.order;
     unsigned blocks = (unsigned)std::min<int64_t>((npos + 255) / 256, 4096);
     hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, stream, ba);
     hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(64), 0, stream, ws.meta);
@@ -277,7 +290,8 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   fa.npos = npos; fa.off0 = off0; fa.off1 = off1; fa.stride0 = ra.stride0; fa.stride1 = ra.stride1;
   fa.ks_num = ws.ks_num; fa.mwu_s = ws.mwu_s; fa.tie = ws.tie; fa.moments = ws.moments; fa.ks_d_ref = all ? ws.ks_d_ref : nullptr;
   fa.tests = tests; fa.want_mstd = prm->want_mstd; fa.out = *out;
-  fa.max_n0 = 64LL << cmax0; fa.max_n1 = 64LL << cmax1;
+  fa.max_n0 = all ? (64LL << cmax0) : std::max<int64_t>(max0, 1); fa.max_n1 = all ? (64LL << cmax1) : std::max<int64_t>(max1, 1);
+  fa.min_cap = all ? 0 : NMOD_MAX_GROUP;
   if (want_comb) {                       // the combine needs the KS track even if the caller does not
     if (!fa.out.ks_d) fa.out.ks_d = ws.tmp_ks_d;
     if (!fa.out.ks_p) fa.out.ks_p = ws.tmp_ks_p;
@@ -316,7 +330,18 @@ static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, c
   int64_t m0 = prm->stride0 > 0 ? prm->stride0 : 0, m1 = prm->stride1 > 0 ? prm->stride1 : 0;
   if (prm->stride0 <= 0) for (int64_t i = 0; i < npos; ++i) m0 = std::max(m0, off0[i + 1] - off0[i]);
   if (prm->stride1 <= 0) for (int64_t i = 0; i < npos; ++i) m1 = std::max(m1, off1[i + 1] - off1[i]);
-  if (m0 > NMOD_MAX_GROUP || m1 > NMOD_MAX_GROUP) return NMOD_ERR_TOO_LARGE;
+  {
+    const bool ks_only = !((prm->tests & (NMOD_TEST_MWU | NMOD_TEST_WELCH)) != 0 || prm->want_mstd);
+    if (!ks_only) { if (m0 > NMOD_MAX_GROUP || m1 > NMOD_MAX_GROUP) return NMOD_ERR_TOO_LARGE; }
+    else {
+      if (std::max(m0, m1) > NMOD_MAX_RANKED) return NMOD_ERR_TOO_LARGE;
+      for (int64_t i = 0; i < npos; ++i) {
+        int64_t a = prm->stride0 > 0 ? prm->stride0 : off0[i + 1] - off0[i];
+        int64_t b = prm->stride1 > 0 ? prm->stride1 : off1[i + 1] - off1[i];
+        if (std::min(a, b) > NMOD_MAX_GROUP) return NMOD_ERR_TOO_LARGE;
+      }
+    }
+  }
   dp.max_n0 = (int32_t)std::max<int64_t>(m0, 1); dp.max_n1 = (int32_t)std::max<int64_t>(m1, 1);
 
   DevBuf d_sig0, d_sig1, d_off0, d_off1, d_run, d_ws, d_out;
@@ -455,7 +480,7 @@ const char* nmod_strerror(int rc) {
     case NMOD_ERR_HIP:
       snprintf(g_errbuf, sizeof(g_errbuf), "HIP runtime error: %s", hipGetErrorString(g_last_hip));
       return g_errbuf;
-    case NMOD_ERR_TOO_LARGE: return "a position has more samples per group than NMOD_MAX_GROUP (2048)";
+    case NMOD_ERR_TOO_LARGE: return "a position has more samples per group than NMOD_MAX_GROUP (2048; in KS-only mode the larger group may hold up to 65535)";
     case NMOD_ERR_WORKSPACE: return "workspace missing or smaller than nmod_workspace_bytes()";
     case NMOD_ERR_NO_DEVICE: return "no HIP device";
     default: return "unknown error code";

@@ -19,7 +19,8 @@ struct FinalizeArgs {
   const uint32_t* ks_num; const uint64_t* mwu_s; const uint64_t* tie; const double* moments;
   const double* ks_d_ref;               // non-null in all-tests mode: the reference's float form of D
   int32_t tests; int32_t want_mstd;
-  int64_t max_n0, max_n1;               // capacity of the largest size class launched
+  int64_t max_n0, max_n1;               // per-group limits of this launch
+  int64_t min_cap;                      // KS-only: capacity limit of the smaller (sorted) group, else 0
   nmod_out out;
 };
 
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
   const int64_t n1 = a.stride1 > 0 ? a.stride1 : a.off1[p + 1] - a.off1[p];
   const double nan = __builtin_nan("");
   unsigned status = 0;
-  const bool too_large = (n0 > a.max_n0 || n1 > a.max_n1);
+  const bool too_large = (n0 > a.max_n0 || n1 > a.max_n1) || (a.min_cap > 0 && (n0 < n1 ? n0 : n1) > a.min_cap);
   const bool empty = (n0 <= 0 || n1 <= 0) || too_large;    // "empty": nothing was computed by K1
   if (n0 <= 0 || n1 <= 0) status |= NMOD_STATUS_EMPTY;
   if (too_large) status |= NMOD_STATUS_TOO_LARGE;

@@ -331,3 +331,27 @@ def test_device_path_unknown_max_side_stream_and_too_large_hint(nm):
         assert big.any() and np.all((st[big] & L.STATUS_TOO_LARGE) != 0) and np.all(np.isnan(ksp[big]))
         assert np.all(st[~big] & L.STATUS_TOO_LARGE == 0)
         H.assert_close_p(ksp[~big], exp['ks_p'][~big], 1e-9, 'ks_p small')
+
+
+def test_ks_only_large_ranked_group(nm):
+    """KS-only mode: only the smaller group of a position is capacity-bound (2048); the other one is ranked,
+    not sorted, and may be much larger (cfg5's 4000-read positions)"""
+    import nanomod_oracle as orc
+    L = nm._lib
+    rng = np.random.default_rng(77)
+    sizes = [(4000, 50), (30, 9000), (2048, 2049), (6000, 400), (3000, 2000), (5, 20000)]
+    ca = [rng.normal(0, 1, a).astype(np.float32) for a, b in sizes]
+    cb = [np.round(rng.normal(0.1, 1, b), 2).astype(np.float32) for a, b in sizes]
+    off0 = np.zeros(len(sizes) + 1, np.int64); off0[1:] = np.cumsum([len(c) for c in ca])
+    off1 = np.zeros(len(sizes) + 1, np.int64); off1[1:] = np.cumsum([len(c) for c in cb])
+    got = nm.detect_host(np.concatenate(ca), off0, np.concatenate(cb), off1, np.zeros(len(sizes), np.int32),
+                         tests=L.TEST_KS, method='stouffer')
+    for i, (a, b) in enumerate(zip(ca, cb)):
+        d, p = orc.ks_2samp(a, b)
+        assert abs(got['ks_d'][i] - d) <= 4.5e-16 and abs(got['ks_p'][i] - max(p, orc.DBL_MIN)) <= 1e-9 * max(p, orc.DBL_MIN), i
+    # all-tests mode still needs both groups <= 2048; both > 2048 is too large in any mode
+    with pytest.raises(L.NanomodLibraryError, match='more samples'):
+        nm.detect_host(np.concatenate(ca), off0, np.concatenate(cb), off1, np.zeros(len(sizes), np.int32))
+    big = np.zeros(2100, np.float32)
+    with pytest.raises(L.NanomodLibraryError, match='more samples'):
+        nm.detect_host(big, np.array([0, 2100]), big, np.array([0, 2100]), np.zeros(1, np.int32), tests=L.TEST_KS, method='ks')

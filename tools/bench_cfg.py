@@ -35,7 +35,8 @@ del s0, s1
 # cfg5: ragged lognormal sizes, 1 M positions
 P = 1_000_000
 rng = np.random.default_rng(5)
-n0 = np.clip(np.round(rng.lognormal(np.log(1000), 0.5, P)), 5, 2048).astype(np.int64)
+cap0 = 2048 if a.all_tests else 4000          # clipped [5, 4000]; all-tests mode sorts both groups (<= 2048)
+n0 = np.clip(np.round(rng.lognormal(np.log(1000), 0.5, P)), 5, cap0).astype(np.int64)
 n1 = np.clip(np.round(rng.lognormal(np.log(50), 0.5, P)), 5, 400).astype(np.int64)
 off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum(n0)
 off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum(n1)
@@ -44,11 +45,11 @@ s0 = torch.randn(int(off0[-1]), dtype=torch.float32, device=dev, generator=g)
 s1 = torch.randn(int(off1[-1]), dtype=torch.float32, device=dev, generator=g)
 o0 = torch.from_numpy(off0).to(dev); o1 = torch.from_numpy(off1).to(dev)
 rid = torch.zeros(P, dtype=torch.int32, device=dev)
-run('cfg5 ragged ~1000v~50 CSR', det, s0, s1, rid, off0=o0, off1=o1, max_n0=2048, max_n1=400)
+run('cfg5 ragged ~1000v~50 CSR', det, s0, s1, rid, off0=o0, off1=o1, max_n0=cap0, max_n1=400)
 # spot-check a few positions against the oracle
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import nanomod_oracle as orc
-res = det.run(s0, s1, rid, off0=o0, off1=o1, max_n0=2048, max_n1=400); torch.cuda.synchronize()
+res = det.run(s0, s1, rid, off0=o0, off1=o1, max_n0=cap0, max_n1=400); torch.cuda.synchronize()
 h0 = s0.cpu().numpy(); h1 = s1.cpu().numpy(); ksp = res['ks_p'].cpu().numpy(); ksd = res['ks_d'].cpu().numpy()
 for i in list(range(0, P, P // 50)):
     d, p = orc.ks_2samp(h0[off0[i]:off0[i + 1]], h1[off1[i]:off1[i + 1]])

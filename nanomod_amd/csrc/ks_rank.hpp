@@ -207,13 +207,13 @@ void ks_rank_kernel(RankStatsArgs args) {
     bool any_tie = false;
 
     // rank NV samples (xq) and add them to the histograms
-    auto rank_and_count = [&](auto nv_tag, const float* xq) {
+    auto rank_and_count = [&](auto nv_tag, const float* kbase, const float* xq) {
       constexpr int NV = decltype(nv_tag)::value;
       const float* lp[NV];
       const float* lb32[NV];
       bool tie_here = false;
 #pragma unroll
-      for (int e = 0; e < NV; ++e) lp[e] = ks_search<C, STEPS, false>(keys, xq[e], &lb32[e]);
+      for (int e = 0; e < NV; ++e) lp[e] = ks_search<C, STEPS, false>(kbase, xq[e], &lb32[e]);
 #pragma unroll
       for (int e = 0; e < NV; ++e) tie_here = tie_here || (*lp[e] == xq[e]);      // keys[skew(C)] is +inf
       if (__ballot(tie_here) != 0ull) {          // ties with S: common for 3-dp rounded signals and the synthetic grid
@@ -235,7 +235,7 @@ void ks_rank_kernel(RankStatsArgs args) {
         for (int e = 0; e < NV; ++e) again = again || (*up[e] == xq[e]);
         if (__ballot(again) != 0ull) {
 #pragma unroll
-          for (int e = 0; e < NV; ++e) up[e] = ks_search<C, STEPS, true>(keys, xq[e]);
+          for (int e = 0; e < NV; ++e) up[e] = ks_search<C, STEPS, true>(kbase, xq[e]);
         }
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
@@ -249,34 +249,95 @@ void ks_rank_kernel(RankStatsArgs args) {
       }
     };
 
-#pragma unroll 1
-    for (int c = 0; c < full_w; ++c) {
-      const int idx = c * (4 * LG) + 4 * gl;
-      float xq[4] = {big, big, big, big};
-      if (c < full) {
-        if (q_vec) {
-          if constexpr (DTYPE == 0) {
-            float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sig_q) + off_q + idx);
-            xq[0] = t.x; xq[1] = t.y; xq[2] = t.z; xq[3] = t.w;
-          } else {
-            short4 t = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(sig_q) + off_q + idx);
-            xq[0] = (float)t.x; xq[1] = (float)t.y; xq[2] = (float)t.z; xq[3] = (float)t.w;
-          }
-        } else {
+    // Two schedules.  "own": the LG lanes of a position rank that position's Q (all positions of the wave
+    // in lock step; the wave runs as long as its largest Q).  "coop": the 64 lanes rank one position's Q
+    // after the other — balanced when the Q sizes of the wave's positions differ (ragged coverage).
+    int slots = (full_w * 4 + tail_w) * LG;
+    bool coop = false;
+    if constexpr (PW > 1) {
+      int coop_cost = 0;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) xq[e] = load_sample<DTYPE>(sig_q, off_q + idx + e);
+      for (int sl = 0; sl < PW; ++sl) {
+        const int qs = __builtin_amdgcn_readlane(q, sl * LG);
+        const int fs = qs / 256;
+        coop_cost += fs * 4 + (qs - fs * 256 + 63) / 64;
+      }
+      coop = coop_cost < full_w * 4 + tail_w;
+    }
+    if (!coop) {
+#pragma unroll 1
+      for (int c = 0; c < full_w; ++c) {
+        const int idx = c * (4 * LG) + 4 * gl;
+        float xq[4] = {big, big, big, big};
+        if (c < full) {
+          if (q_vec) {
+            if constexpr (DTYPE == 0) {
+              float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sig_q) + off_q + idx);
+              xq[0] = t.x; xq[1] = t.y; xq[2] = t.z; xq[3] = t.w;
+            } else {
+              short4 t = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(sig_q) + off_q + idx);
+              xq[0] = (float)t.x; xq[1] = (float)t.y; xq[2] = (float)t.z; xq[3] = (float)t.w;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xq[e] = load_sample<DTYPE>(sig_q, off_q + idx + e);
+          }
+        }
+        rank_and_count(std::integral_constant<int, 4>{}, keys, xq);
+      }
+#pragma unroll 1
+      for (int c = 0; c < tail_w; ++c) {
+        const int idx = full * (4 * LG) + c * LG + gl;
+        float xq[1] = {big};
+        if (idx < q) xq[0] = load_sample<DTYPE>(sig_q, off_q + idx);
+        rank_and_count(std::integral_constant<int, 1>{}, keys, xq);
+      }
+    } else {
+      const int cfull = q / 256;
+      slots = (cfull * 4 + (q - cfull * 256 + 63) / 64) * 64;        // per position: what the 64 lanes will process
+#pragma unroll 1
+      for (int sl = 0; sl < PW; ++sl) {
+        const int src = sl * LG;
+        const int qs = __builtin_amdgcn_readlane(q, src);
+        const unsigned long long sp = (unsigned long long)(uintptr_t)sig_q;
+        // (readlane returns int: go through unsigned, or a low word >= 2^31 would sign-extend into the high word)
+        auto rl64 = [&](unsigned long long v) {
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+          const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+          return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+        };
+        const void* sigs = reinterpret_cast<const void*>((uintptr_t)rl64(sp));
+        const int64_t offs = (int64_t)rl64((unsigned long long)off_q);
+        const float* kb = lds_all + (wave * PW + sl) * POS_WORDS;
+        const int fs = qs / 256, ts = (qs - fs * 256 + 63) / 64;
+        const bool vec = (offs & 3) == 0;
+#pragma unroll 1
+        for (int c = 0; c < fs; ++c) {
+          const int idx = c * 256 + 4 * lane;
+          float xq[4];
+          if (vec) {
+            if constexpr (DTYPE == 0) {
+              float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sigs) + offs + idx);
+              xq[0] = t.x; xq[1] = t.y; xq[2] = t.z; xq[3] = t.w;
+            } else {
+              short4 t = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(sigs) + offs + idx);
+              xq[0] = (float)t.x; xq[1] = (float)t.y; xq[2] = (float)t.z; xq[3] = (float)t.w;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xq[e] = load_sample<DTYPE>(sigs, offs + idx + e);
+          }
+          rank_and_count(std::integral_constant<int, 4>{}, kb, xq);
+        }
+#pragma unroll 1
+        for (int c = 0; c < ts; ++c) {
+          const int idx = fs * 256 + c * 64 + lane;
+          float xq[1] = {big};
+          if (idx < qs) xq[0] = load_sample<DTYPE>(sigs, offs + idx);
+          rank_and_count(std::integral_constant<int, 1>{}, kb, xq);
         }
       }
-      rank_and_count(std::integral_constant<int, 4>{}, xq);
     }
-#pragma unroll 1
-    for (int c = 0; c < tail_w; ++c) {
-      const int idx = full * (4 * LG) + c * LG + gl;
-      float xq[1] = {big};
-      if (idx < q) xq[0] = load_sample<DTYPE>(sig_q, off_q + idx);
-      rank_and_count(std::integral_constant<int, 1>{}, xq);
-    }
-    const int slots = (full_w * 4 + tail_w) * LG;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (gl == 0) hist[ks_skew_rt(m)] -= (unsigned)(slots - q) * 0x10001u;   // the FLT_MAX slots

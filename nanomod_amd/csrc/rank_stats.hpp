@@ -47,9 +47,6 @@ struct RankStatsArgs {
   double* ks_d_ref;                            // [npos] max |fl(c0/n0) - fl(c1/n1)| exactly as ks_2samp forms it (all-tests mode)
 };
 
-template <int R>
-struct Regs { float v[R]; };
-
 __device__ __forceinline__ void ce(float& lo, float& hi) {
   float a = fminf(lo, hi), b = fmaxf(lo, hi);
   lo = a; hi = b;

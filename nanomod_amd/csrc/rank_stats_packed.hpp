@@ -21,11 +21,6 @@ namespace nmod {
 
 // ---- segmented (LG-lane) wave helpers --------------------------------------------------------
 template <int LG>
-__device__ __forceinline__ float seg_mirror_f(float x) {
-  if constexpr (LG == 16) return dpp_f<kDppRowMirror>(x, x);
-  else return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x7C1F));
-}
-template <int LG>
 __device__ __forceinline__ int seg_mirror_i(int x) {
   if constexpr (LG == 8) return dpp_i<kDppRowHalfMirror, 0xf, 0xf, true>(0, x);
   else if constexpr (LG == 16) return dpp_i<kDppRowMirror, 0xf, 0xf, true>(0, x);

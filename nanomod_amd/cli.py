@@ -43,6 +43,10 @@ def build_parser():
     d.add_argument('--percentile', type=float, default=0.1)                            # NanoMod.py:364
     d.add_argument('--WindOvlp', type=int, default=0, choices=[0, 1])                  # NanoMod.py:365
     d.add_argument('--NA', type=str, default='', choices=['', 'A', 'C', 'G', 'T'])     # NanoMod.py:366
+    d.add_argument('--downsampling_quantile', type=float, default=0.25)                # NanoMod.py:389
+    d.add_argument('--downsampling', type=int, default=100)                            # NanoMod.py:390
+    d.add_argument('--coverages', type=str, default='0-0')                             # NanoMod.py:392
+    d.add_argument('--seed', type=int, default=0, help='seed of the down-sampling draws (the reference is unseeded)')
     d.add_argument('--device', type=int, default=0)
     return p
 
@@ -123,6 +127,11 @@ def run_detect(a, log=print):
                              want_mstd=a.mstd != 0, device=a.device)
     if npos and np.any(res['status'] & L.STATUS_MWU_ALL_IDENTICAL):
         raise ValueError('All numbers are identical in mannwhitneyu')                  # scipy 1.2.1, uncaught in the reference
+    cov = [int(x) for x in a.coverages.split('-')]                                     # NanoMod.py:174-176
+    if npos:
+        detect.downsample_update(res, sig0, off0, sig1, off1, rid, strand, cov * 2 if len(cov) == 1 else cov,
+                                 iters=a.downsampling, quantile=a.downsampling_quantile, seed=a.seed, nb=nb,
+                                 weights_dif=a.WeightsDif, method=dev_method, device=a.device)
     if a.outLevel <= detect.OUTPUT_INFO:
         log('Producing pvalues: consuming time %d' % (time.time() - t0))
     if method != 'ks' and nb == 0:                                                     # myDetect.py:413

@@ -79,9 +79,6 @@ def _coverage_threshold(moptions, m_str):
 # myDetect.py:327-363
 def getKStest(moptions, a, b, m_str):
     cov = _coverage_threshold(moptions, m_str)
-    if not (cov <= 0 or (len(a) <= cov and len(b) <= cov)):
-        raise NotImplementedError('the unseeded down-sampling branch (myDetect.py:345-361) is outside '
-                                  'the parity contract (SURVEY.md §8a row A3\')')
     both = encode_signals(np.concatenate([np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)]))
     sig0, sig1 = both[:len(a)], both[len(a):]
     off0 = np.array([0, len(a)], dtype=np.int64)
@@ -90,8 +87,13 @@ def getKStest(moptions, a, b, m_str):
                            device=moptions.get('nmod_device', 0))
     if r['status'][0] & L.STATUS_MWU_ALL_IDENTICAL:
         raise ValueError('All numbers are identical in mannwhitneyu')      # scipy 1.2.1 behaviour
-    return [(float(r['mwu_u'][0]), float(r['mwu_p'][0])), (float(r['t_t'][0]), float(r['t_p'][0])),
-            (float(r['ks_d'][0]), float(r['ks_p'][0]))]
+    ks = (float(r['ks_d'][0]), float(r['ks_p'][0]))
+    if not (cov <= 0 or (len(a) <= cov and len(b) <= cov)):                  # myDetect.py:345-361, seeded
+        dsd, dsp = engine.downsample_ks(sig0, off0, sig1, off1, [0], [cov], iters=int(moptions.get('downsampling', 100)),
+                                        quantile=float(moptions.get('downsampling_quantile', 0.25)),
+                                        seed=int(moptions.get('nmod_seed', 0)), device=moptions.get('nmod_device', 0))
+        ks = (float(dsd[0]), float(dsp[0]))
+    return [(float(r['mwu_u'][0]), float(r['mwu_p'][0])), (float(r['t_t'][0]), float(r['t_p'][0])), ks]
 
 
 # myDetect.py:366-371
@@ -259,10 +261,30 @@ def region_rank(moptions, sorted_ind, use_pind):
 
 
 # myDetect.py:416-462
+def downsample_update(res, sig0, off0, sig1, off1, rid, strands, coverages, *, iters=100, quantile=0.25, seed=0,
+                      nb=2, weights_dif=2.0, method='stouffer', device=0):
+    """Down-sampling branch (myDetect.py:339-361) on a finished batch: positions where a group exceeds its
+    strand's coverage threshold get the KS pair of the `quantile`-th of `iters` resamples (seeded here,
+    unseeded in the reference) and the combined track is recomputed; MWU / Welch keep the full data.
+    Returns the indices of the positions that were down-sampled."""
+    c = (int(coverages[0]), int(coverages[1]))
+    if c[0] <= 0 and c[1] <= 0:
+        return np.zeros(0, dtype=np.int64)
+    cov_pos = np.where(np.asarray(strands) == '+', c[0], c[1]).astype(np.int64)
+    n0a = np.diff(off0); n1a = np.diff(off1)
+    flag = np.nonzero((cov_pos > 0) & ((n0a > cov_pos) | (n1a > cov_pos)))[0]
+    if len(flag):
+        dsd, dsp = engine.downsample_ks(sig0, off0, sig1, off1, flag, cov_pos[flag], iters=iters, quantile=quantile,
+                                        seed=seed, device=device)
+        res['ks_d'][flag] = dsd
+        res['ks_p'][flag] = dsp
+        if method != 'ks':
+            res['comb_st'], res['comb_p'] = engine.combine_host(res['ks_d'], res['ks_p'], rid, nb=nb, weights_dif=weights_dif,
+                                                                method=method, device=device)
+    return flag
+
+
 def mtest2(moptions):
-    cov = moptions.get('coverages', (0, 0))
-    if int(cov[0]) > 0 or int(cov[1]) > 0:
-        raise NotImplementedError('down-sampling KS (myDetect.py:345-361) is outside the parity contract')
     print("Start sorting")
     meta, sig0, off0, sig1, off1, rid = build_csr(moptions)
     method = moptions['testMethod']
@@ -277,6 +299,11 @@ def mtest2(moptions):
                              method=dev_method, want_mstd=want_mstd, device=moptions.get('nmod_device', 0))
     if len(meta) and np.any(res['status'] & L.STATUS_MWU_ALL_IDENTICAL):
         raise ValueError('All numbers are identical in mannwhitneyu')                             # scipy 1.2.1, uncaught in the reference
+    if len(meta):
+        downsample_update(res, sig0, off0, sig1, off1, rid, [m[1] for m in meta], moptions.get('coverages', (0, 0)),
+                          iters=int(moptions.get('downsampling', 100)), quantile=float(moptions.get('downsampling_quantile', 0.25)),
+                          seed=int(moptions.get('nmod_seed', 0)), nb=nb, weights_dif=moptions.get('WeightsDif', 2.0),
+                          method=dev_method, device=moptions.get('nmod_device', 0))
     cols = [res[k].tolist() for k in ('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p')]
     sign_test = [(m, [(u, pu), (t, pt), (d, pk)]) for m, u, pu, t, pt, d, pk in zip(meta, *cols)]
     moptions['sign_test'] = sign_test

@@ -208,6 +208,21 @@ def getKStest(a, b):
     return [(stu, pu), (stt, pt), (stks, pks)]
 
 
+# myDetect.py:345-361 — the down-sampling branch.  The reference draws from numpy's unseeded global RNG, so
+# this restatement (taking an explicit Generator) is only statistically comparable with any other run.
+def ks_downsampled(a, b, cov, iters=100, quantile=0.25, rng=None):
+    rng = rng if rng is not None else np.random.default_rng()
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    p_array = np.zeros(iters); st_array = np.zeros(iters)
+    for i in range(iters):
+        a_temp = rng.choice(a, cov) if len(a) > cov else a
+        b_temp = rng.choice(b, cov) if len(b) > cov else b
+        st, pks = ks_2samp(a_temp, b_temp)
+        p_array[i] = m_min_float(pks); st_array[i] = m_max_float(st)
+    ind = np.argsort(p_array)[int(iters * quantile)]
+    return float(st_array[ind]), float(p_array[ind])
+
+
 # --------------------------------------------------------------------------
 # Batch form on the build's CSR layout.
 METHOD_KS, METHOD_STOUFFER, METHOD_FISHER = 0, 1, 2

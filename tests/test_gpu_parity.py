@@ -355,3 +355,71 @@ def test_ks_only_large_ranked_group(nm):
     big = np.zeros(2100, np.float32)
     with pytest.raises(L.NanomodLibraryError, match='more samples'):
         nm.detect_host(big, np.array([0, 2100]), big, np.array([0, 2100]), np.zeros(1, np.int32), tests=L.TEST_KS, method='ks')
+
+
+def test_downsampling_branch_statistically_matches(nm):
+    """--coverages > 0 (myDetect.py:345-361): seeded on the device, unseeded in the reference, so compare
+    distributions: over many positions the selected 25th-percentile p-values of the two implementations must
+    agree (two-sample KS between them not significant, medians close), MWU / Welch are untouched, positions
+    under the threshold keep the plain KS pair, and the run is reproducible for a fixed seed."""
+    import nanomod_oracle as orc
+    rng = np.random.default_rng(5)
+    npos, cov = 160, 40
+    chunks_a = [rng.normal(0, 1, int(rng.integers(60, 140))).astype(np.float32) for _ in range(npos)]
+    chunks_b = [rng.normal(0.25, 1, int(rng.integers(20, 140))).astype(np.float32) for _ in range(npos)]
+    mo = {'ds2': ['A', 'B'], 'outLevel': 3, 'mstd': 0, 'coverages': [cov, cov], 'downsampling': 100,
+          'downsampling_quantile': 0.25, 'neighborPvalues': 2, 'WeightsDif': 2.0, 'testMethod': 'stouffer', 'rankUse': 'pv',
+          'SaveTest': 0, 'RegionRankbyST': 0, 'outFolder': '/tmp', 'FileID': 'ds', 'MinCoverage': 5, 'nmod_seed': 11}
+    for g, (ds, ch) in enumerate((('A', chunks_a), ('B', chunks_b))):
+        mo[ds] = {'norm_mean': {('c', '+'): {100 + i: [np.float64(v) for v in ch[i]] for i in range(npos)}},
+                  'base': {('c', '+'): {100 + i: 'A' for i in range(npos)}}, 'basedict': {}}
+    import copy
+    mo2 = copy.deepcopy(mo)
+    nm.mtest2(mo)
+    nm.mtest2(mo2)
+    got_p = np.array([r[1][2][1] for r in mo['sign_test']]); got_d = np.array([r[1][2][0] for r in mo['sign_test']])
+    assert np.array_equal(got_p, np.array([r[1][2][1] for r in mo2['sign_test']]))          # seeded: reproducible
+    ref = [orc.ks_downsampled(chunks_a[i], chunks_b[i], cov, 100, 0.25, np.random.default_rng(1000 + i)) for i in range(npos)]
+    ref_p = np.array([r[1] for r in ref]); ref_d = np.array([r[0] for r in ref])
+    small = np.array([len(chunks_a[i]) <= cov and len(chunks_b[i]) <= cov for i in range(npos)])
+    assert not small.any()                                   # every position here is down-sampled
+    from scipy import stats
+    assert stats.ks_2samp(np.log(got_p), np.log(ref_p)).pvalue > 0.01
+    assert abs(np.median(np.log(got_p)) - np.median(np.log(ref_p))) < 0.35
+    assert abs(got_d.mean() - ref_d.mean()) < 0.02
+    # per position the two selected p-values are draws from the same sampling distribution: same order of magnitude
+    assert np.mean(np.abs(np.log(got_p) - np.log(ref_p)) < 1.5) > 0.9
+    # MWU / Welch come from the full data
+    full = [orc.getKStest(chunks_a[i].astype(np.float64), chunks_b[i].astype(np.float64)) for i in range(5)]
+    for i in range(5):
+        assert mo['sign_test'][i][1][0][0] == full[i][0][0] and abs(mo['sign_test'][i][1][1][1] - full[i][1][1]) < 1e-9 * full[i][1][1]
+    # below the threshold nothing changes
+    mo3 = copy.deepcopy(mo); mo3['coverages'] = [1000, 1000]
+    for ds in ('A', 'B'):
+        mo3[ds] = mo2[ds]
+    mo4 = copy.deepcopy(mo3); mo4['coverages'] = [0, 0]
+    nm.mtest2(mo3); nm.mtest2(mo4)
+    assert [r[1][2] for r in mo3['sign_test']] == [r[1][2] for r in mo4['sign_test']]
+    # the single-position entry point takes the same branch
+    one = nm.getKStest({'coverages': [cov, cov], 'nmod_seed': 3}, chunks_a[0], chunks_b[0], '+')
+    assert 0 < one[2][1] <= 1 and one[0][0] == full[0][0][0]
+
+
+def test_downsampling_cli_matches_mtest2_same_seed(nm):
+    """`--coverages 12 --seed 4` through the CLI writes the same table as mtest2 with nmod_seed=4 on the same groups"""
+    from nanomod_amd import cli
+    from test_abi_and_host import _fixture_containers
+    fx = H.load_inputs('g50')
+    with tempfile.TemporaryDirectory() as tmp:
+        mo = H.build_moptions(fx, tmp, 'ds', 2, 2.0, 'stouffer')
+        mo.update({'coverages': [12, 12], 'nmod_seed': 4, 'SaveTest': 1})
+        nm.mfilter_coverage(mo)
+        nm.mtest2(mo)
+        p0, p1 = _fixture_containers('g50', tmp)
+        rc = cli.main(['detect', '--wrkBase1', p0, '--wrkBase2', p1, '--FileID', 'x', '--outFolder', tmp, '--coverages', '12',
+                       '--seed', '4', '--topN', '3', '--outLevel', '3'])
+        assert rc == 0
+        a = open(os.path.join(tmp, 'ds_sign_test.txt')).read(); b = open(os.path.join(tmp, 'x_sign_test.txt')).read()
+        assert a == b
+        exp, table = H.load_expected('g50_stouffer')
+        assert a != table                                # the branch did change some KS pairs

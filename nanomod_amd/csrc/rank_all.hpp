@@ -1,0 +1,249 @@
+// K1, all-tests form for positions whose two groups fall in the same size class
+// (tests mask = MWU | Welch | KS: what getKStest computes for every position, myDetect.py:327-343).
+//
+// Both groups are sorted at once, each in R registers x LG lanes (the two halves of a position's
+// 2*LG lanes run the same bitonic network), the moments are taken on the way, and the run extents of
+// equal keys are written next to the keys.  Call group 1 "A" (m samples) and group 2 "B" (q samples).
+// Every lane of the position then takes B samples x (sorted index j, run [j_s, j_e)) and finds
+// L = #{a < x} by a branchless binary search in A; a tie with A gives U = #{a <= x} from A's run table.
+// At the end of every B run that is everything the three tests need:
+//   * Mann-Whitney:  sum_{a in A} (2 #{b < a} + #{b == a}) = sum_{b in B} (2m - U(b) - L(b))
+//   * tie correction: sum over pooled tie groups of t^3 - t
+//                     = 3 sum_{elements of A and B} p (p - 1)      (p = position inside its own run)
+//                     + 3 sum_{B runs tied with an A run} a b (a + b)
+//   * KS:  max over the pooled points of |F_A - F_B| is reached either at a B value
+//          (counts (U, j_e)) or at the pooled point just below one (counts (L, j_s)): between two
+//          B values F_B is constant and F_A monotone.  ks_2samp forms D as fl(c0/n0) - fl(c1/n1) in
+//          fp64; a larger integer numerator |c0 n1 - c1 n0| always gives a larger float D
+//          (they differ by >= 1/(n0 n1)), so the maximum of the float form over all candidates is
+//          the reference's D bit for bit.  c/n is formed as q0 = c r, q = fma(fma(-q0, n, c), r, q0)
+//          with r = fl(1/n): correctly rounded for every c <= n <= 4096 (checked exhaustively).
+// This replaces the merge-path walk of the pooled sample (one sequential step per pooled element,
+// ~80 VALU instructions each) by one search per B sample spread over all lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ks_rank.hpp"
+
+namespace nmod {
+
+__host__ __device__ constexpr int rank_all_pos_words(int C) {
+  int w = 2 * ks_region_words(C) + 2 * (C + kLdsPad);     // A keys + A runs (skewed), B keys + B runs (linear)
+  while ((w & 31) != 8) w += 4;                           // consecutive positions start 8 banks apart
+  return w;
+}
+
+// Run extents of equal keys inside each sorted group, (start | end << 16) per element at dst_lane[r],
+// and pp = sum over the lane's elements of p (p - 1), p = 1-based position of the element in its run.
+template <int R, int LG>
+__device__ __forceinline__ void seg_runs_and_ties(int* dst_lane, float (&y)[R], int gl, bool is_b, unsigned& pp) {
+  constexpr int N = R * LG;
+  // LG == 8: both groups of a position share one DPP row: the second group's scan values are biased by N,
+  // so whatever leaks in from the first group (< N) can never win a max
+  const int bias = (LG == 8 && is_b) ? N : 0;
+  const float nanv = __builtin_nanf("");
+  float prev_last = lane_prev(y[R - 1], nanv);
+  float next_first = lane_next(y[0], nanv);
+  prev_last = (gl == 0) ? nanv : prev_last;
+  next_first = (gl == LG - 1) ? nanv : next_first;
+  // each sweep works on an opaque in-place copy of the keys: otherwise the compiler keeps the 2*R comparison
+  // masks of all sweeps alive in SGPRs and spills them
+  auto launder = [&]() {
+#pragma unroll
+    for (int r = 0; r < R; ++r) asm volatile("" : "+v"(y[r]));
+  };
+  int run = bias;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float p = (r == 0) ? prev_last : y[r - 1];
+    run = (y[r] != p) ? (gl * R + r + bias) : run;
+  }
+  int carry = lane_prev_i(seg_scan_max_i32<LG>(run), 0);
+  carry = (gl == 0) ? bias : carry;
+  launder();
+  int acc = bias;
+#pragma unroll
+  for (int r = R - 1; r >= 0; --r) {
+    float q = (r == R - 1) ? next_first : y[r + 1];
+    acc = (y[r] != q) ? max(acc, N - (gl * R + r + 1) + bias) : acc;
+  }
+  int m = seg_mirror_i<LG>(acc);
+  m = seg_scan_max_i32<LG>(m);
+  m = seg_mirror_i<LG>(m);
+  int carry_r = lane_next_i(m, 0);
+  carry_r = (gl == LG - 1) ? bias : carry_r;
+  unsigned short* dst16 = reinterpret_cast<unsigned short*>(dst_lane);
+  launder();
+  run = carry;
+  unsigned acc_pp = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float p = (r == 0) ? prev_last : y[r - 1];
+    const int e = gl * R + r + bias;
+    run = (y[r] != p) ? e : run;
+    const unsigned pm1 = (unsigned)(e - run);
+    acc_pp += __umul24(pm1, pm1) + pm1;
+    dst16[2 * r] = (unsigned short)(run - bias);
+    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+  pp = acc_pp;
+  launder();
+  acc = carry_r;
+#pragma unroll
+  for (int r = R - 1; r >= 0; --r) {
+    float q = (r == R - 1) ? next_first : y[r + 1];
+    acc = (y[r] != q) ? max(acc, N - (gl * R + r + 1) + bias) : acc;
+    dst16[2 * r + 1] = (unsigned short)(N - (acc - bias));
+    if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// sum of a per-lane fp64 value over the 2*LG lanes of a position
+template <int LG>
+__device__ __forceinline__ double pos_allsum_f64(double v) {
+  if constexpr (LG == 8) return seg_allsum_f64<16>(v);
+  else if constexpr (LG == 16) return seg_allsum_f64<32>(v);
+  else return wave_sum_f64(v);
+}
+
+// fl(c / n) for an integer 0 <= c <= n <= 4096, r = fl(1 / n)
+__device__ __forceinline__ double exact_quot(int c, double n, double r) {
+  const double dc = (double)c;
+  const double q0 = __dmul_rn(dc, r);
+  const double rem = __fma_rn(-q0, n, dc);
+  return __fma_rn(rem, r, q0);
+}
+
+template <int R, int LG, int DTYPE>
+__global__ __launch_bounds__(64 * kWavesPerBlock, (R <= 16 ? 4 : 2))
+void rank_all_kernel(RankStatsArgs args) {
+  static_assert(LG == 8 || LG == 16 || LG == 32, "lanes per group");
+  static_assert(R >= 8 && R <= 32, "registers per lane");
+  constexpr int C = R * LG;                       // capacity per group
+  constexpr int LP = 2 * LG;                      // lanes per position
+  constexpr int PW = 64 / LP;                     // positions per wave
+  constexpr int S_WORDS = ks_region_words(C);     // skewed A region (keys or runs) incl. the tail
+  constexpr int Q_WORDS = C + kLdsPad;
+  constexpr int POS_WORDS = rank_all_pos_words(C);
+  constexpr int STEPS = (C == 64) ? 6 : (C == 128) ? 7 : (C == 256) ? 8 : (C == 512) ? 9 : 10;
+  static_assert((1 << STEPS) == C, "capacity must be a power of two <= 1024");
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gl = lane & (LG - 1);                 // lane inside its group
+  const int pl = lane & (LP - 1);                 // lane inside its position
+  const int slot = lane / LP;                     // which of the wave's positions
+  const bool is_b = (lane & LG) != 0;             // second group of the position
+
+  float* keysA = lds_all + (wave * PW + slot) * POS_WORDS;      // skewed; run words at + S_WORDS
+  float* keysB = keysA + 2 * S_WORDS;                             // linear; run words at + Q_WORDS
+  const int* runB = reinterpret_cast<const int*>(keysB + Q_WORDS);
+  const int e0 = gl * R;
+  float* my_keys = is_b ? keysB + e0 : keysA + ks_skew_rt(e0);   // R consecutive words either way
+  int* my_runs = reinterpret_cast<int*>(my_keys + (is_b ? Q_WORDS : S_WORDS));
+
+  const float inf = __builtin_inff();
+  LaneSel sel;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) sel.s[b] = ((lane >> b) & 1) ? inf : -inf;
+  if (pl < kKsTail) {
+    keysA[ks_skew(C) + pl] = inf;                                                 // rank C: every key is below x
+    reinterpret_cast<int*>(keysA + S_WORDS)[ks_skew(C) + pl] = C | (C << 16);
+  }
+
+  int64_t count = args.npos;
+  const int32_t* list = nullptr;
+  if (args.pos_list) {
+    count = args.class_meta[args.class_id];
+    list = args.pos_list + args.class_meta[kClassStride + args.class_id];
+  }
+  const int64_t items = (count + PW - 1) / PW;
+  const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
+
+  for (int64_t it = wave_global; it < items; it += wave_stride) {
+    const int64_t li = it * PW + slot;
+    const bool valid = li < count;
+    const int64_t pos = valid ? (list ? (int64_t)list[li] : li) : 0;
+    int64_t o0 = 0, o1 = 0; int n0 = 0, n1 = 0;
+    if (valid) {
+      if (args.stride0 > 0) { o0 = pos * args.stride0; n0 = (int)args.stride0; }
+      else { o0 = args.off0[pos]; n0 = (int)(args.off0[pos + 1] - o0); }
+      if (args.stride1 > 0) { o1 = pos * args.stride1; n1 = (int)args.stride1; }
+      else { o1 = args.off1[pos]; n1 = (int)(args.off1[pos + 1] - o1); }
+    }
+
+    float x[R];
+    load_packed<R, LG, DTYPE>(x, is_b ? args.sig1 : args.sig0, is_b ? o1 : o0, is_b ? n1 : n0, gl);
+    {
+      double mean, m2;
+      seg_moments<R, LG, DTYPE>(x, is_b ? n1 : n0, mean, m2);
+      if (valid && gl == 0) {
+        double* mo = args.moments + pos * 4 + (is_b ? 2 : 0);
+        mo[0] = mean; mo[1] = m2;
+      }
+    }
+    seg_sort<R, LG>(x, sel, lane);
+    store_sorted<R>(my_keys, x, 0);
+    unsigned pp;
+    seg_runs_and_ties<R, LG>(my_runs, x, gl, is_b, pp);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- every lane of the position ranks B samples pl, pl + LP, ... into A
+    const int m = n0, q = n1;
+    const int per = (q + LP - 1) / LP;
+    int steps_w;
+    if constexpr (PW == 4) {
+      steps_w = max(max(__builtin_amdgcn_readlane(per, 0), __builtin_amdgcn_readlane(per, 16)),
+                    max(__builtin_amdgcn_readlane(per, 32), __builtin_amdgcn_readlane(per, 48)));
+    } else if constexpr (PW == 2) {
+      steps_w = max(__builtin_amdgcn_readlane(per, 0), __builtin_amdgcn_readlane(per, 32));
+    } else {
+      steps_w = __builtin_amdgcn_readfirstlane(per);
+    }
+    const double dm = (double)m, dq = (double)q;
+    const double rm = 1.0 / dm, rq = 1.0 / dq;
+    const int two_m = 2 * m;
+    unsigned s_lane = 0;
+    unsigned long long tie3 = 0;
+    double dmax = 0.0;
+#pragma unroll 1
+    for (int s = 0; s < steps_w; ++s) {
+      const int jq = s * LP + pl;
+      const float xq = keysB[jq];
+      const int rb = runB[jq];
+      const int rb_s = rb & 0xffff, rb_e = (int)((unsigned)rb >> 16);
+      const bool cand = (jq < q) && (rb_e == jq + 1);               // the end of a run of B
+      const float* p = ks_search<C, STEPS, false>(keysA, xq);
+      const int ra = *reinterpret_cast<const int*>(p + S_WORDS);      // p is the first key of its run: start == L
+      const bool tie = (*p == xq);
+      const int L = ra & 0xffff;
+      const int U = tie ? (int)((unsigned)ra >> 16) : L;
+      const int a = U - L, b = rb_e - rb_s;
+      s_lane += cand ? (unsigned)__mul24(b, two_m - U - L) : 0u;
+      const unsigned ab = cand ? (unsigned)__mul24(a, b) : 0u;
+      tie3 += (unsigned long long)ab * (unsigned long long)(unsigned)(a + b);
+      const double d_at = exact_quot(U, dm, rm) - exact_quot(rb_e, dq, rq);
+      const double d_before = exact_quot(L, dm, rm) - exact_quot(rb_s, dq, rq);
+      const double dd = fmax(fabs(d_at), fabs(d_before));
+      dmax = cand ? fmax(dmax, dd) : dmax;
+    }
+    dmax = pos_max_f64<LG>(dmax, lane);
+    const unsigned long long S = pos_sum_u32<LG>(s_lane, lane);
+    const unsigned long long PP = pos_sum_u32<LG>(pp, lane);
+    const double t3 = pos_allsum_f64<LG>((double)tie3);              // < 2^53: exact
+    if (valid && pl == 0) {
+      // the +inf pads of each group form one run of P = C - n keys: take its sum_{p<=P} p (p - 1) = (P^3 - P) / 3 out
+      const unsigned long long pa = (unsigned long long)(C - m), pb = (unsigned long long)(C - q);
+      const unsigned long long pads = (pa * pa * pa - pa) / 3ull + (pb * pb * pb - pb) / 3ull;
+      args.mwu_s[pos] = S;
+      args.tie[pos] = 3ull * (PP - pads) + 3ull * (unsigned long long)t3;
+      args.ks_d_ref[pos] = (m > 0 && q > 0) ? dmax : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace nmod

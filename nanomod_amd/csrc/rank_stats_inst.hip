@@ -3,6 +3,7 @@
 #include "rank_stats.hpp"
 #include "rank_stats_packed.hpp"
 #include "ks_rank.hpp"
+#include "rank_all.hpp"
 #include "rank_stats_launch.hpp"
 
 #ifndef NMOD_INST_DTYPE
@@ -52,11 +53,11 @@ KernelFn pick_ks(int cs) {
 }
 KernelFn pick_packed(int cm) {
   switch (cm) {
-    case 0: return rank_stats_packed_kernel<8, 8, DT, ALL>;
-    case 1: return rank_stats_packed_kernel<16, 8, DT, ALL>;
-    case 2: return rank_stats_packed_kernel<16, 16, DT, ALL>;
-    case 3: return rank_stats_packed_kernel<32, 16, DT, ALL>;
-    default: return rank_stats_packed_kernel<32, 32, DT, ALL>;
+    case 0: return rank_all_kernel<8, 8, DT>;
+    case 1: return rank_all_kernel<16, 8, DT>;
+    case 2: return rank_all_kernel<16, 16, DT>;
+    case 3: return rank_all_kernel<32, 16, DT>;
+    default: return rank_all_kernel<32, 32, DT>;
   }
 }
 }  // namespace

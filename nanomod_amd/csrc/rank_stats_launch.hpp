@@ -45,7 +45,10 @@ inline size_t rank_stats_lds_bytes(int cls, bool all) {
     return (size_t)ks_positions_per_wave(cs) * w * 4 * 4;                   // bytes, 4 waves per block
   } else if (cls >= kNumGeneralClasses) {
     int cm = cls - kNumGeneralClasses;
-    words = (size_t)packed_positions_per_wave(cm) * 2 * ((64u << cm) + 4);
+    size_t C = 64u << cm;
+    size_t w = 2 * (C + C / 8 + 8) + 2 * (C + 4);                           // rank_all_pos_words (rank_all.hpp)
+    while ((w & 31) != 8) w += 4;
+    return (size_t)packed_positions_per_wave(cm) * w * 4 * 4;
   } else {
     words = (64u << (cls / kNumSizeClasses)) + 4 + (64u << (cls % kNumSizeClasses)) + 4;   // kLdsPad = 4
   }

@@ -20,26 +20,103 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "rank_stats_packed.hpp"
 
 namespace nmod {
 
-// LDS layout: sorted keys and histogram bins are skewed by 4 pad words per 32 (word(i) = i + 4*(i>>5)).
-// A power-of-two binary search probes indices == 2^j - 1 (mod 2^(j+1)); unskewed, every probe of the
-// first steps lands on one bank (rocprof: 85 % of the LDS cycles were bank conflicts).  With the skew
-// the probes of different 32-blocks fall on different banks, and because the search position is
-// always a multiple of the current step the skewed offsets are compile-time constants: no extra VALU.
-constexpr int kKsTail = 8;         // +inf sentinels / spare bins after the last skewed word
+// what a lane without a sample reads in the unconditional Q loads (see the software pipeline in ks_rank_kernel)
+static __device__ const float kKsBig4[4] = {3.4028234663852886e38f, 3.4028234663852886e38f, 3.4028234663852886e38f, 3.4028234663852886e38f};
 
-__host__ __device__ constexpr int ks_skew(int i) { return i + ((i >> 5) << 2); }
-__device__ __forceinline__ int ks_skew_rt(int i) { return i + ((i >> 5) << 2); }
-__host__ __device__ constexpr int ks_region_words(int C) { return ks_skew(C) + kKsTail; }
-__host__ __device__ constexpr int ks_rank_pos_words(int C) {
-  // keys + histogram, padded so that consecutive positions start 8 banks apart
-  int w = 2 * ks_region_words(C);
-  while ((w & 31) != 8) w += 4;
+// LDS layout: the sorted keys (and the histogram bins) of a position form an R x (LG + 1) matrix, key
+// i = R * lane + r at word r * (LG + 1) + lane: row = register, column = lane, one spare column.
+//   * the lanes store / load their registers with R ds_write_b32 / ds_read_b32 whose addresses are
+//     consecutive across the lanes (conflict-free, immediate offsets);
+//   * a power-of-two binary search probes index p + h - 1 with p a multiple of 2h.  While h >= R that is
+//     row R - 1 of column (p + h) / R - 1: the first log2(LG) steps walk along one row and different columns
+//     are different banks; the last log2(R) steps walk down the column with steps of h rows, and the odd
+//     row stride spreads them over the banks.  In the blocked layout every probe of a step shared its index
+//     modulo 2h, i.e. its bank (rocprof: 64-85 % of the LDS cycles were bank conflicts);
+//   * the search position is a pointer and every probe offset / step a compile-time constant;
+//   * key C (rank C: every key is below x) is row 0 of the spare column: the +inf sentinel and bin C live there.
+template <int R, int LG>
+struct KsLayout {
+  static constexpr int C = R * LG;
+  static constexpr int ROW = LG + 1;                 // words per row
+  static constexpr int REGION = R * ROW;             // keys or bins of one position
+  static constexpr int LAST = (R - 1) * ROW + LG - 1;   // key C - 1
+  static constexpr int END = LG;                      // key / bin C
+  __device__ static __forceinline__ int word(int i) { return (i & (R - 1)) * ROW + i / R; }
+};
+
+// words of one position (keys + histogram), padded so that the positions sharing a 32-lane half
+// of the wave start LG banks apart (their row walks then use disjoint banks)
+__host__ __device__ constexpr int ks_rank_pos_words(int R, int LG) {
+  int w = 2 * R * (LG + 1);
+  if (LG <= 16) while ((w & 31) != LG) ++w;
   return w;
 }
+
+// A pointer selected between a kernel argument and a __device__ constant is generic to the compiler, and a generic
+// load (flat_load) counts against lgkmcnt as well as vmcnt: say explicitly that these are global addresses.
+template <typename T>
+__device__ __forceinline__ T ks_global_load(const void* p) {
+  typedef const T __attribute__((address_space(1)))* GlobalPtr;
+  return *(GlobalPtr)(p);
+}
+
+// rows start at any sample: the 16- / 8-byte loads are declared with the alignment of one sample
+typedef float KsF4v __attribute__((ext_vector_type(4)));
+typedef short KsS4v __attribute__((ext_vector_type(4)));
+typedef KsF4v KsF4 __attribute__((aligned(4)));
+typedef KsS4v KsS4 __attribute__((aligned(2)));
+
+// The S rows of a work item, requested long before they are needed (software pipeline of ks_rank_kernel).
+// request() issues the same loads in every lane, with no branch and no use of the data — a load that only
+// some paths issue, or a select on its result, makes the compiler wait at the request — and finish()
+// turns the raw registers into keys (+inf pads) once the data has arrived.  Lane gl takes samples
+// k*4*LG + 4*gl .. + 3 (k < R/4); the chunk that holds the end of the row reads the LAST four samples of the
+// row instead (the order of S does not matter: it is about to be sorted) and drops the ones the previous lane
+// already has; rows shorter than four samples are read one sample at a time by lane 0.
+template <int R, int LG, int DTYPE>
+struct KsRows {
+  using T = typename std::conditional<DTYPE == 0, float, int16_t>::type;
+  using V4 = typename std::conditional<DTYPE == 0, KsF4, KsS4>::type;
+  static constexpr int NK = R / 4;
+  V4 v[NK];
+  T s[3];
+
+  __device__ __forceinline__ void request(const void* sig, int64_t off, int n, int gl) {
+    const T* row = reinterpret_cast<const T*>(sig) + off;
+    const T* dummy = reinterpret_cast<const T*>(kKsBig4);
+    const bool long_row = n >= 4;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int idx = k * (4 * LG) + 4 * gl;
+      const int t = n - idx;
+      const T* p = (long_row && t > 0) ? row + ((t >= 4) ? idx : n - 4) : dummy;
+      v[k] = ks_global_load<V4>(p);
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) s[e] = ks_global_load<T>((!long_row && gl == 0 && e < n) ? row + e : dummy);
+  }
+
+  __device__ __forceinline__ void finish(float (&x)[R], int n, int gl) const {
+    const float inf = __builtin_inff();
+    const bool long_row = n >= 4;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int idx = k * (4 * LG) + 4 * gl;
+      const int t = long_row ? n - idx : 0;          // samples of this chunk: component j is one of them iff j >= 4 - t
+      x[4 * k + 0] = (t >= 4) ? (float)v[k].x : inf;
+      x[4 * k + 1] = (t >= 3) ? (float)v[k].y : inf;
+      x[4 * k + 2] = (t >= 2) ? (float)v[k].z : inf;
+      x[4 * k + 3] = (t >= 1) ? (float)v[k].w : inf;
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) x[e] = (!long_row && gl == 0 && e < n) ? (float)s[e] : x[e];
+  }
+};
 
 template <int LG>
 __device__ __forceinline__ unsigned seg_allmax_u32(unsigned v) {
@@ -82,59 +159,59 @@ __device__ __forceinline__ void seg_sort_any(float (&x)[R], const LaneSel& sel, 
   if constexpr (LG == 64) merge_lanes<R, 64>(x, sel, lane);
 }
 
-// branchless binary search in the skewed key array: returns the pointer to skewed word L (LE = false:
-// L = #{s < x}) or U (LE = true: U = #{s <= x}); `base` points at key 0.
-template <int C, int STEPS, bool LE>
-__device__ __forceinline__ const float* ks_search(const float* base, float x, const float** block_start = nullptr) {
+// branchless binary search: returns the pointer to key L (LE = false: L = #{s < x}) or key U (LE = true:
+// U = #{s <= x}); `base` points at key 0.  *col gets the pointer to row 0 of the column that holds the rank.
+template <int R, int LG, bool LE>
+__device__ __forceinline__ const float* ks_search(const float* base, float x, const float** col = nullptr) {
+  using Lay = KsLayout<R, LG>;
   const float* p = base;
-  const float last = base[ks_skew(C - 1)];
+  const float last = base[Lay::LAST];
   const bool all = LE ? (last <= x) : (last < x);                 // rank C: every key is below x
 #pragma unroll
-  for (int st = STEPS - 1; st >= 0; --st) {
-    constexpr int dummy = 0; (void)dummy;
-    const int h = 1 << st;
-    const int hp = ks_skew(h);                                     // skewed step (p is a multiple of 2h)
-    const int probe = (h >= 32) ? hp - 5 : h - 1;                  // skewed offset of key p + h - 1
-    const float t = p[probe];
+  for (int hc = LG / 2; hc >= 1; hc >>= 1) {                       // h = hc * R keys: along row R - 1
+    const float t = p[(R - 1) * Lay::ROW + hc - 1];
     const bool right = LE ? (t <= x) : (t < x);
-    p = right ? p + hp : p;
-    if (st == 5 && block_start) *block_start = p;                  // skewed word of the 32-block that holds rank L
+    p = right ? p + hc : p;
   }
-  if (block_start && all) *block_start = base + ks_skew(C);
-  return all ? base + ks_skew(C) : p;
+  if (col) *col = all ? base + Lay::END : p;
+#pragma unroll
+  for (int h = R / 2; h >= 1; h >>= 1) {                           // down the column
+    const float t = p[(h - 1) * Lay::ROW];
+    const bool right = LE ? (t <= x) : (t < x);
+    p = right ? p + h * Lay::ROW : p;
+  }
+  return all ? base + Lay::END : p;
 }
 
 // second launch-bound argument = minimum waves per SIMD: keeps every form whose LDS footprint allows
-// four waves per SIMD at <= 128 VGPRs (the compiler otherwise spends 130-175 registers on scheduling
+// four waves per SIMD (R <= 16; the R = 32 forms are limited to two by their LDS) at <= 128 VGPRs (the compiler otherwise spends 130-175 registers on scheduling
 // freedom and occupancy drops to 2-3); no spills result
 template <int R, int LG, int DTYPE>
-__global__ __launch_bounds__(64 * kWavesPerBlock, (LG <= 32 ? 4 : 2))
+__global__ __launch_bounds__(64 * kWavesPerBlock, (R <= 16 ? 4 : 2))
 void ks_rank_kernel(RankStatsArgs args) {
   static_assert(LG == 8 || LG == 16 || LG == 32 || LG == 64, "lanes per sorted group");
   static_assert(R >= 8 && R <= 32 && (R & (R - 1)) == 0, "registers per lane");
   constexpr int C = R * LG;                    // capacity of the sorted group
   constexpr int PW = 64 / LG;                  // positions per wave
-  constexpr int POS_WORDS = ks_rank_pos_words(C);
-  constexpr int HIST_OFF = ks_region_words(C); // words from key 0 to bin 0
-  constexpr int STEPS = (C == 64) ? 6 : (C == 128) ? 7 : (C == 256) ? 8 : (C == 512) ? 9 : (C == 1024) ? 10 : 11;
-  static_assert((1 << STEPS) == C, "capacity must be a power of two");
+  using Lay = KsLayout<R, LG>;
+  constexpr int ROW = Lay::ROW;
+  constexpr int POS_WORDS = ks_rank_pos_words(R, LG);
+  constexpr int HIST_OFF = Lay::REGION;        // words from key 0 to bin 0
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gl = lane & (LG - 1);
   const int slot = lane / LG;
-  float* keys = lds_all + (wave * PW + slot) * POS_WORDS;        // sorted S of this lane's position (skewed)
-  unsigned* hist = reinterpret_cast<unsigned*>(keys + HIST_OFF);    // skewed bin k: (#L == k) << 16 | (#U == k)
+  float* keys = lds_all + (wave * PW + slot) * POS_WORDS;        // sorted S of this lane's position (KsLayout)
+  unsigned* hist = reinterpret_cast<unsigned*>(keys + HIST_OFF);    // bin k: (#L == k) << 16 | (#U == k), same layout
   const int e0 = gl * R;                                             // first key / bin this lane owns
-  const int w0 = ks_skew_rt(e0);                                     // its skewed word (R consecutive words)
-  const int w_next = ks_skew_rt(e0 + R);                             // skewed word of key / bin e0 + R
 
   const float inf = __builtin_inff();
   LaneSel sel;
 #pragma unroll
   for (int b = 0; b < 6; ++b) sel.s[b] = ((lane >> b) & 1) ? inf : -inf;
-  if (gl < kKsTail) keys[ks_skew(C) + gl] = inf;
+  for (int r = gl; r < R; r += LG) keys[r * ROW + Lay::END] = inf;   // the spare column: key C (and beyond) = +inf
 
   int64_t count = args.npos;
   const int32_t* list = nullptr;
@@ -146,48 +223,75 @@ void ks_rank_kernel(RankStatsArgs args) {
   const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
 
-  for (int64_t it = wave_global; it < items; it += wave_stride) {
+  // One work item = the PW positions of a wave.  S = the smaller group (D is symmetric in the groups).
+  struct Item { bool valid, swap; int m, q; int64_t pos, off_s, off_q; };
+  auto describe = [&](int64_t it) {
+    Item d;
     const int64_t li = it * PW + slot;
-    const bool valid = li < count;
-    const int64_t pos = valid ? (list ? (int64_t)list[li] : li) : 0;
+    d.valid = it < items && li < count;
+    d.pos = d.valid ? (list ? (int64_t)list[li] : li) : 0;
     int64_t o0 = 0, o1 = 0; int n0 = 0, n1 = 0;
-    if (valid) {
-      if (args.stride0 > 0) { o0 = pos * args.stride0; n0 = (int)args.stride0; }
-      else { o0 = args.off0[pos]; n0 = (int)(args.off0[pos + 1] - o0); }
-      if (args.stride1 > 0) { o1 = pos * args.stride1; n1 = (int)args.stride1; }
-      else { o1 = args.off1[pos]; n1 = (int)(args.off1[pos + 1] - o1); }
+    if (d.valid) {
+      if (args.stride0 > 0) { o0 = d.pos * args.stride0; n0 = (int)args.stride0; }
+      else { o0 = args.off0[d.pos]; n0 = (int)(args.off0[d.pos + 1] - o0); }
+      if (args.stride1 > 0) { o1 = d.pos * args.stride1; n1 = (int)args.stride1; }
+      else { o1 = args.off1[d.pos]; n1 = (int)(args.off1[d.pos + 1] - o1); }
     }
-    // S = the smaller group (D is symmetric in the groups)
-    const bool swap = n1 < n0;
-    const int m = swap ? n1 : n0, q = swap ? n0 : n1;
-    const void* sig_s = swap ? args.sig1 : args.sig0;
-    const void* sig_q = swap ? args.sig0 : args.sig1;
-    const int64_t off_s = swap ? o1 : o0, off_q = swap ? o0 : o1;
-
-    float x[R];
-    load_packed<R, LG, DTYPE>(x, sig_s, off_s, m, gl);
-    seg_sort_any<R, LG>(x, sel, lane);
-    store_sorted<R>(keys + w0, x, 0);
-    // ties inside S (pads are +inf: excluded by the finite test on the upper element)
-    bool s_tie = false;
-    {
-      const float nxt = lane_next(x[0], inf);
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float up = (r == R - 1) ? ((gl == LG - 1) ? inf : nxt) : x[r + 1];
-        s_tie = s_tie || (x[r] == up && up < inf);
-      }
+    d.swap = n1 < n0;
+    d.m = d.swap ? n1 : n0; d.q = d.swap ? n0 : n1;
+    d.off_s = d.swap ? o1 : o0; d.off_q = d.swap ? o0 : o1;
+    return d;
+  };
+  const float big = 3.4028234663852886e38f;
+  // one 16-byte load per lane: samples idx .. idx + 3 of a Q row when `have`, FLT_MAX otherwise.  The load is
+  // issued by EVERY lane (lanes without samples read a block of FLT_MAX): a load that only some paths issue
+  // makes the number of outstanding loads unknown to the compiler, and every later wait becomes vmcnt(0).
+  auto load_q4 = [&](float (&xq)[4], const void* sig, int64_t off, int idx, bool have) {
+    if constexpr (DTYPE == 0) {
+      const float* src = have ? reinterpret_cast<const float*>(sig) + off + idx : kKsBig4;
+      const KsF4 t = ks_global_load<KsF4>(src);
+      xq[0] = t.x; xq[1] = t.y; xq[2] = t.z; xq[3] = t.w;
+    } else {
+      const int16_t* src = have ? reinterpret_cast<const int16_t*>(sig) + off + idx : reinterpret_cast<const int16_t*>(kKsBig4);
+      const KsS4 t = ks_global_load<KsS4>(src);
+      xq[0] = have ? (float)t.x : big; xq[1] = have ? (float)t.y : big;
+      xq[2] = have ? (float)t.z : big; xq[3] = have ? (float)t.w : big;
     }
-    // clear this lane's bins e0 .. e0 + R - 1; the last lane also clears bin C
-#pragma unroll
-    for (int r = 0; r < R; r += 4) *reinterpret_cast<uint4*>(hist + w0 + r) = make_uint4(0, 0, 0, 0);
-    if (gl == LG - 1) *reinterpret_cast<uint4*>(hist + ks_skew(C)) = make_uint4(0, 0, 0, 0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+  };
+  auto load_q1 = [&](const void* sig, int64_t off, int idx, bool have) {
+    if constexpr (DTYPE == 0) {
+      return ks_global_load<float>(have ? reinterpret_cast<const float*>(sig) + off + idx : kKsBig4);
+    } else {
+      const int16_t v = ks_global_load<int16_t>(have ? reinterpret_cast<const int16_t*>(sig) + off + idx : reinterpret_cast<const int16_t*>(kKsBig4));
+      return have ? (float)v : big;
+    }
+  };
 
-    // ---- rank every Q sample into S.  Slots past the end of Q carry FLT_MAX: they rank at L = U = m
-    // without ever tying, so the loop needs no validity masks; their count is taken out of bin m below.
-    const float big = 3.4028234663852886e38f;
+  // Software pipeline: the S rows of the NEXT item are requested while this item's Q is ranked, and every
+  // round of Q samples is requested before the previous round is ranked — otherwise each item pays five
+  // dependent HBM round trips (measured: the load-only skeleton of this kernel ran at 3.9 TB/s).
+  Item cur = describe(wave_global);
+  float x[R];
+  {
+    KsRows<R, LG, DTYPE> first;
+    first.request(cur.swap ? args.sig1 : args.sig0, cur.off_s, cur.m, gl);
+    first.finish(x, cur.m, gl);
+  }
+  // vmcnt(0) (expcnt / lgkmcnt untouched): S rows are waited for here and at the bottom of the loop, where they
+  // have long arrived — vmcnt retires in order, so a wait placed at the sort would also wait for the Q round
+  // requested just before it
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+
+  for (int64_t it = wave_global; it < items; it += wave_stride) {
+    const bool valid = cur.valid;
+    const int64_t pos = cur.pos;
+    const int m = cur.m, q = cur.q;
+    const void* sig_q = cur.swap ? args.sig0 : args.sig1;
+    const int64_t off_q = cur.off_q;
+
+    // ---- the ranking schedule (needs only q) and the first round of Q, requested before the sort.
+    // Slots past the end of Q carry FLT_MAX: they rank at L = U = m without ever tying, so the ranking loop needs
+    // no validity masks; their count is taken out of bin m below.
     // full rounds of one 16-byte load per lane, then the remaining < 4*LG samples one per lane
     const int full = q / (4 * LG);
     const int tail = (q - full * (4 * LG) + LG - 1) / LG;
@@ -203,52 +307,6 @@ void ks_rank_kernel(RankStatsArgs args) {
       full_w = __builtin_amdgcn_readfirstlane(full);
       tail_w = __builtin_amdgcn_readfirstlane(tail);
     }
-    const bool q_vec = __ballot((off_q & 3) != 0) == 0ull;
-    bool any_tie = false;
-
-    // rank NV samples (xq) and add them to the histograms
-    auto rank_and_count = [&](auto nv_tag, const float* kbase, const float* xq) {
-      constexpr int NV = decltype(nv_tag)::value;
-      const float* lp[NV];
-      const float* lb32[NV];
-      bool tie_here = false;
-#pragma unroll
-      for (int e = 0; e < NV; ++e) lp[e] = ks_search<C, STEPS, false>(kbase, xq[e], &lb32[e]);
-#pragma unroll
-      for (int e = 0; e < NV; ++e) tie_here = tie_here || (*lp[e] == xq[e]);      // keys[skew(C)] is +inf
-      if (__ballot(tie_here) != 0ull) {          // ties with S: common for 3-dp rounded signals and the synthetic grid
-        any_tie = true;
-        // a tied sample almost always ties with ONE key: U = L + 1 (the next skewed word is +1, or +5 when
-        // L is the last key of its 32-block); only if that next key ties again (duplicates inside S) fall
-        // back to the full upper-bound search
-        const float* up[NV];
-        bool again = false;
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          const bool eq = (*lp[e] == xq[e]);
-          // (32-bit LDS offsets: a generic-pointer difference would be computed in 64 bits)
-          const unsigned dl = (unsigned)(uintptr_t)lp[e] - (unsigned)(uintptr_t)lb32[e];
-          const int step = (dl == 31u * 4u) ? 5 : 1;
-          up[e] = eq ? lp[e] + step : lp[e];
-        }
-#pragma unroll
-        for (int e = 0; e < NV; ++e) again = again || (*up[e] == xq[e]);
-        if (__ballot(again) != 0ull) {
-#pragma unroll
-          for (int e = 0; e < NV; ++e) up[e] = ks_search<C, STEPS, true>(kbase, xq[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, 0x10000u);
-          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up[e])) + HIST_OFF, 1u);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < NV; ++e)
-          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, 0x10001u);
-      }
-    };
-
     // Two schedules.  "own": the LG lanes of a position rank that position's Q (all positions of the wave
     // in lock step; the wave runs as long as its largest Q).  "coop": the 64 lanes rank one position's Q
     // after the other — balanced when the Q sizes of the wave's positions differ (ragged coverage).
@@ -264,32 +322,106 @@ void ks_rank_kernel(RankStatsArgs args) {
       }
       coop = coop_cost < full_w * 4 + tail_w;
     }
+    // requests that the sort hides: the next item's S rows, then this item's first rounds of Q
+    const Item nxt = describe(it + wave_stride);
+    KsRows<R, LG, DTYPE> rows_next;
+    rows_next.request(nxt.swap ? args.sig1 : args.sig0, nxt.off_s, nxt.m, gl);
+    float xa[4] = {big, big, big, big};          // the round being ranked next
+    float xt = big;                              // first one-per-lane round
+    if (!coop) {
+      load_q4(xa, sig_q, off_q, 4 * gl, 0 < full);
+      const int idx = full * (4 * LG) + gl;
+      xt = load_q1(sig_q, off_q, idx, idx < q);
+    }
+
+#if !(defined(NMOD_EXP) && (NMOD_EXP & 1))
+    seg_sort_any<R, LG>(x, sel, lane);
+#endif
+#pragma unroll
+    for (int r = 0; r < R; ++r) keys[r * ROW + gl] = x[r];
+    // ties inside S (pads are +inf: excluded by the finite test on the upper element)
+    bool s_tie = false;
+    {
+      const float nxt = lane_next(x[0], inf);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float up = (r == R - 1) ? ((gl == LG - 1) ? inf : nxt) : x[r + 1];
+        s_tie = s_tie || (x[r] == up && up < inf);
+      }
+    }
+    // clear this lane's bins e0 .. e0 + R - 1; the last lane also clears bin C
+#pragma unroll
+    for (int r = 0; r < R; ++r) hist[r * ROW + gl] = 0u;
+    if (gl == LG - 1) hist[Lay::END] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- rank every Q sample into S
+    bool any_tie = false;
+
+    // rank NV samples (xq) and add them to the histograms
+    auto rank_and_count = [&](auto nv_tag, const float* kbase, const float* xq) {
+      constexpr int NV = decltype(nv_tag)::value;
+      const float* lp[NV];
+      const float* lcol[NV];
+      bool tie_here = false;
+#pragma unroll
+      for (int e = 0; e < NV; ++e) lp[e] = ks_search<R, LG, false>(kbase, xq[e], &lcol[e]);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) tie_here = tie_here || (*lp[e] == xq[e]);      // keys[skew(C)] is +inf
+      if (__ballot(tie_here) != 0ull) {          // ties with S: common for 3-dp rounded signals and the synthetic grid
+        any_tie = true;
+        // a tied sample almost always ties with ONE key: U = L + 1 (the next row of the column, or row 0 of the
+        // next column when L is in the last row); only if that next key ties again (duplicates inside S) fall
+        // back to the full upper-bound search
+        const float* up[NV];
+        bool again = false;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+          const bool eq = (*lp[e] == xq[e]);
+          // (32-bit LDS offsets: a generic-pointer difference would be computed in 64 bits)
+          const unsigned dl = (unsigned)(uintptr_t)lp[e] - (unsigned)(uintptr_t)lcol[e];
+          const int step = (dl == (unsigned)((R - 1) * ROW * 4)) ? 1 - (R - 1) * ROW : ROW;
+          up[e] = eq ? lp[e] + step : lp[e];
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) again = again || (*up[e] == xq[e]);
+        if (__ballot(again) != 0ull) {
+#pragma unroll
+          for (int e = 0; e < NV; ++e) up[e] = ks_search<R, LG, true>(kbase, xq[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, 0x10000u);
+          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up[e])) + HIST_OFF, 1u);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < NV; ++e)
+          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, 0x10001u);
+      }
+    };
+
+    // everything requested before the sort has arrived; from here the number of outstanding loads is known
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     if (!coop) {
 #pragma unroll 1
       for (int c = 0; c < full_w; ++c) {
-        const int idx = c * (4 * LG) + 4 * gl;
-        float xq[4] = {big, big, big, big};
-        if (c < full) {
-          if (q_vec) {
-            if constexpr (DTYPE == 0) {
-              float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sig_q) + off_q + idx);
-              xq[0] = t.x; xq[1] = t.y; xq[2] = t.z; xq[3] = t.w;
-            } else {
-              short4 t = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(sig_q) + off_q + idx);
-              xq[0] = (float)t.x; xq[1] = (float)t.y; xq[2] = (float)t.z; xq[3] = (float)t.w;
-            }
-          } else {
+        float xb[4];
+        load_q4(xb, sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
+#if !(defined(NMOD_EXP) && (NMOD_EXP & 2))
+        rank_and_count(std::integral_constant<int, 4>{}, keys, xa);
+#else
+        if (xa[0] + xa[1] + xa[2] + xa[3] == 12345.f) atomicAdd(hist, 1u);
+#endif
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xq[e] = load_sample<DTYPE>(sig_q, off_q + idx + e);
-          }
-        }
-        rank_and_count(std::integral_constant<int, 4>{}, keys, xq);
+        for (int e = 0; e < 4; ++e) xa[e] = xb[e];
       }
 #pragma unroll 1
       for (int c = 0; c < tail_w; ++c) {
-        const int idx = full * (4 * LG) + c * LG + gl;
-        float xq[1] = {big};
-        if (idx < q) xq[0] = load_sample<DTYPE>(sig_q, off_q + idx);
+        float xq[1] = {xt};
+        const int idx = full * (4 * LG) + (c + 1) * LG + gl;
+        xt = load_q1(sig_q, off_q, idx, idx < q);
         rank_and_count(std::integral_constant<int, 1>{}, keys, xq);
       }
     } else {
@@ -310,49 +442,32 @@ void ks_rank_kernel(RankStatsArgs args) {
         const int64_t offs = (int64_t)rl64((unsigned long long)off_q);
         const float* kb = lds_all + (wave * PW + sl) * POS_WORDS;
         const int fs = qs / 256, ts = (qs - fs * 256 + 63) / 64;
-        const bool vec = (offs & 3) == 0;
 #pragma unroll 1
         for (int c = 0; c < fs; ++c) {
           const int idx = c * 256 + 4 * lane;
           float xq[4];
-          if (vec) {
-            if constexpr (DTYPE == 0) {
-              float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sigs) + offs + idx);
-              xq[0] = t.x; xq[1] = t.y; xq[2] = t.z; xq[3] = t.w;
-            } else {
-              short4 t = *reinterpret_cast<const short4*>(reinterpret_cast<const int16_t*>(sigs) + offs + idx);
-              xq[0] = (float)t.x; xq[1] = (float)t.y; xq[2] = (float)t.z; xq[3] = (float)t.w;
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xq[e] = load_sample<DTYPE>(sigs, offs + idx + e);
-          }
+          load_q4(xq, sigs, offs, idx, true);
           rank_and_count(std::integral_constant<int, 4>{}, kb, xq);
         }
 #pragma unroll 1
         for (int c = 0; c < ts; ++c) {
           const int idx = fs * 256 + c * 64 + lane;
-          float xq[1] = {big};
-          if (idx < qs) xq[0] = load_sample<DTYPE>(sigs, offs + idx);
+          float xq[1] = {load_q1(sigs, offs, idx, idx < qs)};
           rank_and_count(std::integral_constant<int, 1>{}, kb, xq);
         }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (gl == 0) hist[ks_skew_rt(m)] -= (unsigned)(slots - q) * 0x10001u;   // the FLT_MAX slots
+    if (gl == 0) hist[Lay::word(m)] -= (unsigned)(slots - q) * 0x10001u;   // the FLT_MAX slots
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // ---- prefix sums of the histograms and the KS numerator; lane gl owns bins e0 + 1 .. e0 + R
     unsigned h[R];
 #pragma unroll
-    for (int r = 0; r < R; r += 4) {
-      uint4 t = *reinterpret_cast<const uint4*>(hist + w0 + r);         // bins e0 + r .. e0 + r + 3
-      if (r > 0) h[r - 1] = t.x;
-      h[r] = t.y; h[r + 1] = t.z; h[r + 2] = t.w;
-    }
-    h[R - 1] = hist[w_next];                                              // bin e0 + R
+    for (int r = 0; r < R - 1; ++r) h[r] = hist[(r + 1) * ROW + gl];     // bins e0 + 1 .. e0 + R - 1
+    h[R - 1] = hist[gl + 1];                                              // bin e0 + R: row 0 of the next column
     unsigned tot = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) tot += h[r];
@@ -365,7 +480,7 @@ void ks_rank_kernel(RankStatsArgs args) {
       // cumU(m-1) makes every bin >= m repeat a_{m-1}.
       const int kq_max = (m - 1) * q;
       int kq = min(e0 * q, kq_max);
-      const int cmax = q - (int)(hist[ks_skew_rt(m)] & 0xffffu);         // cumU(m-1)
+      const int cmax = q - (int)(hist[Lay::word(m)] & 0xffffu);          // cumU(m-1)
       int c = min((int)(cum & 0xffffu), cmax);
       int hi = __mul24(c, m) - kq, lo = hi;                              // bin e0 itself: a valid a_k
 #pragma unroll
@@ -381,11 +496,8 @@ void ks_rank_kernel(RankStatsArgs args) {
       // general form with the run ends of S as masks
       float s_own[R];
 #pragma unroll
-      for (int r = 0; r < R; r += 4) {
-        float4 t = *reinterpret_cast<const float4*>(keys + w0 + r);
-        s_own[r] = t.x; s_own[r + 1] = t.y; s_own[r + 2] = t.z; s_own[r + 3] = t.w;
-      }
-      const float s_next = keys[w_next];                 // key e0 + R (or the +inf sentinel)
+      for (int r = 0; r < R; ++r) s_own[r] = keys[r * ROW + gl];
+      const float s_next = keys[gl + 1];                 // key e0 + R (or the +inf sentinel)
       // Pads are +inf, so "s_{k-1} != s_k" alone marks the run ends: it holds at k = m and fails for k > m.
       int cl = (int)(cum >> 16), cu = (int)(cum & 0xffffu);   // cumL(k-1), cumU(k-1) entering bin k = e0 + 1
       int hi = (gl == 0) ? cu * m : 0, lo = 0;                  // k = 0: (cumU(0), 0)
@@ -410,6 +522,9 @@ void ks_rank_kernel(RankStatsArgs args) {
     best = seg_allmax_u32<LG>(best);
     if (valid && gl == 0) args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    rows_next.finish(x, nxt.m, gl);
+    cur = nxt;
   }
 }
 

@@ -27,15 +27,15 @@
 
 namespace nmod {
 
-__host__ __device__ constexpr int rank_all_pos_words(int C) {
-  int w = 2 * ks_region_words(C) + 2 * (C + kLdsPad);     // A keys + A runs (skewed), B keys + B runs (linear)
-  while ((w & 31) != 8) w += 4;                           // consecutive positions start 8 banks apart
+__host__ __device__ constexpr int rank_all_pos_words(int R, int LG) {
+  int w = 4 * R * (LG + 1);                               // A keys, A runs, B keys, B runs: four KsLayout regions
+  if (LG == 8) while ((w & 31) != 16) ++w;                // two positions share a 32-lane half: 16 banks apart
   return w;
 }
 
-// Run extents of equal keys inside each sorted group, (start | end << 16) per element at dst_lane[r],
+// Run extents of equal keys inside each sorted group, (start | end << 16) per element at dst_lane[r * STRIDE],
 // and pp = sum over the lane's elements of p (p - 1), p = 1-based position of the element in its run.
-template <int R, int LG>
+template <int R, int LG, int STRIDE>
 __device__ __forceinline__ void seg_runs_and_ties(int* dst_lane, float (&y)[R], int gl, bool is_b, unsigned& pp) {
   constexpr int N = R * LG;
   // LG == 8: both groups of a position share one DPP row: the second group's scan values are biased by N,
@@ -83,7 +83,7 @@ __device__ __forceinline__ void seg_runs_and_ties(int* dst_lane, float (&y)[R], 
     run = (y[r] != p) ? e : run;
     const unsigned pm1 = (unsigned)(e - run);
     acc_pp += __umul24(pm1, pm1) + pm1;
-    dst16[2 * r] = (unsigned short)(run - bias);
+    dst16[2 * r * STRIDE] = (unsigned short)(run - bias);
     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
   pp = acc_pp;
@@ -93,7 +93,7 @@ __device__ __forceinline__ void seg_runs_and_ties(int* dst_lane, float (&y)[R], 
   for (int r = R - 1; r >= 0; --r) {
     float q = (r == R - 1) ? next_first : y[r + 1];
     acc = (y[r] != q) ? max(acc, N - (gl * R + r + 1) + bias) : acc;
-    dst16[2 * r + 1] = (unsigned short)(N - (acc - bias));
+    dst16[2 * r * STRIDE + 1] = (unsigned short)(N - (acc - bias));
     if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -122,11 +122,12 @@ void rank_all_kernel(RankStatsArgs args) {
   constexpr int C = R * LG;                       // capacity per group
   constexpr int LP = 2 * LG;                      // lanes per position
   constexpr int PW = 64 / LP;                     // positions per wave
-  constexpr int S_WORDS = ks_region_words(C);     // skewed A region (keys or runs) incl. the tail
-  constexpr int Q_WORDS = C + kLdsPad;
-  constexpr int POS_WORDS = rank_all_pos_words(C);
-  constexpr int STEPS = (C == 64) ? 6 : (C == 128) ? 7 : (C == 256) ? 8 : (C == 512) ? 9 : 10;
-  static_assert((1 << STEPS) == C, "capacity must be a power of two <= 1024");
+  using Lay = KsLayout<R, LG>;
+  constexpr int ROW = Lay::ROW;
+  constexpr int REGION = Lay::REGION;             // keys or runs of one group (KsLayout: ks_rank.hpp)
+  constexpr int POS_WORDS = rank_all_pos_words(R, LG);
+  constexpr int LOG_R = (R == 8) ? 3 : (R == 16) ? 4 : 5;
+  static_assert((1 << LOG_R) == R, "registers per lane: 8, 16 or 32");
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
 
   const int lane = threadIdx.x & 63;
@@ -136,20 +137,18 @@ void rank_all_kernel(RankStatsArgs args) {
   const int slot = lane / LP;                     // which of the wave's positions
   const bool is_b = (lane & LG) != 0;             // second group of the position
 
-  float* keysA = lds_all + (wave * PW + slot) * POS_WORDS;      // skewed; run words at + S_WORDS
-  float* keysB = keysA + 2 * S_WORDS;                             // linear; run words at + Q_WORDS
-  const int* runB = reinterpret_cast<const int*>(keysB + Q_WORDS);
-  const int e0 = gl * R;
-  float* my_keys = is_b ? keysB + e0 : keysA + ks_skew_rt(e0);   // R consecutive words either way
-  int* my_runs = reinterpret_cast<int*>(my_keys + (is_b ? Q_WORDS : S_WORDS));
+  float* keysA = lds_all + (wave * PW + slot) * POS_WORDS;      // run words at + REGION
+  float* keysB = keysA + 2 * REGION;                              // run words at + REGION
+  float* my_keys = (is_b ? keysB : keysA) + gl;                   // this lane's column: register r at + r * ROW
+  int* my_runs = reinterpret_cast<int*>(my_keys + REGION);
 
   const float inf = __builtin_inff();
   LaneSel sel;
 #pragma unroll
   for (int b = 0; b < 6; ++b) sel.s[b] = ((lane >> b) & 1) ? inf : -inf;
-  if (pl < kKsTail) {
-    keysA[ks_skew(C) + pl] = inf;                                                 // rank C: every key is below x
-    reinterpret_cast<int*>(keysA + S_WORDS)[ks_skew(C) + pl] = C | (C << 16);
+  for (int r = pl; r < R; r += LP) {                                              // the spare column of A
+    keysA[r * ROW + Lay::END] = inf;                                                // rank C: every key is below x
+    reinterpret_cast<int*>(keysA + REGION)[r * ROW + Lay::END] = C | (C << 16);
   }
 
   int64_t count = args.npos;
@@ -185,9 +184,10 @@ void rank_all_kernel(RankStatsArgs args) {
       }
     }
     seg_sort<R, LG>(x, sel, lane);
-    store_sorted<R>(my_keys, x, 0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) my_keys[r * ROW] = x[r];
     unsigned pp;
-    seg_runs_and_ties<R, LG>(my_runs, x, gl, is_b, pp);
+    seg_runs_and_ties<R, LG, ROW>(my_runs, x, gl, is_b, pp);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -212,12 +212,13 @@ void rank_all_kernel(RankStatsArgs args) {
 #pragma unroll 1
     for (int s = 0; s < steps_w; ++s) {
       const int jq = s * LP + pl;
-      const float xq = keysB[jq];
-      const int rb = runB[jq];
+      const int wq = __mul24(jq & (R - 1), ROW) + (jq >> LOG_R);
+      const float xq = keysB[wq];
+      const int rb = reinterpret_cast<const int*>(keysB + REGION)[wq];
       const int rb_s = rb & 0xffff, rb_e = (int)((unsigned)rb >> 16);
       const bool cand = (jq < q) && (rb_e == jq + 1);               // the end of a run of B
-      const float* p = ks_search<C, STEPS, false>(keysA, xq);
-      const int ra = *reinterpret_cast<const int*>(p + S_WORDS);      // p is the first key of its run: start == L
+      const float* p = ks_search<R, LG, false>(keysA, xq);
+      const int ra = *reinterpret_cast<const int*>(p + REGION);      // p is the first key of its run: start == L
       const bool tie = (*p == xq);
       const int L = ra & 0xffff;
       const int U = tie ? (int)((unsigned)ra >> 16) : L;

@@ -39,15 +39,15 @@ inline size_t rank_stats_lds_bytes(int cls, bool all) {
   size_t words;
   if (cls >= kKsClassBase) {
     int cs = cls - kKsClassBase;
-    size_t C = 64u << cs;
-    size_t w = 2 * (C + C / 8 + 8);                                          // ks_rank_pos_words (ks_rank.hpp)
-    while ((w & 31) != 8) w += 4;
+    size_t LG = (size_t)ks_lanes_per_group(cs), R = (64u << cs) / LG;
+    size_t w = 2 * R * (LG + 1);                                             // ks_rank_pos_words (ks_rank.hpp)
+    if (LG <= 16) while ((w & 31) != LG) ++w;
     return (size_t)ks_positions_per_wave(cs) * w * 4 * 4;                   // bytes, 4 waves per block
   } else if (cls >= kNumGeneralClasses) {
     int cm = cls - kNumGeneralClasses;
-    size_t C = 64u << cm;
-    size_t w = 2 * (C + C / 8 + 8) + 2 * (C + 4);                           // rank_all_pos_words (rank_all.hpp)
-    while ((w & 31) != 8) w += 4;
+    size_t LG = 32u / (size_t)packed_positions_per_wave(cm), R = (64u << cm) / LG;
+    size_t w = 4 * R * (LG + 1);                                             // rank_all_pos_words (rank_all.hpp)
+    if (LG == 8) while ((w & 31) != 16) ++w;
     return (size_t)packed_positions_per_wave(cm) * w * 4 * 4;
   } else {
     words = (64u << (cls / kNumSizeClasses)) + 4 + (64u << (cls % kNumSizeClasses)) + 4;   // kLdsPad = 4

@@ -151,7 +151,7 @@ def main():
         value = total_positions * args.steps / elapsed
         k1_avg_s = (k1_ms / max(k1_n, 1)) * 1e-3
         # measured for the default N=1 workload only (4.6 M positions, KS mode)
-        traffic = 7.389e9 if (P == P_ECOLI and world == 1 and not args.all_tests) else None
+        traffic = 7.406e9 if (P == P_ECOLI and world == 1 and not args.all_tests) else None
         algo_bytes = ALGO_BYTES_PER_POS + (32 if args.all_tests else 0)          # 16 B x 2 more (stat, p) pairs
         achieved = algo_bytes * n_local / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
         line = {
@@ -166,8 +166,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_note': 'HBM bytes per launch from rocprofv3 PMC passes of this command (FETCH_SIZE x2 per the '
-                                         'gfx950 correction + WRITE_SIZE), profiles/r1_ksrank_pmc_summary.txt; not re-measured in this run',
-                         'kernel': 'rank_stats_packed_kernel<32,8,f32,ALL>' if args.all_tests else 'ks_rank_kernel<16,16,f32>', 'kernel_avg_ms': k1_avg_s * 1e3,
+                                         'gfx950 correction + WRITE_SIZE), profiles/r1_final_pmc_summary.txt; not re-measured in this run',
+                         'kernel': 'rank_all_kernel<16,16,f32>' if args.all_tests else 'ks_rank_kernel<16,16,f32>', 'kernel_avg_ms': k1_avg_s * 1e3,
                          'algorithmic_bytes_per_position': algo_bytes,
                          'other_kernels_avg_ms': {'finalize': k2_ms / max(k1_n, 1), 'combine': k3_ms / max(k1_n, 1)}},
         }

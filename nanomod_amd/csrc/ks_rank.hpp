@@ -27,6 +27,8 @@ namespace nmod {
 
 // what a lane without a sample reads in the unconditional Q loads (see the software pipeline in ks_rank_kernel)
 static __device__ const float kKsBig4[4] = {3.4028234663852886e38f, 3.4028234663852886e38f, 3.4028234663852886e38f, 3.4028234663852886e38f};
+// ... and in the unconditional S loads: +inf, the pad value of the sort (int16 rows: 32767, replaced in finish())
+static __device__ const unsigned kKsInf4[4] = {0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u};
 
 // LDS layout: the sorted keys (and the histogram bins) of a position form an R x (LG + 1) matrix, key
 // i = R * lane + r at word r * (LG + 1) + lane: row = register, column = lane, one spare column.
@@ -88,7 +90,7 @@ struct KsRows {
 
   __device__ __forceinline__ void request(const void* sig, int64_t off, int n, int gl) {
     const T* row = reinterpret_cast<const T*>(sig) + off;
-    const T* dummy = reinterpret_cast<const T*>(kKsBig4);
+    const T* dummy = reinterpret_cast<const T*>(kKsInf4);
     const bool long_row = n >= 4;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -97,8 +99,14 @@ struct KsRows {
       const T* p = (long_row && t > 0) ? row + ((t >= 4) ? idx : n - 4) : dummy;
       v[k] = ks_global_load<V4>(p);
     }
+    // rows shorter than four samples (rare): lane 0 reads them one by one.  These loads are conditional; the caller
+    // waits for all row loads with an explicit vmcnt(0) before it starts counting outstanding loads again.
+    s[0] = s[1] = s[2] = T(0);
+    if (__ballot(!long_row && n > 0) != 0ull) {
 #pragma unroll
-    for (int e = 0; e < 3; ++e) s[e] = ks_global_load<T>((!long_row && gl == 0 && e < n) ? row + e : dummy);
+      for (int e = 0; e < 3; ++e)
+        if (!long_row && gl == 0 && e < n) s[e] = ks_global_load<T>(row + e);
+    }
   }
 
   __device__ __forceinline__ void finish(float (&x)[R], int n, int gl) const {
@@ -108,13 +116,24 @@ struct KsRows {
     for (int k = 0; k < NK; ++k) {
       const int idx = k * (4 * LG) + 4 * gl;
       const int t = long_row ? n - idx : 0;          // samples of this chunk: component j is one of them iff j >= 4 - t
-      x[4 * k + 0] = (t >= 4) ? (float)v[k].x : inf;
-      x[4 * k + 1] = (t >= 3) ? (float)v[k].y : inf;
-      x[4 * k + 2] = (t >= 2) ? (float)v[k].z : inf;
-      x[4 * k + 3] = (t >= 1) ? (float)v[k].w : inf;
+      if constexpr (DTYPE == 0) {
+        x[4 * k + 0] = v[k].x; x[4 * k + 1] = v[k].y; x[4 * k + 2] = v[k].z; x[4 * k + 3] = v[k].w;   // empty chunks read +inf
+        if (__ballot(t > 0 && t < 4) != 0ull) {      // a chunk that holds the end of a row: drop the overlap
+          x[4 * k + 0] = (t >= 4 || t <= 0) ? x[4 * k + 0] : inf;
+          x[4 * k + 1] = (t >= 3 || t <= 0) ? x[4 * k + 1] : inf;
+          x[4 * k + 2] = (t >= 2 || t <= 0) ? x[4 * k + 2] : inf;
+        }
+      } else {
+        x[4 * k + 0] = (t >= 4) ? (float)v[k].x : inf;
+        x[4 * k + 1] = (t >= 3) ? (float)v[k].y : inf;
+        x[4 * k + 2] = (t >= 2) ? (float)v[k].z : inf;
+        x[4 * k + 3] = (t >= 1) ? (float)v[k].w : inf;
+      }
     }
+    if (__ballot(!long_row && n > 0) != 0ull) {
 #pragma unroll
-    for (int e = 0; e < 3; ++e) x[e] = (!long_row && gl == 0 && e < n) ? (float)s[e] : x[e];
+      for (int e = 0; e < 3; ++e) x[e] = (!long_row && gl == 0 && e < n) ? (float)s[e] : x[e];
+    }
   }
 };
 
@@ -191,7 +210,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (R <= 16 ? 4 : 2))
 void ks_rank_kernel(RankStatsArgs args) {
   static_assert(LG == 8 || LG == 16 || LG == 32 || LG == 64, "lanes per sorted group");
   static_assert(R >= 8 && R <= 32 && (R & (R - 1)) == 0, "registers per lane");
-  constexpr int C = R * LG;                    // capacity of the sorted group
   constexpr int PW = 64 / LG;                  // positions per wave
   using Lay = KsLayout<R, LG>;
   constexpr int ROW = Lay::ROW;
@@ -339,15 +357,18 @@ void ks_rank_kernel(RankStatsArgs args) {
 #endif
 #pragma unroll
     for (int r = 0; r < R; ++r) keys[r * ROW + gl] = x[r];
-    // ties inside S (pads are +inf: excluded by the finite test on the upper element)
-    bool s_tie = false;
+    // ties inside S: the smallest gap between neighbours is exactly 0.  Between two +inf pads the gap is NaN,
+    // which min() drops.  (A gap that underflows to 0 would only send the wave down the general evaluation path.)
+    bool s_tie;
     {
       const float nxt = lane_next(x[0], inf);
+      float gap = inf;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float up = (r == R - 1) ? ((gl == LG - 1) ? inf : nxt) : x[r + 1];
-        s_tie = s_tie || (x[r] == up && up < inf);
+        gap = fminf(gap, up - x[r]);
       }
+      s_tie = gap == 0.0f;
     }
     // clear this lane's bins e0 .. e0 + R - 1; the last lane also clears bin C
 #pragma unroll

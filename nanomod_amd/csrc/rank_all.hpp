@@ -161,20 +161,44 @@ void rank_all_kernel(RankStatsArgs args) {
   const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
 
-  for (int64_t it = wave_global; it < items; it += wave_stride) {
+  struct Item { bool valid; int n0, n1; int64_t pos, my_off; };
+  auto describe = [&](int64_t it) {
+    Item d;
     const int64_t li = it * PW + slot;
-    const bool valid = li < count;
-    const int64_t pos = valid ? (list ? (int64_t)list[li] : li) : 0;
-    int64_t o0 = 0, o1 = 0; int n0 = 0, n1 = 0;
-    if (valid) {
-      if (args.stride0 > 0) { o0 = pos * args.stride0; n0 = (int)args.stride0; }
-      else { o0 = args.off0[pos]; n0 = (int)(args.off0[pos + 1] - o0); }
-      if (args.stride1 > 0) { o1 = pos * args.stride1; n1 = (int)args.stride1; }
-      else { o1 = args.off1[pos]; n1 = (int)(args.off1[pos + 1] - o1); }
+    d.valid = it < items && li < count;
+    d.pos = d.valid ? (list ? (int64_t)list[li] : li) : 0;
+    int64_t o0 = 0, o1 = 0;
+    d.n0 = 0; d.n1 = 0;
+    if (d.valid) {
+      if (args.stride0 > 0) { o0 = d.pos * args.stride0; d.n0 = (int)args.stride0; }
+      else { o0 = args.off0[d.pos]; d.n0 = (int)(args.off0[d.pos + 1] - o0); }
+      if (args.stride1 > 0) { o1 = d.pos * args.stride1; d.n1 = (int)args.stride1; }
+      else { o1 = args.off1[d.pos]; d.n1 = (int)(args.off1[d.pos + 1] - o1); }
     }
+    d.my_off = is_b ? o1 : o0;
+    return d;
+  };
+  const void* my_sig = is_b ? args.sig1 : args.sig0;
 
-    float x[R];
-    load_packed<R, LG, DTYPE>(x, is_b ? args.sig1 : args.sig0, is_b ? o1 : o0, is_b ? n1 : n0, gl);
+  // software pipeline (see ks_rank_kernel): the rows of the next item are requested at the top of the loop and
+  // turned into keys at the bottom, a whole item later
+  Item cur = describe(wave_global);
+  float x[R];
+  {
+    KsRows<R, LG, DTYPE> first;
+    first.request(my_sig, cur.my_off, is_b ? cur.n1 : cur.n0, gl);
+    first.finish(x, is_b ? cur.n1 : cur.n0, gl);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+
+  for (int64_t it = wave_global; it < items; it += wave_stride) {
+    const bool valid = cur.valid;
+    const int64_t pos = cur.pos;
+    const int n0 = cur.n0, n1 = cur.n1;
+    const Item nxt = describe(it + wave_stride);
+    KsRows<R, LG, DTYPE> rows_next;
+    rows_next.request(my_sig, nxt.my_off, is_b ? nxt.n1 : nxt.n0, gl);
+
     {
       double mean, m2;
       seg_moments<R, LG, DTYPE>(x, is_b ? n1 : n0, mean, m2);
@@ -244,6 +268,9 @@ void rank_all_kernel(RankStatsArgs args) {
       args.ks_d_ref[pos] = (m > 0 && q > 0) ? dmax : 0.0;
     }
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): requested a whole item ago
+    rows_next.finish(x, is_b ? nxt.n1 : nxt.n0, gl);
+    cur = nxt;
   }
 }
 

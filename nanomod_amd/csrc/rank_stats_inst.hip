@@ -17,6 +17,8 @@ constexpr int DT = NMOD_INST_DTYPE;
 constexpr bool ALL = NMOD_INST_ALL != 0;
 using KernelFn = void (*)(RankStatsArgs);
 
+#if NMOD_INST_ALL
+// all-tests builds: rank_all_kernel for same-class positions, the general merge-path kernel for the rest
 template <int C0, int C1>
 constexpr KernelFn kernel_of() { return rank_stats_kernel<(1 << C0), (1 << C1), DT, ALL, ALL>; }
 
@@ -41,6 +43,17 @@ KernelFn pick(int c0, int c1) {
     default: return pick1<5>(c1);
   }
 }
+KernelFn pick_packed(int cm) {
+  switch (cm) {
+    case 0: return rank_all_kernel<8, 8, DT>;
+    case 1: return rank_all_kernel<16, 8, DT>;
+    case 2: return rank_all_kernel<16, 16, DT>;
+    case 3: return rank_all_kernel<32, 16, DT>;
+    default: return rank_all_kernel<32, 32, DT>;
+  }
+}
+#else
+// KS-only builds carry only the ks_rank kernels
 KernelFn pick_ks(int cs) {
   switch (cs) {
     case 0: return ks_rank_kernel<8, 8, DT>;
@@ -51,15 +64,7 @@ KernelFn pick_ks(int cs) {
     default: return ks_rank_kernel<32, 64, DT>;
   }
 }
-KernelFn pick_packed(int cm) {
-  switch (cm) {
-    case 0: return rank_all_kernel<8, 8, DT>;
-    case 1: return rank_all_kernel<16, 8, DT>;
-    case 2: return rank_all_kernel<16, 16, DT>;
-    case 3: return rank_all_kernel<32, 16, DT>;
-    default: return rank_all_kernel<32, 32, DT>;
-  }
-}
+#endif
 }  // namespace
 
 #define NMOD_CAT2(a, b) a##b
@@ -70,15 +75,14 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
                             const RankStatsArgs& args) {
   const bool ks = cls >= kKsClassBase;
   const bool packed = !ks && cls >= kNumGeneralClasses;
-  // KS-only builds carry only the ks_rank kernels; the merge-path kernels are instantiated for all-tests mode
   KernelFn fn = nullptr;
-  if constexpr (ALL) {
-    if (ks) return hipErrorInvalidValue;
-    fn = packed ? pick_packed(cls - kNumGeneralClasses) : pick(cls / kNumSizeClasses, cls % kNumSizeClasses);
-  } else {
-    if (!ks) return hipErrorInvalidValue;
-    fn = pick_ks(cls - kKsClassBase);
-  }
+#if NMOD_INST_ALL
+  if (ks) return hipErrorInvalidValue;
+  fn = packed ? pick_packed(cls - kNumGeneralClasses) : pick(cls / kNumSizeClasses, cls % kNumSizeClasses);
+#else
+  if (!ks) return hipErrorInvalidValue;
+  fn = pick_ks(cls - kKsClassBase);
+#endif
   const size_t lds = rank_stats_lds_bytes(cls, ALL);
   if (ks || packed) {
     const int pw = ks ? ks_positions_per_wave(cls - kKsClassBase) : packed_positions_per_wave(cls - kNumGeneralClasses);

@@ -2,7 +2,7 @@
 //
 // Size classes.  A group of n samples needs capacity 64 << c (c = 0..5: 64 .. 2048).
 //   general class  c0 * 6 + c1      (0..35): rank_stats_kernel<1<<c0, 1<<c1>, 64 lanes per group;
-//   packed class   36 + cm          (36..40): rank_stats_packed_kernel, both groups in capacity 64 << cm,
+//   packed class   36 + cm          (36..40): rank_all_kernel (rank_all.hpp), both groups in capacity 64 << cm,
 //                  used when max(c0,c1) = cm <= 4 and min(c0,c1) >= cm - 1:
 //                  cm 0..1 -> (R, LG) = (8,8) (16,8): four positions per wave; cm 2..3 -> (16,16) (32,16): two;
 //                  cm 4 -> (32,32): one.

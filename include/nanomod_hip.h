@@ -58,14 +58,15 @@ enum {
   NMOD_OK = 0,
   NMOD_ERR_INVALID_ARG = -1,
   NMOD_ERR_HIP = -2,          /* a HIP runtime call failed; see nmod_strerror */
-  NMOD_ERR_TOO_LARGE = -3,    /* a position has more samples per group than NMOD_MAX_GROUP / NMOD_MAX_RANKED */
+  NMOD_ERR_TOO_LARGE = -3,    /* a position has more samples in a group than NMOD_MAX_RANKED */
   NMOD_ERR_WORKSPACE = -4,    /* workspace missing or too small (device-memory mode) */
   NMOD_ERR_NO_DEVICE = -5
 };
 
-#define NMOD_MAX_GROUP 2048   /* max samples per group per position (wave-resident sort); in KS-only mode
-                                 (tests == NMOD_TEST_KS) it bounds only the SMALLER group of a position */
-#define NMOD_MAX_RANKED 65535 /* KS-only mode: max samples of the larger (ranked, not sorted) group */
+#define NMOD_MAX_GROUP 2048   /* largest group the wave-resident kernels sort (both groups in all-tests mode, the
+                                 smaller one in KS-only mode); positions beyond it take the workgroup-per-position
+                                 pass (big_rank.hpp), slower but unlimited up to NMOD_MAX_RANKED */
+#define NMOD_MAX_RANKED 65535 /* max samples per group per position in any mode (16-bit ranks, 32-bit KS numerator) */
 #define NMOD_MAX_NB 64        /* max --neighborPvalues */
 
 typedef struct nmod_params {

@@ -18,7 +18,8 @@ METHOD_KS, METHOD_STOUFFER, METHOD_FISHER = 0, 1, 2
 TEST_KS, TEST_MWU, TEST_WELCH, TEST_ALL = 1, 2, 4, 7
 STATUS_MWU_ALL_IDENTICAL, STATUS_T_NAN, STATUS_EMPTY, STATUS_TOO_LARGE = 1, 2, 4, 8
 KERNEL_RANK_STATS, KERNEL_FINALIZE, KERNEL_COMBINE, KERNEL_SYNTH = 0, 1, 2, 3
-MAX_GROUP = 2048
+MAX_GROUP = 2048          # largest group of the wave-resident kernels; larger ones (<= MAX_RANKED) take big_rank_kernel
+MAX_RANKED = 65535
 MAX_NB = 64
 
 METHOD_BY_NAME = {'ks': METHOD_KS, 'stouffer': METHOD_STOUFFER, 'fisher': METHOD_FISHER}

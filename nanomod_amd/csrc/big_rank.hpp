@@ -1,0 +1,192 @@
+// K1, large-position form: positions whose sorted group does not fit the wave-resident kernels
+// (more than 2 048 samples in a group in all-tests mode, or in the SMALLER group in KS-only mode).
+// The reference has no size limit (scipy sorts whatever getKStest is given, myDetect.py:327-343); deep
+// coverage is rare, so this path is built for correctness and generality, not for the roofline:
+// one 256-thread workgroup per position,
+//   1. copies both groups into a power-of-two scratch slab in HBM (+inf pads) and takes the fp64 moments,
+//   2. sorts each slab with a block-wide bitonic network — in LDS when the group fits 8 192 keys, in the
+//      (L2-resident) slab otherwise,
+//   3. ranks group 2 into group 1 with plain binary searches and applies the same per-run formulas as
+//      rank_all.hpp: rank sum, tie term, the KS candidates (U, j_e) / (L, j_s) in the float form of
+//      ks_2samp (all-tests) or as the exact integer numerator (KS-only).
+// Scratch comes from a bump allocator over a slab that the host sizes from the classifier's totals.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rank_stats.hpp"
+
+namespace nmod {
+
+constexpr int kBigThreads = 256;
+constexpr int kBigLdsKeys = 8192;           // 32 KB: groups up to this size are sorted in LDS
+
+struct BigArgs {
+  const void* sig0; const void* sig1;
+  const int64_t* off0; const int64_t* off1;
+  int64_t stride0, stride1;
+  const int32_t* pos_list;                  // the big positions (class kBigClass of the binning)
+  const int32_t* class_meta;                // [kBigClass] count, [kClassStride + kBigClass] offset into pos_list
+  int32_t big_class;
+  int32_t all;                              // 1: MWU / Welch / float-form D; 0: KS numerator only
+  float* scratch;                           // slab of sum (pow2(n0) + pow2(n1)) floats
+  unsigned long long* cursor;               // bump allocator over the slab
+  uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments; double* ks_d_ref;
+};
+
+__host__ __device__ inline int64_t big_pow2_ceil(int64_t n) {
+  int64_t p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+template <int DTYPE>
+__device__ __forceinline__ float big_load(const void* sig, int64_t i) {
+  if constexpr (DTYPE == 0) return reinterpret_cast<const float*>(sig)[i];
+  else return (float)reinterpret_cast<const int16_t*>(sig)[i];
+}
+
+__device__ __forceinline__ double big_block_sum(double v, double* red) {
+  const int tid = threadIdx.x;
+  v = wave_sum_f64(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// bitonic network over P keys (P a power of two) by the whole block; `keys` is LDS or global memory
+__device__ __forceinline__ void big_bitonic(float* keys, int P) {
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (P >> 1); t += kBigThreads) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // the element of the pair with bit j clear
+        const int p = i | j;
+        const bool up = (i & k) == 0;
+        const float a = keys[i], b = keys[p];
+        if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ int big_lower_bound(const float* s, int n, float x) {   // #{s < x}
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (s[mid] < x) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ int big_upper_bound(const float* s, int n, float x) {   // #{s <= x}
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (s[mid] <= x) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+template <int DTYPE>
+__global__ __launch_bounds__(kBigThreads)
+void big_rank_kernel(BigArgs a) {
+  __shared__ float lds_keys[kBigLdsKeys];
+  __shared__ double red[4];
+  __shared__ unsigned long long sh_base, sh_s, sh_t, sh_best;
+  const int tid = threadIdx.x;
+  const int64_t count = a.class_meta[a.big_class];
+  const int32_t* list = a.pos_list + a.class_meta[kClassStride + a.big_class];
+  const float inf = __builtin_inff();
+
+  for (int64_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
+    const int64_t pos = list[bi];
+    int64_t o0, o1; int n0, n1;
+    if (a.stride0 > 0) { o0 = pos * a.stride0; n0 = (int)a.stride0; } else { o0 = a.off0[pos]; n0 = (int)(a.off0[pos + 1] - o0); }
+    if (a.stride1 > 0) { o1 = pos * a.stride1; n1 = (int)a.stride1; } else { o1 = a.off1[pos]; n1 = (int)(a.off1[pos + 1] - o1); }
+    const int P0 = (int)big_pow2_ceil(n0), P1 = (int)big_pow2_ceil(n1);
+    if (tid == 0) {
+      sh_base = atomicAdd(a.cursor, (unsigned long long)(P0 + P1));
+      sh_s = 0ull; sh_t = 0ull; sh_best = 0ull;
+    }
+    __syncthreads();
+    float* A = a.scratch + sh_base;
+    float* B = A + P0;
+
+    // ---- moments (two-pass, fp64) and the sorted copies
+    for (int g = 0; g < 2; ++g) {
+      const void* sig = g ? a.sig1 : a.sig0;
+      const int64_t off = g ? o1 : o0;
+      const int n = g ? n1 : n0, P = g ? P1 : P0;
+      float* dst = g ? B : A;
+      if (a.all) {
+        double s = 0.0;
+        for (int i = tid; i < n; i += kBigThreads) s += (double)big_load<DTYPE>(sig, off + i);
+        s = big_block_sum(s, red);
+        const double mu = s / (double)n;
+        double q = 0.0;
+        for (int i = tid; i < n; i += kBigThreads) { const double d = (double)big_load<DTYPE>(sig, off + i) - mu; q += d * d; }
+        q = big_block_sum(q, red);
+        if (tid == 0) {
+          double* mo = a.moments + pos * 4 + 2 * g;
+          if constexpr (DTYPE == 0) { mo[0] = mu; mo[1] = q; }
+          else { mo[0] = s / 1000.0 / (double)n; mo[1] = q * 1e-6; }
+        }
+      }
+      if (P <= kBigLdsKeys) {
+        for (int i = tid; i < P; i += kBigThreads) lds_keys[i] = (i < n) ? big_load<DTYPE>(sig, off + i) : inf;
+        __syncthreads();
+        big_bitonic(lds_keys, P);
+        for (int i = tid; i < P; i += kBigThreads) dst[i] = lds_keys[i];
+      } else {
+        for (int i = tid; i < P; i += kBigThreads) dst[i] = (i < n) ? big_load<DTYPE>(sig, off + i) : inf;
+        __syncthreads();
+        big_bitonic(dst, P);
+      }
+      __syncthreads();
+    }
+
+    // ---- rank group 2 into group 1, one run end of group 2 at a time (formulas: rank_all.hpp)
+    const int m = n0, q = n1;
+    const double dm = (double)m, dq = (double)q;
+    unsigned long long s_acc = 0ull, t_acc = 0ull, best = 0ull;
+    double dmax = 0.0;
+    for (int j = tid; j < q; j += kBigThreads) {
+      const float x = B[j];
+      if (j + 1 < q && B[j + 1] == x) continue;                     // not the end of its run
+      const int js = big_lower_bound(B, q, x), je = j + 1;
+      const int L = big_lower_bound(A, m, x);
+      const int U = (L < m && A[L] == x) ? big_upper_bound(A, m, x) : L;
+      const unsigned long long ta = (unsigned long long)(U - L), tb = (unsigned long long)(je - js);
+      s_acc += tb * (unsigned long long)(2 * m - U - L);
+      t_acc += tb * tb * tb - tb + 3ull * ta * tb * (ta + tb);
+      if (a.all) {
+        const double d_at = (double)U / dm - (double)je / dq;            // ks_2samp's float form: fl(c0/n0) - fl(c1/n1)
+        const double d_before = (double)L / dm - (double)js / dq;
+        dmax = fmax(dmax, fmax(fabs(d_at), fabs(d_before)));
+      } else {
+        const long long n_at = (long long)U * q - (long long)je * m, n_before = (long long)L * q - (long long)js * m;
+        const unsigned long long m_at = (unsigned long long)(n_at < 0 ? -n_at : n_at);
+        const unsigned long long m_before = (unsigned long long)(n_before < 0 ? -n_before : n_before);
+        best = max(best, max(m_at, m_before));
+      }
+    }
+    if (a.all) {
+      for (int i = tid; i < m; i += kBigThreads) {                   // runs of group 1: a^3 - a each
+        const float x = A[i];
+        if (i + 1 < m && A[i + 1] == x) continue;
+        const unsigned long long ta = (unsigned long long)(i + 1 - big_lower_bound(A, m, x));
+        t_acc += ta * ta * ta - ta;
+      }
+      atomicAdd(&sh_s, s_acc);
+      atomicAdd(&sh_t, t_acc);
+      best = (unsigned long long)__double_as_longlong(dmax);         // non-negative doubles order like their bits
+    }
+    atomicMax(&sh_best, best);
+    __syncthreads();
+    if (tid == 0) {
+      if (a.all) {
+        a.mwu_s[pos] = sh_s; a.tie[pos] = sh_t;
+        a.ks_d_ref[pos] = __longlong_as_double((long long)sh_best);
+      } else {
+        a.ks_num[pos] = (uint32_t)sh_best;                           // <= 65 535^2 < 2^32
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace nmod

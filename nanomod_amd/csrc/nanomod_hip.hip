@@ -14,6 +14,7 @@
 #include "rank_stats.hpp"
 #include "rank_stats_launch.hpp"
 #include "pvalue_kernels.hpp"
+#include "big_rank.hpp"
 
 namespace nmod {
 
@@ -51,8 +52,12 @@ struct Workspace {
   int64_t bytes;
 };
 constexpr int kMetaInts = 160;
-constexpr int kMetaMax = 3 * kClassStride;
-constexpr int kNumPairs = kNumClasses;
+constexpr int kMetaMax = 3 * kClassStride;      // [144..145] max n0 / n1
+constexpr int kMetaBigTotal = kMetaMax + 2;     // [146..147] u64: scratch floats the large positions need
+constexpr int kMetaBigCursor = kMetaMax + 4;    // [148..149] u64: bump allocator of big_rank_kernel
+constexpr int kBigClass = kNumClasses;          // 47: positions for big_rank_kernel (big_rank.hpp)
+constexpr int kNumPairs = kNumClasses + 1;      // <= kClassStride
+static_assert(kNumPairs <= kClassStride, "class tables");
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -78,7 +83,7 @@ static Workspace carve(void* base, int64_t npos) {
 // ---------------------------------------------------------------- binning kernels
 struct BinArgs {
   int64_t npos; const int64_t* off0; const int64_t* off1; int64_t stride0, stride1;
-  int cmax0, cmax1; int ks_only; int64_t lim0, lim1; uint8_t* cls; int32_t* meta; int32_t* order;
+  int cmax0, cmax1; int ks_only; int allow_big; int64_t lim0, lim1; uint8_t* cls; int32_t* meta; int32_t* order;
 };
 
 
@@ -104,11 +109,18 @@ __global__ __launch_bounds__(256) void classify_kernel(BinArgs a) {
     int64_t n0 = a.stride0 > 0 ? a.stride0 : a.off0[p + 1] - a.off0[p];
     int64_t n1 = a.stride1 > 0 ? a.stride1 : a.off1[p + 1] - a.off1[p];
     int c0 = size_class_of(n0), c1 = size_class_of(n1);
-    // KS-only: only the smaller (sorted) group is capacity-bound; the other is bounded by the promised maxima
-    const bool over = a.ks_only ? ((c0 < c1 ? c0 : c1) >= kNumSizeClasses || n0 > a.lim0 || n1 > a.lim1)
-                                : (c0 > a.cmax0 || c1 > a.cmax1);
-    int cid = (over || n0 <= 0 || n1 <= 0) ? 255
-              : a.ks_only ? kKsClassBase + (c0 < c1 ? c0 : c1) : launch_class_of(c0, c1);
+    // beyond what the caller promised (or the format allows): skipped, NMOD_STATUS_TOO_LARGE
+    const bool over = n0 > a.lim0 || n1 > a.lim1 || n0 > NMOD_MAX_RANKED || n1 > NMOD_MAX_RANKED;
+    // beyond the wave-resident kernels: KS-only sorts the smaller group only, all-tests mode sorts both
+    const bool big = a.ks_only ? (c0 < c1 ? c0 : c1) >= kNumSizeClasses : (c0 >= kNumSizeClasses || c1 >= kNumSizeClasses);
+    int cid;
+    if (over || n0 <= 0 || n1 <= 0 || (big && !a.allow_big)) cid = 255;
+    else if (big) cid = kBigClass;
+    else if (a.ks_only) cid = kKsClassBase + (c0 < c1 ? c0 : c1);
+    else cid = (c0 > a.cmax0 || c1 > a.cmax1) ? 255 : launch_class_of(c0, c1);
+    if (cid == kBigClass)
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.meta + kMetaBigTotal),
+                (unsigned long long)(big_pow2_ceil(n0) + big_pow2_ceil(n1)));
     a.cls[p] = (uint8_t)cid;
     if (cid != 255) atomicAdd(&hist[cid], 1);
   }
@@ -197,6 +209,24 @@ static int launch_combine(const nmod_params* prm, hipStream_t stream, int64_t np
   return NMOD_OK;
 }
 
+// scratch slab of the large-position pass: stream-ordered allocation, plain hipMalloc as the fallback
+struct DevScratch {
+  void* p = nullptr; bool async = false;
+  hipError_t alloc(size_t bytes, hipStream_t s) {
+    if (hipMallocAsync(&p, bytes ? bytes : 4, s) == hipSuccess) { async = true; return hipSuccess; }
+    (void)hipGetLastError();
+    p = nullptr;
+    return hipMalloc(&p, bytes ? bytes : 4);
+  }
+  hipError_t release(hipStream_t s) {
+    hipError_t e = hipSuccess;
+    if (p) e = async ? hipFreeAsync(p, s) : (hipStreamSynchronize(s), hipFree(p));
+    p = nullptr;
+    return e;
+  }
+  ~DevScratch() { if (p) { if (async) hipFreeAsync(p, nullptr); else hipFree(p); } }
+};
+
 static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0, const int64_t* off0,
                          const void* sig1, const int64_t* off1, const int32_t* run_id, void* workspace,
                          int64_t workspace_bytes, nmod_out* out) {
@@ -234,17 +264,13 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     if (max0 <= 0) max0 = mx[0];
     if (max1 <= 0) max1 = mx[1];
   }
+  if (std::max(max0, max1) > NMOD_MAX_RANKED) return NMOD_ERR_TOO_LARGE;
   int cmax0 = size_class_of(std::max<int64_t>(max0, 1)), cmax1 = size_class_of(std::max<int64_t>(max1, 1));
-  if (all) {
-    if (cmax0 >= kNumSizeClasses || cmax1 >= kNumSizeClasses) return NMOD_ERR_TOO_LARGE;
-  } else {
-    // KS-only: the smaller group of a position is sorted (<= NMOD_MAX_GROUP), the other is only ranked
-    // (a position whose smaller group exceeds the capacity gets NMOD_STATUS_TOO_LARGE from the classifier;
-    //  the maxima alone cannot tell, because they may come from different positions)
-    if (std::max(max0, max1) > NMOD_MAX_RANKED) return NMOD_ERR_TOO_LARGE;
-    if (uniform && std::min(max0, max1) > NMOD_MAX_GROUP) return NMOD_ERR_TOO_LARGE;
-    cmax0 = std::min(cmax0, kNumSizeClasses - 1); cmax1 = std::min(cmax1, kNumSizeClasses - 1);
-  }
+  // positions beyond the wave-resident kernels (both groups sorted in all-tests mode, the smaller one in KS-only
+  // mode) go to big_rank_kernel; the maxima tell whether any can exist
+  const bool big_possible = all ? (cmax0 >= kNumSizeClasses || cmax1 >= kNumSizeClasses)
+                                : (std::min(cmax0, cmax1) >= kNumSizeClasses);
+  cmax0 = std::min(cmax0, kNumSizeClasses - 1); cmax1 = std::min(cmax1, kNumSizeClasses - 1);
 
   RankStatsArgs ra;
   memset(&ra, 0, sizeof(ra));
@@ -260,13 +286,14 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
                : launch_rank_stats_d1_a0(cls, num_cus, work, stream, ra);
   };
 
-  if (uniform) {
+  DevScratch big_scratch;
+  if (uniform && !big_possible) {
     ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
     NMOD_HIP(launch(all ? launch_class_of(cmax0, cmax1) : kKsClassBase + std::min(cmax0, cmax1), npos));
   } else {
     BinArgs ba;
     ba.npos = npos; ba.off0 = off0; ba.off1 = off1; ba.stride0 = ra.stride0; ba.stride1 = ra.stride1;
-    ba.cmax0 = cmax0; ba.cmax1 = cmax1; ba.ks_only = all ? 0 : 1; ba.lim0 = std::max<int64_t>(max0, 1); ba.lim1 = std::max<int64_t>(max1, 1);
+    ba.cmax0 = cmax0; ba.cmax1 = cmax1; ba.ks_only = all ? 0 : 1; ba.allow_big = 1; ba.lim0 = std::max<int64_t>(max0, 1); ba.lim1 = std::max<int64_t>(max1, 1);
     ba.cls = ws.cls; ba.meta = ws.meta; ba.order = ws.order;
     unsigned blocks = (unsigned)std::min<int64_t>((npos + 255) / 256, 4096);
     hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, stream, ba);
@@ -282,6 +309,31 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
       ra.pos_list = ws.order; ra.class_meta = ws.meta; ra.class_id = cls;
       NMOD_HIP(launch(cls, npos));
     }
+    if (big_possible) {
+      // the only host round trip of this path: how many large positions, how much scratch
+      int32_t head[4];
+      NMOD_HIP(hipMemcpyAsync(&head[0], ws.meta + kBigClass, 4, hipMemcpyDeviceToHost, stream));
+      NMOD_HIP(hipMemcpyAsync(&head[2], ws.meta + kMetaBigTotal, 8, hipMemcpyDeviceToHost, stream));
+      NMOD_HIP(hipStreamSynchronize(stream));
+      const int64_t nbig = head[0];
+      unsigned long long total;
+      memcpy(&total, &head[2], 8);
+      if (nbig > 0) {
+        NMOD_HIP(big_scratch.alloc((size_t)total * 4, stream));
+        BigArgs bg;
+        memset(&bg, 0, sizeof(bg));
+        bg.sig0 = sig0; bg.sig1 = sig1; bg.off0 = off0; bg.off1 = off1; bg.stride0 = ra.stride0; bg.stride1 = ra.stride1;
+        bg.pos_list = ws.order; bg.class_meta = ws.meta; bg.big_class = kBigClass; bg.all = all ? 1 : 0;
+        bg.scratch = (float*)big_scratch.p;
+        bg.cursor = reinterpret_cast<unsigned long long*>(ws.meta + kMetaBigCursor);
+        bg.ks_num = ws.ks_num; bg.mwu_s = ws.mwu_s; bg.tie = ws.tie; bg.moments = ws.moments; bg.ks_d_ref = ws.ks_d_ref;
+        const unsigned blocks = (unsigned)std::min<int64_t>(nbig, (int64_t)num_cus * 2);
+        if (prm->dtype == NMOD_DTYPE_F32) hipLaunchKernelGGL(big_rank_kernel<0>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
+        else hipLaunchKernelGGL(big_rank_kernel<1>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
+        NMOD_HIP(hipGetLastError());
+        NMOD_HIP(big_scratch.release(stream));
+      }
+    }
   }
 
   // ---- p-values
@@ -290,8 +342,10 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   fa.npos = npos; fa.off0 = off0; fa.off1 = off1; fa.stride0 = ra.stride0; fa.stride1 = ra.stride1;
   fa.ks_num = ws.ks_num; fa.mwu_s = ws.mwu_s; fa.tie = ws.tie; fa.moments = ws.moments; fa.ks_d_ref = all ? ws.ks_d_ref : nullptr;
   fa.tests = tests; fa.want_mstd = prm->want_mstd; fa.out = *out;
-  fa.max_n0 = all ? (64LL << cmax0) : std::max<int64_t>(max0, 1); fa.max_n1 = all ? (64LL << cmax1) : std::max<int64_t>(max1, 1);
-  fa.min_cap = all ? 0 : NMOD_MAX_GROUP;
+  // what K1 covered: the promised maxima (large positions included); without a large-position pass the class capacity
+  fa.max_n0 = (all && !big_possible) ? (64LL << cmax0) : std::max<int64_t>(max0, 1);
+  fa.max_n1 = (all && !big_possible) ? (64LL << cmax1) : std::max<int64_t>(max1, 1);
+  fa.min_cap = 0;
   if (want_comb) {                       // the combine needs the KS track even if the caller does not
     if (!fa.out.ks_d) fa.out.ks_d = ws.tmp_ks_d;
     if (!fa.out.ks_p) fa.out.ks_p = ws.tmp_ks_p;
@@ -330,18 +384,7 @@ static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, c
   int64_t m0 = prm->stride0 > 0 ? prm->stride0 : 0, m1 = prm->stride1 > 0 ? prm->stride1 : 0;
   if (prm->stride0 <= 0) for (int64_t i = 0; i < npos; ++i) m0 = std::max(m0, off0[i + 1] - off0[i]);
   if (prm->stride1 <= 0) for (int64_t i = 0; i < npos; ++i) m1 = std::max(m1, off1[i + 1] - off1[i]);
-  {
-    const bool ks_only = !((prm->tests & (NMOD_TEST_MWU | NMOD_TEST_WELCH)) != 0 || prm->want_mstd);
-    if (!ks_only) { if (m0 > NMOD_MAX_GROUP || m1 > NMOD_MAX_GROUP) return NMOD_ERR_TOO_LARGE; }
-    else {
-      if (std::max(m0, m1) > NMOD_MAX_RANKED) return NMOD_ERR_TOO_LARGE;
-      for (int64_t i = 0; i < npos; ++i) {
-        int64_t a = prm->stride0 > 0 ? prm->stride0 : off0[i + 1] - off0[i];
-        int64_t b = prm->stride1 > 0 ? prm->stride1 : off1[i + 1] - off1[i];
-        if (std::min(a, b) > NMOD_MAX_GROUP) return NMOD_ERR_TOO_LARGE;
-      }
-    }
-  }
+  if (std::max(m0, m1) > NMOD_MAX_RANKED) return NMOD_ERR_TOO_LARGE;
   dp.max_n0 = (int32_t)std::max<int64_t>(m0, 1); dp.max_n1 = (int32_t)std::max<int64_t>(m1, 1);
 
   DevBuf d_sig0, d_sig1, d_off0, d_off1, d_run, d_ws, d_out;

@@ -204,10 +204,10 @@ def test_edge_statuses(nm):
     assert r['ks_d'][1] == 1.0
     assert r['status'][2] == 0
     assert r['status'][3] & L.STATUS_EMPTY
-    # more samples than NMOD_MAX_GROUP
-    big = np.zeros(2049, np.float32)
+    # more samples than the format allows (NMOD_MAX_RANKED)
+    big = np.zeros(65536, np.float32)
     with pytest.raises(L.NanomodLibraryError, match='more samples'):
-        nm.detect_host(big, np.array([0, 2049]), big, np.array([0, 2049]), np.zeros(1, np.int32))
+        nm.detect_host(big, np.array([0, 65536]), big, np.array([0, 65536]), np.zeros(1, np.int32))
     # empty batch
     r = nm.detect_host(np.zeros(0, np.float32), np.zeros(1, np.int64), np.zeros(0, np.float32), np.zeros(1, np.int64),
                        np.zeros(0, np.int32))
@@ -349,12 +349,61 @@ def test_ks_only_large_ranked_group(nm):
     for i, (a, b) in enumerate(zip(ca, cb)):
         d, p = orc.ks_2samp(a, b)
         assert abs(got['ks_d'][i] - d) <= 4.5e-16 and abs(got['ks_p'][i] - max(p, orc.DBL_MIN)) <= 1e-9 * max(p, orc.DBL_MIN), i
-    # all-tests mode still needs both groups <= 2048; both > 2048 is too large in any mode
-    with pytest.raises(L.NanomodLibraryError, match='more samples'):
-        nm.detect_host(np.concatenate(ca), off0, np.concatenate(cb), off1, np.zeros(len(sizes), np.int32))
-    big = np.zeros(2100, np.float32)
-    with pytest.raises(L.NanomodLibraryError, match='more samples'):
-        nm.detect_host(big, np.array([0, 2100]), big, np.array([0, 2100]), np.zeros(1, np.int32), tests=L.TEST_KS, method='ks')
+
+
+@pytest.mark.parametrize('grid', [False, True])
+def test_large_positions_all_tests_and_ks_only(nm, grid):
+    """positions beyond the wave-resident kernels (> 2048 samples in a sorted group) take big_rank_kernel: LDS sort
+    (<= 8192 keys) and in-slab sort (> 8192), mixed with ordinary positions in one ragged batch, ties, both modes"""
+    import nanomod_oracle as orc
+    L = nm._lib
+    rng = np.random.default_rng(78 + grid)
+    sizes = [(3000, 2500), (100, 90), (5000, 100), (2049, 2049), (9000, 8500), (40, 12000), (2048, 2048), (4097, 300),
+             (20000, 17000), (7, 5)]
+    ca = [rng.normal(0, 1, a) for a, b in sizes]
+    cb = [rng.normal(0.05 if i % 3 else 0.0, 1.1, b) for i, (a, b) in enumerate(sizes)]
+    if grid:
+        ca = [np.round(c, 2) for c in ca]; cb = [np.round(c, 2) for c in cb]
+        cb[3] = ca[3].copy()                                            # identical groups
+    ca = [c.astype(np.float32) for c in ca]; cb = [c.astype(np.float32) for c in cb]
+    off0 = np.zeros(len(sizes) + 1, np.int64); off0[1:] = np.cumsum([len(c) for c in ca])
+    off1 = np.zeros(len(sizes) + 1, np.int64); off1[1:] = np.cumsum([len(c) for c in cb])
+    sig0, sig1 = np.concatenate(ca), np.concatenate(cb)
+    rid = np.zeros(len(sizes), np.int32)
+    got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='stouffer')
+    exp = orc.detect_batch(sig0, off0, sig1, off1, rid, 2, 2.0, orc.METHOD_STOUFFER)
+    H.compare_outputs(got, exp, True)
+    assert np.array_equal(got['status'], exp['status'])
+    ks = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+    H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
+    H.assert_close_p(ks['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
+    # int16 milli-unit input through the same path
+    q0 = np.round(sig0 * 1000).astype(np.int16); q1 = np.round(sig1 * 1000).astype(np.int16)
+    got16 = nm.detect_host(q0, off0, q1, off1, rid, nb=2, weights_dif=2.0, method='stouffer')
+    exp16 = orc.detect_batch(q0.astype(np.float64) / 1000, off0, q1.astype(np.float64) / 1000, off1, rid, 2, 2.0, orc.METHOD_STOUFFER)
+    H.compare_outputs(got16, exp16, True)
+
+
+def test_large_positions_fixed_stride_and_limit(nm):
+    """a fixed-coverage batch whose every position is large, and the format's limit of 65 535 samples per group"""
+    import nanomod_oracle as orc
+    L = nm._lib
+    rng = np.random.default_rng(5)
+    npos, n0, n1 = 7, 2500, 3100
+    sig0 = rng.normal(0, 1, npos * n0).astype(np.float32); sig1 = np.round(rng.normal(0.1, 1, npos * n1), 3).astype(np.float32)
+    off0 = np.arange(npos + 1, dtype=np.int64) * n0; off1 = np.arange(npos + 1, dtype=np.int64) * n1
+    rid = np.zeros(npos, np.int32)
+    exp = orc.detect_batch(sig0, off0, sig1, off1, rid, 2, 2.0, orc.METHOD_FISHER)
+    got = nm.detect_host(sig0, None, sig1, None, rid, nb=2, weights_dif=2.0, method='fisher', stride0=n0, stride1=n1)
+    H.compare_outputs(got, exp, True)
+    ks = nm.detect_host(sig0, None, sig1, None, rid, nb=2, weights_dif=2.0, method='fisher', stride0=n0, stride1=n1, tests=L.TEST_KS)
+    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+    H.assert_close_p(ks['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
+    big = np.zeros(65536, np.float32)
+    for tests in (L.TEST_ALL, L.TEST_KS):
+        with pytest.raises(L.NanomodLibraryError, match='more samples'):
+            nm.detect_host(big, np.array([0, 65536]), big[:10], np.array([0, 10]), np.zeros(1, np.int32), tests=tests, method='ks')
 
 
 def test_downsampling_branch_statistically_matches(nm):

@@ -5,8 +5,9 @@ One "step" = one pass of the hot path (K1 rank statistics + K2 p-values + K3 win
 combine) over one rank's shard of the synthetic genome, inputs resident in HBM.
 Workload at N=1: BASELINE.json configs[1] — E. coli 4.6 Mb, 200 v 200 reads/position,
 KS + weighted Stouffer (window 5), float32 signals.  For N>1 every rank owns 4.6 M
-positions of an N x 4.6 M position genome (weak scaling), computes them with a
-+-nb halo, and the per-base p-value tracks are reassembled with an RCCL all-gather.
+positions of an N x 4.6 M position genome (weak scaling) and computes them with a
++-nb halo of recomputed neighbours: the data path has no collective, every rank keeps its
+slice of the per-base tracks in HBM (nanomod_amd/sharding.py; gather=True would reassemble them).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -110,17 +111,15 @@ def main():
     det.synth_fill(sig1, SEED, lo_h, n_local, 1, N1, PLANT_PERIOD, PLANT_SHIFT)
     rid = torch.zeros(n_local, dtype=torch.int32, device=dev)       # one contiguous run
     out = det.alloc_outputs(n_local)
-    gathered = None
-    if world > 1:
-        gathered = {k: torch.empty(total_positions, dtype=torch.float64, device=dev) for k in ('ks_p', 'comb_p')}
 
     def compute(lo_hh, hi_hh):                       # this rank's block + halo is resident: [lo_h, hi_h)
         assert (lo_hh, hi_hh) == (lo_h, hi_h)
         return det.run(sig0, sig1, rid, stride0=N0, stride1=N1, npos=n_local, out=out)
 
     def step():
-        # partition + halo + one RCCL all-gather per track: the code path tests/test_sharding_gloo.py covers
-        return sharding.sharded_detect(compute, total_positions, NB, tracks=('ks_p', 'comb_p'), out=gathered)
+        # partition + halo, no collective in the data path (every rank keeps its slice of the tracks in HBM):
+        # the code path tests/test_sharding_gloo.py covers
+        return sharding.sharded_detect(compute, total_positions, NB, tracks=('ks_p', 'comb_p'), gather=False)
 
     for _ in range(args.warmup):
         step()
@@ -162,7 +161,7 @@ def main():
             'config': {'workload': 'E. coli 4.6 Mb x %d: %d positions/GPU, %d v %d reads/position, KS + weighted '
                                    'Stouffer window=%d (BASELINE.json configs[1])' % (world, P, N0, N1, 2 * NB + 1),
                        'positions_per_gpu': P, 'n0': N0, 'n1': N1, 'neighborPvalues': NB, 'WeightsDif': WDIF,
-                       'parallelism': 'position-sharded x%d, +-%d halo, RCCL all-gather of ks_p/comb_p' % (world, NB)},
+                       'parallelism': 'position-sharded x%d, +-%d halo recomputed, no data-path collective' % (world, NB)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_note': 'HBM bytes per launch from rocprofv3 PMC passes of this command (FETCH_SIZE x2 per the '
@@ -171,7 +170,7 @@ def main():
                          'algorithmic_bytes_per_position': algo_bytes,
                          'other_kernels_avg_ms': {'finalize': k2_ms / max(k1_n, 1), 'combine': k3_ms / max(k1_n, 1)}},
         }
-        if not args.no_cpu and not args.all_tests:
+        if not args.no_cpu and not args.all_tests and world == 1:   # the CPU baseline is an N=1 figure
             threads = usable_cpus()
             cap = args.cpu_sample or 1_000_000
             cap = min(cap, n_local)

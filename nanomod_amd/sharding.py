@@ -2,8 +2,10 @@
 
 Per-position tests are independent and the window combine needs only +-nb
 neighbours of the KS p-value track, so every rank takes one contiguous block of
-positions, also computes a halo of nb positions on each side instead of
-exchanging anything, and the per-base tracks are reassembled with ONE
+positions and also computes a halo of nb positions on each side instead of
+exchanging anything: the data path has no collective.  Each rank ends up with
+its own slice of every per-base track (what a per-rank table writer needs);
+`gather=True` additionally reassembles the full tracks on every rank with ONE
 all-gather per track (RCCL over xGMI when the backend is "nccl").
 """
 from __future__ import annotations
@@ -21,10 +23,10 @@ def halo_bounds(lo, hi, nb, npos):
     return max(lo - nb, 0), min(hi + nb, npos)
 
 
-def sharded_detect(compute, npos, nb, tracks=('ks_p', 'comb_p'), group=None, out=None):
+def sharded_detect(compute, npos, nb, tracks=('ks_p', 'comb_p'), group=None, out=None, gather=True):
     """Run `compute(lo_h, hi_h) -> {track: 1-D tensor over [lo_h, hi_h)}` on this rank's block
-    (+ halo), drop the halo and all-gather every requested track.  Returns full-length tensors
-    (identical on every rank).  `compute` is the HIP path in production; the world_size-2 CPU
+    (+ halo), drop the halo and — with gather=True — all-gather every requested track.  Returns full-length
+    tensors (identical on every rank), or with gather=False this rank's slice [lo, hi) of every track.  `compute` is the HIP path in production; the world_size-2 CPU
     tests inject a checker so the partition / halo / reassembly logic runs under gloo.
     `out`: optional {track: tensor[per * world]} reused across calls (no allocation per step)."""
     import torch
@@ -38,7 +40,7 @@ def sharded_detect(compute, npos, nb, tracks=('ks_p', 'comb_p'), group=None, out
     res = {}
     for name in tracks:
         mine = local[name][lo - lo_h: lo - lo_h + (hi - lo)] if hi > lo else None
-        if world == 1:
+        if world == 1 or not gather:
             res[name] = mine
             continue
         if out is not None:

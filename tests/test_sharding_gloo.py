@@ -38,6 +38,12 @@ def _worker(rank, world, port, npos, nb, method, q):
         r = oracle_c.detect_batch(sig0[off0[lo]:off0[hi]], o0, sig1[off1[lo]:off1[hi]], o1, rid[lo:hi], nb, 2.0, method, threads=1)
         return {k: torch.from_numpy(v) for k, v in r.items() if k != 'status'}
     out = sharding.sharded_detect(compute, npos, nb, tracks=('ks_p', 'comb_p', 'comb_st'))
+    # gather=False (what bench.py times): this rank's slice only, halo dropped, no collective
+    mine = sharding.sharded_detect(compute, npos, nb, tracks=('ks_p', 'comb_p', 'comb_st'), gather=False)
+    lo, hi = sharding.shard_bounds(npos, world, rank)
+    for k, v in mine.items():
+        got = np.zeros(0) if v is None else v.numpy()
+        assert got.shape[0] == hi - lo and np.array_equal(got, out[k].numpy()[lo:hi], equal_nan=True), (rank, k)
     q.put((rank, {k: v.numpy().copy() for k, v in out.items()}))
     dist.barrier()
     dist.destroy_process_group()

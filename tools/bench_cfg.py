@@ -35,7 +35,7 @@ del s0, s1
 # cfg5: ragged lognormal sizes, 1 M positions
 P = 1_000_000
 rng = np.random.default_rng(5)
-cap0 = 2048 if a.all_tests else 4000          # clipped [5, 4000]; all-tests mode sorts both groups (<= 2048)
+cap0 = 4000                                   # clipped [5, 4000]; groups beyond 2048 take big_rank_kernel in all-tests mode
 n0 = np.clip(np.round(rng.lognormal(np.log(1000), 0.5, P)), 5, cap0).astype(np.int64)
 n1 = np.clip(np.round(rng.lognormal(np.log(50), 0.5, P)), 5, 400).astype(np.int64)
 off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum(n0)

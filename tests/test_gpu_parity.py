@@ -472,3 +472,25 @@ def test_downsampling_cli_matches_mtest2_same_seed(nm):
         assert a == b
         exp, table = H.load_expected('g50_stouffer')
         assert a != table                                # the branch did change some KS pairs
+
+
+def test_welch_p_value_grid(nm):
+    """the incomplete-beta continued fraction (division-free forward recurrence) over a grid of degrees of freedom
+    and t values: tiny and huge groups, null to extreme shifts (p from 1 down to the DBL_MIN clamp)"""
+    import nanomod_oracle as orc
+    rng = np.random.default_rng(99)
+    ca, cb = [], []
+    for n0, n1 in [(2, 2), (2, 9), (3, 3), (5, 7), (30, 30), (200, 180), (1000, 40), (2000, 2000), (6000, 5000)]:
+        for delta in (0.0, 1e-3, 0.03, 0.3, 1.0, 3.0, 10.0, 60.0):
+            for s1 in (1.0, 0.05, 7.0):
+                ca.append(rng.normal(0, 1, n0)); cb.append(rng.normal(delta, s1, n1))
+    ca = [c.astype(np.float32) for c in ca]; cb = [c.astype(np.float32) for c in cb]
+    off0 = np.zeros(len(ca) + 1, np.int64); off0[1:] = np.cumsum([len(c) for c in ca])
+    off1 = np.zeros(len(cb) + 1, np.int64); off1[1:] = np.cumsum([len(c) for c in cb])
+    sig0, sig1 = np.concatenate(ca), np.concatenate(cb)
+    rid = np.zeros(len(ca), np.int32)
+    got = nm.detect_host(sig0, off0, sig1, off1, rid, method='ks')
+    exp = orc.detect_batch(sig0, off0, sig1, off1, rid, 2, 2.0, orc.METHOD_KS)
+    H.assert_close_stat(got['t_t'], exp['t_t'], 1e-11, 1e-15, 't_t')
+    H.assert_close_p(got['t_p'], exp['t_p'], 1e-9, 't_p')
+    assert (exp['t_p'] < 1e-200).any() and (exp['t_p'] > 0.5).any()

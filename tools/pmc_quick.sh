@@ -9,7 +9,7 @@ import csv,glob,collections
 for f in sorted(glob.glob('$OUT/p/*/*counter_collection.csv')):
     d=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'rank_' in r['Kernel_Name'] or 'ks_rank' in r['Kernel_Name']:
+        if any(t in r['Kernel_Name'] for t in ('rank_', 'finalize', 'combine')):
             d[(r['Kernel_Name'][:48],r['Counter_Name'])].append(float(r['Counter_Value']))
     for k,v in sorted(d.items()): print('  %-50s %-22s %.6g'%(k[0],k[1],sum(v)/len(v)))
 PY

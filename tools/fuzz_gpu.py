@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the HIP path against the C oracle (run on the GPU box: python tools/fuzz_gpu.py [rounds]).
+Random ragged batches: group sizes from 1 to ~9000 with random size ranges per batch, continuous / gridded /
+heavily tied values, optional int16 input, both test masks.  Test infrastructure, like everything under oracle/."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tests'))
+import nanomod_amd as nm            # noqa: E402
+import oracle_c                     # noqa: E402
+import helpers as H                 # noqa: E402
+
+L = nm._lib
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+master = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+for it in range(rounds):
+    rng = np.random.default_rng(master.integers(1 << 62))
+    hi0 = int(rng.choice([3, 8, 40, 64, 65, 130, 260, 600, 1100, 2048, 2500, 9000]))
+    hi1 = int(rng.choice([3, 8, 40, 64, 65, 130, 260, 600, 1100, 2048, 2500, 9000]))
+    lo0 = int(rng.integers(1, hi0 + 1)) if rng.random() < 0.5 else 1
+    lo1 = int(rng.integers(1, hi1 + 1)) if rng.random() < 0.5 else 1
+    npos = int(rng.integers(1, 400 if max(hi0, hi1) <= 600 else 40))
+    mode = rng.choice(['cont', 'grid2', 'grid0', 'i16'])
+    n0 = rng.integers(lo0, hi0 + 1, npos); n1 = rng.integers(lo1, hi1 + 1, npos)
+    off0 = np.zeros(npos + 1, np.int64); off0[1:] = np.cumsum(n0)
+    off1 = np.zeros(npos + 1, np.int64); off1[1:] = np.cumsum(n1)
+    a = rng.normal(0, 1, off0[-1]); b = rng.normal(rng.choice([0.0, 0.1, 1.0]), rng.choice([1.0, 0.3, 2.0]), off1[-1])
+    if mode == 'grid2':
+        a, b = np.round(a, 2), np.round(b, 2)
+    elif mode == 'grid0':
+        a, b = np.round(a, 0), np.round(b, 0)
+    if mode == 'i16':
+        s0 = np.round(a * 1000).astype(np.int16); s1 = np.round(b * 1000).astype(np.int16)
+        r0, r1 = s0.astype(np.float64) / 1000, s1.astype(np.float64) / 1000
+    else:
+        s0 = a.astype(np.float32); s1 = b.astype(np.float32); r0, r1 = s0, s1
+    rid = np.cumsum(rng.random(npos) < 0.1).astype(np.int32)
+    nb = int(rng.integers(0, 4)); method = str(rng.choice(['stouffer', 'fisher']))
+    exp = oracle_c.detect_batch(s0, off0, s1, off1, rid, nb, 2.0, method, threads=0)
+    got = nm.detect_host(s0, off0, s1, off1, rid, nb=nb, weights_dif=2.0, method=method)
+    ident = (exp['status'] & 1) != 0          # MWU all identical: U / p NaN on both sides
+    H.compare_outputs(got, exp, True)
+    assert np.array_equal(got['status'], exp['status'])
+    ks = nm.detect_host(s0, off0, s1, off1, rid, nb=nb, weights_dif=2.0, method=method, tests=L.TEST_KS)
+    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+    H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
+    H.assert_close_p(ks['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
+    print('round %d ok: npos %d sizes [%d..%d] x [%d..%d] %s nb %d %s identical %d' % (it, npos, lo0, hi0, lo1, hi1, mode, nb, method, ident.sum()), flush=True)
+print('fuzz ok')

@@ -72,8 +72,8 @@ def usable_cpus():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)     # the first ~7 launches run 5-20 % slow (clock ramp, profiles/r1_final_kernel_trace_summary.txt)
     ap.add_argument('--positions', type=int, default=P_ECOLI, help='positions per GPU (default: E. coli 4.6 M)')
     ap.add_argument('--cpu-sample', type=int, default=0, help='cap on positions for the CPU baseline (0 = 1 M)')
     ap.add_argument('--no-cpu', action='store_true')

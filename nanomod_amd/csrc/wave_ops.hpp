@@ -24,9 +24,23 @@ __device__ __forceinline__ float dpp_f(float old, float src) {
   return __int_as_float(dpp_i<CTRL, ROW_MASK, BANK_MASK, BOUND_CTRL>(__float_as_int(old), __float_as_int(src)));
 }
 
+// Which exchanges go through the LDS crossbar (ds_swizzle, bit mode: lane ^ mask inside 32 lanes) instead of
+// a DPP move.  A DPP move is a VALU instruction (~6 cycles of the SIMD with the v_med3 that consumes it,
+// tools/valu_rate.hip); ds_swizzle issues on the LDS pipe, which K1's sort leaves mostly idle.
+// bits: 1 xor1, 2 xor2, 4 xor4, 8 xor8, 16 mirror2, 32 mirror4, 64 mirror8, 128 mirror16
+#ifndef NMOD_SWZ_MASK
+#define NMOD_SWZ_MASK 0
+#endif
+template <int XORMASK>
+__device__ __forceinline__ float lane_swizzle_xor(float x) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x1F | (XORMASK << 10)));
+}
+
 // value of lane (l ^ M) for M in {1,2,4,8,16}
 template <int M>
 __device__ __forceinline__ float lane_xor(float x) {
+  if constexpr (M <= 8 && (NMOD_SWZ_MASK & M) != 0) return lane_swizzle_xor<M>(x);
+  else
   // every lane has a valid source in these patterns, so bound_ctrl:1 with old = 0 lets the
   // compiler emit the bare v_mov_b32_dpp (a tied `old` costs an extra v_mov per move)
   if constexpr (M == 1) return dpp_f<NMOD_QP(1, 0, 3, 2), 0xf, 0xf, true>(0.0f, x);
@@ -44,7 +58,8 @@ __device__ __forceinline__ float lane_xor(float x) {
 // value of lane (l ^ (G-1)): reversal inside aligned groups of G lanes
 template <int G>
 __device__ __forceinline__ float lane_mirror(float x, int lane) {
-  if constexpr (G == 2) return dpp_f<NMOD_QP(1, 0, 3, 2), 0xf, 0xf, true>(0.0f, x);
+  if constexpr (G <= 16 && (NMOD_SWZ_MASK & (G * 8)) != 0) return lane_swizzle_xor<G - 1>(x);
+  else if constexpr (G == 2) return dpp_f<NMOD_QP(1, 0, 3, 2), 0xf, 0xf, true>(0.0f, x);
   else if constexpr (G == 4) return dpp_f<NMOD_QP(3, 2, 1, 0), 0xf, 0xf, true>(0.0f, x);
   else if constexpr (G == 8) return dpp_f<kDppRowHalfMirror, 0xf, 0xf, true>(0.0f, x);
   else if constexpr (G == 16) return dpp_f<kDppRowMirror, 0xf, 0xf, true>(0.0f, x);

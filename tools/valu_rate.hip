@@ -16,9 +16,12 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int rep = 0; rep < 4; ++rep) {
-      if constexpr (MODE == 0) {          // in-lane CE: v_min + v_max
+      if constexpr (MODE == 0) {          // in-lane CE: v_min + v_max (the pairing alternates, or a repeated CE folds away)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) { float a = fminf(x[r], x[r + 1]), b = fmaxf(x[r], x[r + 1]); x[r] = a; x[r + 1] = b; }
+        for (int r = 0; r < 16; r += 2) {
+          const int i = (r + (rep & 1)) & 15, j = (r + 1 + (rep & 1)) & 15;
+          float a = fminf(x[i], x[j]), b = fmaxf(x[i], x[j]); x[i] = a; x[j] = b;
+        }
       } else if constexpr (MODE == 1) {   // quad_perm dpp + med3
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_fmed3f(x[r], lane_xor<1>(x[r]), c);
@@ -37,9 +40,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
       } else if constexpr (MODE == 6) {   // ds_swizzle + med3
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_fmed3f(x[r], lane_xor<16>(x[r]), c);
-      } else if constexpr (MODE == 7) {   // v_add_f32 baseline
+      } else if constexpr (MODE == 7) {   // integer baseline: v_mad_u32_u24 (independent v_add_f32 pairs become v_pk_add_f32)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = x[r] + c;
+        for (int r = 0; r < 16; ++r) x[r] = __int_as_float(__umul24(__float_as_int(x[r]), 3) + lane);
       } else if constexpr (MODE == 8) {   // v_cndmask pairs: cmp + 2 cndmask
 #pragma unroll
         for (int r = 0; r < 16; r += 2) { bool g = x[r] > x[r + 1]; float a = g ? x[r + 1] : x[r], b = g ? x[r] : x[r + 1]; x[r] = a; x[r + 1] = b; }
@@ -69,7 +72,7 @@ void run(const char* name, int valu_per_block, float* d) {
 
 int main() {
   float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
-  run<7>("v_add_f32", 16, d);
+  run<7>("v_mad_u32_u24", 16, d);
   run<0>("in-lane CE (v_min+v_max)", 16, d);
   run<4>("v_med3_f32", 16, d);
   run<1>("dpp quad_perm mov + med3", 32, d);

@@ -135,36 +135,64 @@ __global__ void class_offsets_kernel(int32_t* meta) {
   }
 }
 
-// positions of one 256-chunk that share a class stay contiguous and ordered inside the class list
+// Every block owns kScatterSpan consecutive positions: it counts their classes, reserves its slots in every class
+// list with ONE atomic per class present (all chunks hammering one counter was the whole cost of this kernel:
+// 0.21 ms for 4.6 M positions of one class), and writes its positions in order.  Each wave walks the DISTINCT
+// classes it holds: one ballot per class present (1-3 for real coverage), not one per class that exists.
+constexpr int kScatterSpan = 16 * 256;
+
 __global__ __launch_bounds__(256) void scatter_kernel(BinArgs a) {
-  __shared__ int base[kNumPairs];
-  for (int64_t chunk = blockIdx.x; chunk * 256 < a.npos; chunk += gridDim.x) {
-    int64_t p = chunk * 256 + threadIdx.x;
-    int cid = (p < a.npos) ? a.cls[p] : 255;
-    // rank inside the chunk among earlier threads of the same class (wave ballots + per-wave prefix)
-    int rank = 0;
-    __shared__ int wave_cnt[4][kNumPairs];
+  __shared__ int wave_cnt[4][kNumPairs];
+  __shared__ int run[kNumPairs];                 // next free slot of this block in every class list
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t span0 = (int64_t)blockIdx.x * kScatterSpan;
+  const int64_t span1 = span0 + kScatterSpan < a.npos ? span0 + kScatterSpan : a.npos;
+  // pass 1: class counts of the span
+  for (int i = threadIdx.x; i < kNumPairs; i += 256) run[i] = 0;
+  __syncthreads();
+  for (int64_t p0 = span0; p0 < span1; p0 += 256) {
+    const int64_t p = p0 + threadIdx.x;
+    const int cid = (p < span1) ? a.cls[p] : 255;
+    unsigned long long todo = __ballot(cid != 255);
+    while (todo != 0ull) {
+      const int c = __builtin_amdgcn_readlane(cid, __ffsll((long long)todo) - 1);
+      const unsigned long long same = __ballot(cid == c);
+      if (lane == 0) atomicAdd(&run[c], __popcll(same));
+      todo &= ~same;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumPairs) {
+    const int c = threadIdx.x;
+    const int tot = run[c];
+    run[c] = a.meta[kClassStride + c] + (tot ? atomicAdd(&a.meta[2 * kClassStride + c], tot) : 0);
+  }
+  __syncthreads();
+  // pass 2: the same walk, now writing; positions of a class keep their order inside the span
+  for (int64_t p0 = span0; p0 < span1; p0 += 256) {
+    const int64_t p = p0 + threadIdx.x;
+    const int cid = (p < span1) ? a.cls[p] : 255;
     for (int i = threadIdx.x; i < 4 * kNumPairs; i += 256) (&wave_cnt[0][0])[i] = 0;
     __syncthreads();
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned long long same = 0;
-    for (int c = 0; c < kNumPairs; ++c) {              // all lanes take part in every ballot
-      unsigned long long m = __ballot(cid == c);
-      if (cid == c) same = m;
+    int rank = 0;
+    unsigned long long todo = __ballot(cid != 255);
+    while (todo != 0ull) {
+      const int c = __builtin_amdgcn_readlane(cid, __ffsll((long long)todo) - 1);
+      const unsigned long long same = __ballot(cid == c);
+      if (cid == c) rank = __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_cnt[wave][c] = __popcll(same);
+      todo &= ~same;
     }
+    __syncthreads();
     if (cid != 255) {
-      rank = __popcll(same & ((1ull << lane) - 1ull));
-      if (rank == 0) wave_cnt[wave][cid] = __popcll(same);
+      for (int w = 0; w < wave; ++w) rank += wave_cnt[w][cid];
+      a.order[run[cid] + rank] = (int32_t)p;
     }
     __syncthreads();
-    if (cid != 255) for (int w = 0; w < wave; ++w) rank += wave_cnt[w][cid];
     if (threadIdx.x < kNumPairs) {
-      int c = threadIdx.x;
-      int tot = wave_cnt[0][c] + wave_cnt[1][c] + wave_cnt[2][c] + wave_cnt[3][c];
-      base[c] = tot ? atomicAdd(&a.meta[2 * kClassStride + c], tot) : 0;
+      const int c = threadIdx.x;
+      run[c] += wave_cnt[0][c] + wave_cnt[1][c] + wave_cnt[2][c] + wave_cnt[3][c];
     }
-    __syncthreads();
-    if (cid != 255) a.order[a.meta[kClassStride + cid] + base[cid] + rank] = (int32_t)p;
     __syncthreads();
   }
 }
@@ -298,7 +326,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     unsigned blocks = (unsigned)std::min<int64_t>((npos + 255) / 256, 4096);
     hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, stream, ba);
     hipLaunchKernelGGL(class_offsets_kernel, dim3(1), dim3(64), 0, stream, ws.meta);
-    hipLaunchKernelGGL(scatter_kernel, dim3(blocks), dim3(256), 0, stream, ba);
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((npos + kScatterSpan - 1) / kScatterSpan)), dim3(256), 0, stream, ba);
     NMOD_HIP(hipGetLastError());
     ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
     bool wanted[kNumClasses] = {false};

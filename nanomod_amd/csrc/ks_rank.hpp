@@ -12,7 +12,7 @@
 //        v = largest Q sample with U = k   :                          (cumU(k),   k)
 //      (k restricted to run ends of S); every other pooled point is dominated by these two, so
 //        ks_num = max_k max(|cumL(k-1)*m - k*q|, |cumU(k)*m - k*q|)
-//      is the same exact integer max|c0*n1 - c1*n0| the merge-path kernels produce.
+//      is the exact integer max|c0*n1 - c1*n0| over the pooled points.
 //      Without ties cumL == cumU and the maximum collapses to max_{k<m} max(a_k, q - a_k),
 //      a_k = cumU(k)*m - k*q: five VALU instructions per histogram bin.
 // Against the two-sort + merge-path form this removes one sort and the whole sequential merge:

@@ -15,6 +15,7 @@
 #include "rank_stats_launch.hpp"
 #include "pvalue_kernels.hpp"
 #include "big_rank.hpp"
+#include "rank_all.hpp"
 
 namespace nmod {
 
@@ -501,7 +502,8 @@ __global__ void selftest_sort_kernel(const float* in, float* out, int* runs) {
   for (int r = 0; r < R; ++r) x[r] = in[r * 64 + lane];
   wave_sort<R>(x, sel, lane);
   store_sorted<R>(out, x, lane);
-  store_runs<R>(runs, x, lane);
+  unsigned pp;
+  seg_runs_and_ties<R, 64, 1>(runs + lane * R, x, lane, false, pp);
 }
 
 template <int R>
@@ -551,7 +553,7 @@ const char* nmod_strerror(int rc) {
     case NMOD_ERR_HIP:
       snprintf(g_errbuf, sizeof(g_errbuf), "HIP runtime error: %s", hipGetErrorString(g_last_hip));
       return g_errbuf;
-    case NMOD_ERR_TOO_LARGE: return "a position has more samples per group than NMOD_MAX_GROUP (2048; in KS-only mode the larger group may hold up to 65535)";
+    case NMOD_ERR_TOO_LARGE: return "a position has more samples in a group than NMOD_MAX_RANKED (65535)";
     case NMOD_ERR_WORKSPACE: return "workspace missing or smaller than nmod_workspace_bytes()";
     case NMOD_ERR_NO_DEVICE: return "no HIP device";
     default: return "unknown error code";

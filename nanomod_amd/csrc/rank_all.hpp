@@ -274,4 +274,136 @@ void rank_all_kernel(RankStatsArgs args) {
   }
 }
 
+// ---- any two capacity classes: one position per wave, 64 lanes per group ---------------------------------
+// (e.g. 1000 v 50 reads.)  Same algorithm as rank_all_kernel; the group with FEWER samples is ranked into the
+// one with more, whichever of the two it is:
+//   E = group 2, T = group 1:  rank sum += b (2m - U - L);  KS candidates (c0, c1) = (U, j_e), (L, j_s)
+//   E = group 1, T = group 2:  rank sum += a (L + U)       (2 #{b < x} + #{b == x} per sample of the run);
+//                              KS candidates (c0, c1) = (j_e, U), (j_s, L)
+// with (j_s, j_e) the run of E and L / U its lower / upper rank in T.
+template <int RT, int RE, bool T_IS_A>
+__device__ __forceinline__ void rank_pair_phase(const float* keysT, const float* keysE, int nT, int nE, int lane,
+                                                unsigned& s_lane, unsigned long long& tie3, double& dmax) {
+  using LT = KsLayout<RT, 64>;
+  using LE = KsLayout<RE, 64>;
+  constexpr int LOG_RE = (RE == 1) ? 0 : (RE == 2) ? 1 : (RE == 4) ? 2 : (RE == 8) ? 3 : (RE == 16) ? 4 : 5;
+  const int steps = __builtin_amdgcn_readfirstlane((nE + 63) >> 6);
+  const double dT = (double)nT, dE = (double)nE;
+  const double rT = 1.0 / dT, rE = 1.0 / dE;
+#pragma unroll 1
+  for (int s = 0; s < steps; ++s) {
+    const int jq = s * 64 + lane;
+    const int wq = __mul24(jq & (RE - 1), LE::ROW) + (jq >> LOG_RE);
+    const float xq = keysE[wq];
+    const int re = reinterpret_cast<const int*>(keysE + LE::REGION)[wq];
+    const int js = re & 0xffff, je = (int)((unsigned)re >> 16);
+    const bool cand = (jq < nE) && (je == jq + 1);                 // the end of a run of E
+    const float* p = ks_search<RT, 64, false>(keysT, xq);
+    const int rt = *reinterpret_cast<const int*>(p + LT::REGION);   // p is the first key of its run: start == L
+    const bool tie = (*p == xq);
+    const int L = rt & 0xffff;
+    const int U = tie ? (int)((unsigned)rt >> 16) : L;
+    const int t = U - L, e = je - js;
+    const int w = T_IS_A ? 2 * nT - U - L : L + U;
+    s_lane += cand ? (unsigned)__mul24(e, w) : 0u;
+    const unsigned te = cand ? (unsigned)__mul24(t, e) : 0u;
+    tie3 += (unsigned long long)te * (unsigned long long)(unsigned)(t + e);
+    const double d_at = exact_quot(U, dT, rT) - exact_quot(je, dE, rE);      // |F_T - F_E|: the sign does not matter
+    const double d_before = exact_quot(L, dT, rT) - exact_quot(js, dE, rE);
+    const double dd = fmax(fabs(d_at), fabs(d_before));
+    dmax = cand ? fmax(dmax, dd) : dmax;
+  }
+}
+
+template <int R0, int R1, int DTYPE>
+__global__ __launch_bounds__(64 * kWavesPerBlock)
+void rank_pair_kernel(RankStatsArgs args) {
+  using LA = KsLayout<R0, 64>;
+  using LB = KsLayout<R1, 64>;
+  constexpr int C0 = 64 * R0, C1 = 64 * R1;
+  constexpr int WAVE_WORDS = 2 * LA::REGION + 2 * LB::REGION;     // keys A, runs A, keys B, runs B
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* keysA = lds_all + wave * WAVE_WORDS;
+  float* keysB = keysA + 2 * LA::REGION;
+
+  const float inf = __builtin_inff();
+  LaneSel sel;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) sel.s[b] = ((lane >> b) & 1) ? inf : -inf;
+  for (int r = lane; r < R0; r += 64) {                            // the spare columns: key / rank C
+    keysA[r * LA::ROW + LA::END] = inf;
+    reinterpret_cast<int*>(keysA + LA::REGION)[r * LA::ROW + LA::END] = C0 | (C0 << 16);
+  }
+  for (int r = lane; r < R1; r += 64) {
+    keysB[r * LB::ROW + LB::END] = inf;
+    reinterpret_cast<int*>(keysB + LB::REGION)[r * LB::ROW + LB::END] = C1 | (C1 << 16);
+  }
+
+  int64_t count = args.npos;
+  const int32_t* list = nullptr;
+  if (args.pos_list) {
+    count = args.class_meta[args.class_id];
+    list = args.pos_list + args.class_meta[kClassStride + args.class_id];
+  }
+  const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
+
+  for (int64_t it = wave_global; it < count; it += wave_stride) {
+    const int64_t pos = list ? (int64_t)list[it] : it;
+    int64_t o0, o1; int n0, n1;
+    if (args.stride0 > 0) { o0 = pos * args.stride0; n0 = (int)args.stride0; }
+    else { o0 = args.off0[pos]; n0 = (int)(args.off0[pos + 1] - o0); }
+    if (args.stride1 > 0) { o1 = pos * args.stride1; n1 = (int)args.stride1; }
+    else { o1 = args.off1[pos]; n1 = (int)(args.off1[pos + 1] - o1); }
+
+    unsigned pp0, pp1;
+    {
+      float xa[R0];
+      load_group<R0, DTYPE>(xa, args.sig0, o0, n0, lane);
+      double mean, m2;
+      group_moments<R0, DTYPE>(xa, n0, lane, mean, m2);
+      if (lane == 0) { double* mo = args.moments + pos * 4; mo[0] = mean; mo[1] = m2; }
+      wave_sort<R0>(xa, sel, lane);
+#pragma unroll
+      for (int r = 0; r < R0; ++r) keysA[r * LA::ROW + lane] = xa[r];
+      seg_runs_and_ties<R0, 64, LA::ROW>(reinterpret_cast<int*>(keysA + LA::REGION) + lane, xa, lane, false, pp0);
+    }
+    {
+      float xb[R1];
+      load_group<R1, DTYPE>(xb, args.sig1, o1, n1, lane);
+      double mean, m2;
+      group_moments<R1, DTYPE>(xb, n1, lane, mean, m2);
+      if (lane == 0) { double* mo = args.moments + pos * 4 + 2; mo[0] = mean; mo[1] = m2; }
+      wave_sort<R1>(xb, sel, lane);
+#pragma unroll
+      for (int r = 0; r < R1; ++r) keysB[r * LB::ROW + lane] = xb[r];
+      seg_runs_and_ties<R1, 64, LB::ROW>(reinterpret_cast<int*>(keysB + LB::REGION) + lane, xb, lane, false, pp1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    unsigned s_lane = 0;
+    unsigned long long tie3 = 0;
+    double dmax = 0.0;
+    if (n1 <= n0) rank_pair_phase<R0, R1, true>(keysA, keysB, n0, n1, lane, s_lane, tie3, dmax);
+    else rank_pair_phase<R1, R0, false>(keysB, keysA, n1, n0, lane, s_lane, tie3, dmax);
+
+    dmax = wave_max_f64(dmax);
+    const unsigned long long S = wave_sum_u64((unsigned long long)s_lane);
+    const unsigned long long PP = wave_sum_u64((unsigned long long)pp0 + (unsigned long long)pp1);
+    const unsigned long long T3 = wave_sum_u64(tie3);
+    if (lane == 0) {
+      const unsigned long long pa = (unsigned long long)(C0 - n0), pb = (unsigned long long)(C1 - n1);
+      const unsigned long long pads = (pa * pa * pa - pa) / 3ull + (pb * pb * pb - pb) / 3ull;
+      args.mwu_s[pos] = S;
+      args.tie[pos] = 3ull * (PP - pads) + 3ull * T3;
+      args.ks_d_ref[pos] = (n0 > 0 && n1 > 0) ? dmax : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace nmod

@@ -1,25 +1,20 @@
-// K1 — per-position rank statistics, one wavefront (64 lanes) per genomic position.
+// K1 — per-position rank statistics: shared types and the register sort of one 64-lane wave.
 //
-// Replaces the data-dependent part of getKStest (myDetect.py:327-343): the
-// sorts / searchsorted of ks_2samp, the rankdata + tiecorrect of mannwhitneyu
-// and the mean / var reductions of ttest_ind.  It emits exact integers
-//     ks_num = max_v |c0(v)*n1 - c1(v)*n0|,  c = #{x <= v}           (KS D numerator)
+// K1 replaces the data-dependent part of getKStest (myDetect.py:327-343): the sorts / searchsorted of
+// ks_2samp, the rankdata + tiecorrect of mannwhitneyu and the mean / var reductions of ttest_ind.
+// It emits exact integers
+//     ks_num = max_v |c0(v)*n1 - c1(v)*n0|,  c = #{x <= v}           (KS D numerator, KS-only mode)
 //     mwu_s  = sum_{a in group 1} (#{b < a} + #{b <= a})             (U1 = n0*n1 - mwu_s/2)
 //     tie    = sum_{pooled tie groups} (t^3 - t)                      (tiecorrect)
-// and fp64 (mean, M2) per group; the p-values are a separate kernel (K2).
-//
-// Algorithm, per wave:
-//   1. coalesced dword loads: lane l takes samples l, l+64, ... into R registers
-//      per group (R = 1..32 -> up to 64*R samples, padded with +inf);
-//   2. each group is sorted in registers by a bitonic network in its "mirror"
-//      form (every merge ascending).  Compare-exchanges between registers of
-//      one lane are v_min/v_max; between lanes they are one DPP move (or
-//      ds_swizzle / ds_bpermute beyond a 16-lane row) + one v_med3_f32 whose
-//      third operand is -inf (keep min) or +inf (keep max) per lane;
-//   3. both sorted groups go to wave-private LDS; each lane finds its merge-path
-//      split by binary search and merges ceil((n0+n1)/64) pooled elements
-//      sequentially, carrying the exact counts (c0, c1) — so the KS numerator,
-//      the rank sums and the tie term come out of one pass, ties included.
+// the float form of D (all-tests mode) and fp64 (mean, M2) per group; the p-values are a separate kernel (K2).
+// The forms of K1: ks_rank.hpp (KS-only), rank_all.hpp (all tests: same-class and any-class positions),
+// big_rank.hpp (groups beyond 2048 samples).  This header holds what they share:
+//   * RankStatsArgs;
+//   * coalesced dword loads: lane l takes samples l, l+64, ... into R registers (padded with +inf);
+//   * the bitonic sort of R registers x 64 lanes in its "mirror" form (every merge ascending):
+//     compare-exchanges between registers of one lane are v_min / v_max; between lanes one DPP move (or
+//     ds_swizzle / ds_bpermute beyond a 16-lane row) + one v_med3_f32 whose third operand is -inf (keep
+//     min) or +inf (keep max) per lane.
 // No MFMA: this is sort / scan / reduction work (BASELINE.json).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -181,212 +176,6 @@ __device__ __forceinline__ void store_sorted(float* dst, const float (&x)[R], in
     *reinterpret_cast<float2*>(dst + lane * 2) = make_float2(x[0], x[1]);
   } else {
     dst[lane] = x[0];
-  }
-}
-
-// run extents of equal keys inside one sorted group, packed (start | end << 16), end exclusive
-template <int R>
-__device__ __forceinline__ void store_runs(int* dst, const float (&x)[R], int lane) {
-  constexpr int N = 64 * R;
-  const float nanv = __builtin_nanf("");
-  float prev_last = lane_prev(x[R - 1], nanv);     // NaN != anything: lane 0 starts a run
-  float next_first = lane_next(x[0], nanv);        // lane 63 ends a run
-  int inc[R];      // running max of run-start indices inside the lane
-  int run = 0;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    float p = (r == 0) ? prev_last : x[r - 1];
-    int e = lane * R + r;
-    run = (x[r] != p) ? e : run;
-    inc[r] = run;
-  }
-  int carry = lane_prev_i(wave_scan_max_i32(run), 0);   // exclusive scan over lanes
-  int suf[R];      // running max of (N - end) from the right: end = N - suf
-  int acc = 0;
-#pragma unroll
-  for (int r = R - 1; r >= 0; --r) {
-    float q = (r == R - 1) ? next_first : x[r + 1];
-    int e = lane * R + r;
-    acc = (x[r] != q) ? max(acc, N - (e + 1)) : acc;
-    suf[r] = acc;
-  }
-  // suffix max over lanes: mirror, prefix-scan, mirror back, shift
-  int m = __builtin_amdgcn_ds_bpermute((63 - lane) << 2, acc);
-  m = wave_scan_max_i32(m);
-  m = __builtin_amdgcn_ds_bpermute((63 - lane) << 2, m);     // inclusive suffix max
-  int carry_r = lane_next_i(m, 0);                              // exclusive
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    int start = max(inc[r], carry);
-    int end = N - max(suf[r], carry_r);
-    dst[lane * R + r] = start | (end << 16);
-  }
-}
-
-// ---- the kernel ----------------------------------------------------------
-template <int R0, int R1, int DTYPE, bool MWU, bool WELCH>
-__global__ __launch_bounds__(64 * kWavesPerBlock)
-void rank_stats_kernel(RankStatsArgs args) {
-  constexpr int NA = 64 * R0, NB = 64 * R1;
-  constexpr int KEYS = NA + kLdsPad + NB + kLdsPad;
-  constexpr int WAVE_LDS = MWU ? 2 * KEYS : KEYS;       // in 4-byte words
-  extern __shared__ __attribute__((aligned(16))) float lds_all[];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* keysA = lds_all + wave * WAVE_LDS;
-  float* keysB = keysA + NA + kLdsPad;
-  int* runA = reinterpret_cast<int*>(keysA + KEYS);
-  int* runB = runA + NA + kLdsPad;
-
-  const float inf = __builtin_inff();
-  LaneSel sel;
-#pragma unroll
-  for (int b = 0; b < 6; ++b) sel.s[b] = ((lane >> b) & 1) ? inf : -inf;
-  if (lane < kLdsPad) {
-    keysA[NA + lane] = inf;
-    keysB[NB + lane] = inf;
-    if constexpr (MWU) { runA[NA + lane] = 0; runB[NB + lane] = 0; }
-  }
-
-  int64_t count = args.npos;
-  const int32_t* list = nullptr;
-  if (args.pos_list) {
-    count = args.class_meta[args.class_id];
-    list = args.pos_list + args.class_meta[kClassStride + args.class_id];
-  }
-  const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
-
-  for (int64_t it = wave_global; it < count; it += wave_stride) {
-    const int64_t pos = list ? (int64_t)list[it] : it;
-    int64_t o0, o1; int n0, n1;
-    if (args.stride0 > 0) { o0 = pos * args.stride0; n0 = (int)args.stride0; }
-    else { o0 = args.off0[pos]; n0 = (int)(args.off0[pos + 1] - o0); }
-    if (args.stride1 > 0) { o1 = pos * args.stride1; n1 = (int)args.stride1; }
-    else { o1 = args.off1[pos]; n1 = (int)(args.off1[pos + 1] - o1); }
-
-    float xa[R0], xb[R1];
-    load_group<R0, DTYPE>(xa, args.sig0, o0, n0, lane);
-    load_group<R1, DTYPE>(xb, args.sig1, o1, n1, lane);
-
-    if constexpr (WELCH) {
-      double mean0, m20, mean1, m21;
-      group_moments<R0, DTYPE>(xa, n0, lane, mean0, m20);
-      group_moments<R1, DTYPE>(xb, n1, lane, mean1, m21);
-      if (lane == 0) {
-        double* mo = args.moments + pos * 4;
-        mo[0] = mean0; mo[1] = m20; mo[2] = mean1; mo[3] = m21;
-      }
-    }
-
-    wave_sort<R0>(xa, sel, lane);
-    wave_sort<R1>(xb, sel, lane);
-
-    store_sorted<R0>(keysA, xa, lane);
-    store_sorted<R1>(keysB, xb, lane);
-    if constexpr (MWU) {
-      store_runs<R0>(runA, xa, lane);
-      store_runs<R1>(runB, xb, lane);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- merge path: lane handles pooled elements [d0, d1)
-    const int total = n0 + n1;
-    const int per = __builtin_amdgcn_readfirstlane((total + 63) >> 6);
-    const int d0 = min(lane * per, total);
-    const int d1 = min(d0 + per, total);
-    int lo = max(0, d0 - n1), hi = min(d0, n0);
-    // wave-uniform iteration count: enough for the widest range
-    const int span = min(min(n0, n1), total);
-    int iters = 32 - __builtin_clz((unsigned)span | 1u);
-    iters = __builtin_amdgcn_readfirstlane(iters);
-#pragma unroll 1
-    for (int s = 0; s < iters; ++s) {
-      int mid = (lo + hi) >> 1;
-      int jb = max(d0 - 1 - mid, 0);
-      float a = keysA[mid];
-      float b = keysB[jb];
-      bool act = lo < hi;
-      bool pred = a <= b;                 // A[mid] precedes B[d0-1-mid] (ties: group 1 first)
-      lo = (act && pred) ? mid + 1 : lo;
-      hi = (act && !pred) ? mid : hi;
-    }
-    int i = lo, j = d0 - lo;
-    float a = keysA[i], b = keysB[j];
-    float la = (i > 0) ? keysA[i - 1] : __builtin_nanf("");
-    int num = i * n1 - j * n0;
-    unsigned best = 0, s_lane = 0, tie_lane = 0;
-    // all-tests mode also reproduces ks_2samp's float expression bit for bit: remember which steps
-    // took group 1 (amask) and which steps tie the lane's running maximum (tmask)
-    const int i_start = i;
-    unsigned long long amask = 0, tmask = 0;
-#pragma unroll 1
-    for (int s = 0; s < per; ++s) {
-      const bool act = (d0 + s) < d1;
-      const bool takeA = a <= b;
-      const float v = takeA ? a : b;
-      if constexpr (MWU) {
-        int rb = runB[j];
-        int ra = runA[max(takeA ? i : i - 1, 0)];
-        int ra_s = ra & 0xffff, ra_e = ra >> 16, rb_s = rb & 0xffff, rb_e = rb >> 16;
-        int ownlen = takeA ? (ra_e - ra_s) : (rb_e - rb_s);
-        int cross = takeA ? ((b == v) ? (rb_e - j) : 0) : ((la == v) ? (i - ra_s) : 0);
-        int t = ownlen + cross;
-        if (act) {
-          s_lane += takeA ? (unsigned)(2 * j + cross) : 0u;
-          tie_lane += (unsigned)(t * t - 1);
-        }
-      }
-      if (act) {
-        i += takeA ? 1 : 0;
-        j += takeA ? 0 : 1;
-        num += takeA ? n1 : -n0;
-        la = takeA ? v : la;
-      }
-      float nv = takeA ? keysA[i] : keysB[j];
-      a = (act && takeA) ? nv : a;
-      b = (act && !takeA) ? nv : b;
-      const bool run_end = fminf(a, b) != v;
-      unsigned mag = (unsigned)abs(num);
-      if constexpr (MWU) {
-        const unsigned long long bit = 1ull << s;
-        const bool cand = act && run_end;
-        const unsigned magc = cand ? mag : 0u;
-        amask |= (act && takeA) ? bit : 0ull;
-        tmask = (magc > best) ? bit : ((cand && magc == best) ? (tmask | bit) : tmask);
-        best = max(best, magc);
-      } else {
-        best = (act && run_end) ? max(best, mag) : best;
-      }
-    }
-    const unsigned lane_best = best;
-    best = wave_max_u32(best);
-    if constexpr (MWU) {
-      // D = max over the pooled points that attain the integer maximum of |fl(c0/n0) - fl(c1/n1)|
-      // (scipy 1.2.1 ks_2samp: cdf = searchsorted(...)/(1.0*n); d = max(|cdf1 - cdf2|))
-      unsigned long long tm = (lane_best == best && best > 0) ? tmask : 0ull;
-      double dmax = 0.0;
-      while (__ballot(tm != 0ull)) {
-        if (tm != 0ull) {
-          const int st = __ffsll((long long)tm) - 1;
-          tm &= tm - 1ull;
-          const int c0 = i_start + __popcll(amask & ((2ull << st) - 1ull));
-          const int c1 = (d0 + st + 1) - c0;
-          dmax = fmax(dmax, fabs((double)c0 / (double)n0 - (double)c1 / (double)n1));
-        }
-      }
-      dmax = wave_max_f64(dmax);
-      if (lane == 0) args.ks_d_ref[pos] = dmax;
-    }
-    if constexpr (MWU) {
-      unsigned long long S = wave_sum_u64((unsigned long long)s_lane);
-      unsigned long long T = wave_sum_u64((unsigned long long)tie_lane);
-      if (lane == 0) { args.mwu_s[pos] = S; args.tie[pos] = T; }
-    }
-    if (lane == 0) args.ks_num[pos] = best;
-    __builtin_amdgcn_wave_barrier();
   }
 }
 

@@ -18,9 +18,9 @@ constexpr bool ALL = NMOD_INST_ALL != 0;
 using KernelFn = void (*)(RankStatsArgs);
 
 #if NMOD_INST_ALL
-// all-tests builds: rank_all_kernel for same-class positions, the general merge-path kernel for the rest
+// all-tests builds: rank_all_kernel for same-class positions, rank_pair_kernel (one position per wave) for the rest
 template <int C0, int C1>
-constexpr KernelFn kernel_of() { return rank_stats_kernel<(1 << C0), (1 << C1), DT, ALL, ALL>; }
+constexpr KernelFn kernel_of() { return rank_pair_kernel<(1 << C0), (1 << C1), DT>; }
 
 template <int C0>
 KernelFn pick1(int c1) {

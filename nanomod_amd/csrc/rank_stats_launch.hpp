@@ -1,7 +1,7 @@
 // Host-side launch interface of K1 (one translation unit per dtype x tests pair).
 //
 // Size classes.  A group of n samples needs capacity 64 << c (c = 0..5: 64 .. 2048).
-//   general class  c0 * 6 + c1      (0..35): rank_stats_kernel<1<<c0, 1<<c1>, 64 lanes per group;
+//   general class  c0 * 6 + c1      (0..35): rank_pair_kernel<1<<c0, 1<<c1> (rank_all.hpp), 64 lanes per group;
 //   packed class   36 + cm          (36..40): rank_all_kernel (rank_all.hpp), both groups in capacity 64 << cm,
 //                  used when max(c0,c1) = cm <= 4 and min(c0,c1) >= cm - 1:
 //                  cm 0..1 -> (R, LG) = (8,8) (16,8): four positions per wave; cm 2..3 -> (16,16) (32,16): two;
@@ -50,9 +50,11 @@ inline size_t rank_stats_lds_bytes(int cls, bool all) {
     if (LG == 8) while ((w & 31) != 16) ++w;
     return (size_t)packed_positions_per_wave(cm) * w * 4 * 4;
   } else {
-    words = (64u << (cls / kNumSizeClasses)) + 4 + (64u << (cls % kNumSizeClasses)) + 4;   // kLdsPad = 4
+    // rank_pair_kernel (rank_all.hpp): keys + runs of both groups, R x 65 words each
+    words = 2 * 65 * ((1u << (cls / kNumSizeClasses)) + (1u << (cls % kNumSizeClasses)));
   }
-  return (all ? 2 : 1) * words * 4 /*bytes*/ * 4 /*waves per block*/;
+  (void)all;
+  return words * 4 /*bytes*/ * 4 /*waves per block*/;
 }
 
 hipError_t launch_rank_stats_d0_a0(int cls, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);

@@ -15,7 +15,8 @@ namespace nmod {
 // ---- segmented (LG-lane) wave helpers --------------------------------------------------------
 template <int LG>
 __device__ __forceinline__ int seg_mirror_i(int x) {
-  if constexpr (LG == 8) return dpp_i<kDppRowHalfMirror, 0xf, 0xf, true>(0, x);
+  if constexpr (LG == 64) return __builtin_amdgcn_ds_bpermute((63 - (int)(threadIdx.x & 63)) << 2, x);
+  else if constexpr (LG == 8) return dpp_i<kDppRowHalfMirror, 0xf, 0xf, true>(0, x);
   else if constexpr (LG == 16) return dpp_i<kDppRowMirror, 0xf, 0xf, true>(0, x);
   else return __builtin_amdgcn_ds_swizzle(x, 0x7C1F);
 }
@@ -27,7 +28,8 @@ __device__ __forceinline__ int seg_scan_max_i32(int v) {
   v = max(v, dpp_i<kDppRowShr + 2>(0, v));
   v = max(v, dpp_i<kDppRowShr + 4>(0, v));
   if constexpr (LG >= 16) v = max(v, dpp_i<kDppRowShr + 8>(0, v));
-  if constexpr (LG == 32) v = max(v, dpp_i<kDppRowBcast15, 0xA>(0, v));
+  if constexpr (LG >= 32) v = max(v, dpp_i<kDppRowBcast15, 0xA>(0, v));
+  if constexpr (LG == 64) v = max(v, dpp_i<kDppRowBcast31, 0xC>(0, v));
   return v;   // LG == 8: lanes 8..15 of a row also see lanes 0..7; callers bias the second group
 }
 

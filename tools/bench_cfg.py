@@ -21,7 +21,8 @@ def run(name, det, sig0, sig1, rid, steps=5, **kw):
     print(json.dumps({'config': name, 'positions': npos, 'positions_per_s': npos / dt, 'ms_per_step': dt * 1e3,
                       'k1_ms': k1 / n, 'input_GBps_over_k1': nbytes / (k1 / n * 1e-3) / 1e9}))
 
-ap = argparse.ArgumentParser(); ap.add_argument('--all-tests', action='store_true'); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument('--all-tests', action='store_true')
+ap.add_argument('--cap0', type=int, default=4000, help='clip of the cfg5 group-1 sizes'); a = ap.parse_args()
 tests = L.TEST_ALL if a.all_tests else L.TEST_KS
 dev = 'cuda:0'
 det = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=tests)
@@ -35,7 +36,7 @@ del s0, s1
 # cfg5: ragged lognormal sizes, 1 M positions
 P = 1_000_000
 rng = np.random.default_rng(5)
-cap0 = 4000                                   # clipped [5, 4000]; groups beyond 2048 take big_rank_kernel in all-tests mode
+cap0 = a.cap0                                 # clipped [5, 4000]; groups beyond 2048 take big_rank_kernel in all-tests mode
 n0 = np.clip(np.round(rng.lognormal(np.log(1000), 0.5, P)), 5, cap0).astype(np.int64)
 n1 = np.clip(np.round(rng.lognormal(np.log(50), 0.5, P)), 5, 400).astype(np.int64)
 off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum(n0)

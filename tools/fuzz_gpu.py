@@ -43,6 +43,8 @@ for it in range(rounds):
     exp = oracle_c.detect_batch(s0, off0, s1, off1, rid, nb, 2.0, method, threads=0)
     got = nm.detect_host(s0, off0, s1, off1, rid, nb=nb, weights_dif=2.0, method=method)
     ident = (exp['status'] & 1) != 0          # MWU all identical: U / p NaN on both sides
+    assert np.all(np.isnan(got['mwu_u'][ident])) and np.all(np.isnan(exp['mwu_u'][ident]))
+    got['mwu_u'][ident] = 0.0; exp['mwu_u'][ident] = 0.0
     H.compare_outputs(got, exp, True)
     assert np.array_equal(got['status'], exp['status'])
     ks = nm.detect_host(s0, off0, s1, off1, rid, nb=nb, weights_dif=2.0, method=method, tests=L.TEST_KS)

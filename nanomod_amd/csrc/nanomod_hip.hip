@@ -356,7 +356,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
         bg.scratch = (float*)big_scratch.p;
         bg.cursor = reinterpret_cast<unsigned long long*>(ws.meta + kMetaBigCursor);
         bg.ks_num = ws.ks_num; bg.mwu_s = ws.mwu_s; bg.tie = ws.tie; bg.moments = ws.moments; bg.ks_d_ref = ws.ks_d_ref;
-        const unsigned blocks = (unsigned)std::min<int64_t>(nbig, (int64_t)num_cus * 2);
+        const unsigned blocks = (unsigned)std::min<int64_t>(nbig, (int64_t)num_cus * 4);   // 4 x 33 KB of LDS per CU
         if (prm->dtype == NMOD_DTYPE_F32) hipLaunchKernelGGL(big_rank_kernel<0>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
         else hipLaunchKernelGGL(big_rank_kernel<1>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
         NMOD_HIP(hipGetLastError());

@@ -129,7 +129,8 @@ class EventTimer:
 
 class DeviceDetector:
     """Device-resident form: inputs and outputs are torch CUDA tensors; nothing is copied
-    and nothing synchronises unless max_n0/max_n1 are unknown for CSR inputs."""
+    and nothing synchronises unless max_n0/max_n1 are unknown for CSR inputs or allow groups beyond MAX_GROUP
+    (one round trip sizes the scratch of the large-position pass)."""
 
     def __init__(self, device=0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_ALL, want_mstd=False):
         import torch

@@ -98,6 +98,18 @@ __device__ __forceinline__ void seg_runs_and_ties(int* dst_lane, float (&y)[R], 
   }
 }
 
+// sum_{p = 1..P} p (p - 1) = (P - 1) P (P + 1) / 3 for the run of P <= 2048 pads, in 32-bit arithmetic:
+// one of the three factors is divisible by 3 and the quotient is < 2^32
+__device__ __forceinline__ unsigned pad_run_pp(int P) {
+  const unsigned p = (unsigned)P;
+  const unsigned t = (p * 43691u) >> 17;                 // p / 3 for p < 2^16
+  const unsigned r = p - 3u * t;
+  const unsigned a = (r == 1u) ? (p - 1u) / 3u : p - 1u;  // (the compiler turns / 3 into the same multiply)
+  const unsigned b = (r == 0u) ? t : p;
+  const unsigned c = (r == 2u) ? (p + 1u) / 3u : p + 1u;
+  return a * b * c;
+}
+
 // sum of a per-lane fp64 value over the 2*LG lanes of a position
 template <int LG>
 __device__ __forceinline__ double pos_allsum_f64(double v) {
@@ -261,8 +273,7 @@ void rank_all_kernel(RankStatsArgs args) {
     const double t3 = pos_allsum_f64<LG>((double)tie3);              // < 2^53: exact
     if (valid && pl == 0) {
       // the +inf pads of each group form one run of P = C - n keys: take its sum_{p<=P} p (p - 1) = (P^3 - P) / 3 out
-      const unsigned long long pa = (unsigned long long)(C - m), pb = (unsigned long long)(C - q);
-      const unsigned long long pads = (pa * pa * pa - pa) / 3ull + (pb * pb * pb - pb) / 3ull;
+      const unsigned long long pads = (unsigned long long)pad_run_pp(C - m) + (unsigned long long)pad_run_pp(C - q);
       args.mwu_s[pos] = S;
       args.tie[pos] = 3ull * (PP - pads) + 3ull * (unsigned long long)t3;
       args.ks_d_ref[pos] = (m > 0 && q > 0) ? dmax : 0.0;
@@ -396,8 +407,7 @@ void rank_pair_kernel(RankStatsArgs args) {
     const unsigned long long PP = wave_sum_u64((unsigned long long)pp0 + (unsigned long long)pp1);
     const unsigned long long T3 = wave_sum_u64(tie3);
     if (lane == 0) {
-      const unsigned long long pa = (unsigned long long)(C0 - n0), pb = (unsigned long long)(C1 - n1);
-      const unsigned long long pads = (pa * pa * pa - pa) / 3ull + (pb * pb * pb - pb) / 3ull;
+      const unsigned long long pads = (unsigned long long)pad_run_pp(C0 - n0) + (unsigned long long)pad_run_pp(C1 - n1);
       args.mwu_s[pos] = S;
       args.tie[pos] = 3ull * (PP - pads) + 3ull * T3;
       args.ks_d_ref[pos] = (n0 > 0 && n1 > 0) ? dmax : 0.0;

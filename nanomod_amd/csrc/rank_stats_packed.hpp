@@ -153,30 +153,33 @@ __device__ __forceinline__ void load_packed(float (&x)[R], const void* sig, int6
   }
 }
 
-// mean and sum of squared deviations of one group (fp64, two-pass); pads are +inf
+// mean and sum of squared deviations of one group in fp64; pads are +inf.  One pass over the keys, shifted by the
+// group's first sample K:  mean = K + S1/n,  M2 = S2 - S1^2/n  with S1 = sum (x - K), S2 = sum (x - K)^2.
+// The shift keeps the cancellation in M2 at ~(1 + (mean - K)^2 / var) ulps of fp64 — np.var's two-pass result to
+// ~1e-14 — for half the instructions of two masked passes (a pad becomes K: it adds 0 to both sums).
 template <int R, int LG, int DTYPE>
 __device__ __forceinline__ void seg_moments(const float (&x)[R], int n, double& mean, double& m2) {
   const float inf = __builtin_inff();
-  double s = 0.0;
+  const int lane = threadIdx.x & 63;
+  float kf = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & ~(LG - 1)) << 2, __float_as_int(x[0])));
+  kf = (kf == inf) ? 0.0f : kf;                                   // empty group
+  const double K = (double)kf;
+  double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    s += (x[r] != inf) ? (double)x[r] : 0.0;
-    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // do not convert all R keys to fp64 at once
+    const float xm = (x[r] != inf) ? x[r] : kf;
+    const double d = (double)xm - K;
+    s1 += d;
+    s2 = __fma_rn(d, d, s2);
+    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);          // do not convert all R keys to fp64 at once
   }
-  s = seg_allsum_f64<LG>(s);
-  const double mu = s / (double)n;
-  double q = 0.0;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    float xr = x[r];
-    asm volatile("" : "+v"(xr));          // opaque copy: stops the compiler keeping R fp64 conversions live from pass 1
-    double d = (double)xr - mu;
-    q += (xr != inf) ? d * d : 0.0;
-    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-  }
-  q = seg_allsum_f64<LG>(q);
+  s1 = seg_allsum_f64<LG>(s1);
+  s2 = seg_allsum_f64<LG>(s2);
+  const double dn = (double)n;
+  const double mu = K + s1 / dn;
+  const double q = s2 - s1 * s1 / dn;
   if constexpr (DTYPE == 0) { mean = mu; m2 = q; }
-  else { mean = s / 1000.0 / (double)n; m2 = q * 1e-6; }
+  else { mean = mu / 1000.0; m2 = q * 1e-6; }
 }
 
 }  // namespace nmod

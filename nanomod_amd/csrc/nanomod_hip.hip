@@ -270,9 +270,13 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   Workspace ws = carve(workspace, npos);
   if (!workspace || workspace_bytes < ws.bytes) return NMOD_ERR_WORKSPACE;
 
-  hipDeviceProp_t prop;
-  NMOD_HIP(hipGetDeviceProperties(&prop, prm->device));
-  const int num_cus = prop.multiProcessorCount;
+  // CU count per device, looked up once (hipGetDeviceProperties is not cheap and this runs every batch)
+  static int cu_cache[64] = {0};
+  int num_cus = (prm->device >= 0 && prm->device < 64) ? cu_cache[prm->device] : 0;
+  if (num_cus <= 0) {
+    NMOD_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, prm->device));
+    if (prm->device >= 0 && prm->device < 64) cu_cache[prm->device] = num_cus;
+  }
 
   int tests = prm->tests;
   if (want_comb) tests |= NMOD_TEST_KS;

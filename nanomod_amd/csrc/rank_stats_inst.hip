@@ -88,13 +88,20 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
     const int pw = ks ? ks_positions_per_wave(cls - kKsClassBase) : packed_positions_per_wave(cls - kNumGeneralClasses);
     work_items = (work_items + pw - 1) / pw;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  int per_cu = 0;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kWavesPerBlock, lds);
-  if (e != hipSuccess) return e;
-  if (per_cu < 1) per_cu = 1;
+  // the dynamic-LDS attribute and the occupancy of a kernel are looked up once per (device, class), not on every launch
+  static int per_cu_cache[16][kClassStride] = {{0}};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 15;      // (slot 15 is never trusted)
+  int per_cu = dev < 15 ? per_cu_cache[dev][cls] : 0;
+  if (per_cu <= 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kWavesPerBlock, lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    per_cu_cache[dev][cls] = per_cu;
+  }
   int64_t blocks = (work_items + kWavesPerBlock - 1) / kWavesPerBlock;
   int64_t cap = (int64_t)num_cus * per_cu;
   if (blocks > cap) blocks = cap;

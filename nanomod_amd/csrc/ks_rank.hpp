@@ -261,28 +261,33 @@ void ks_rank_kernel(RankStatsArgs args) {
     return d;
   };
   const float big = 3.4028234663852886e38f;
-  // one 16-byte load per lane: samples idx .. idx + 3 of a Q row when `have`, FLT_MAX otherwise.  The load is
+  // one 16-byte (f32) / 8-byte (i16) load per lane: samples idx .. idx + 3 of a Q row when `have`.  The load is
   // issued by EVERY lane (lanes without samples read a block of FLT_MAX): a load that only some paths issue
   // makes the number of outstanding loads unknown to the compiler, and every later wait becomes vmcnt(0).
-  auto load_q4 = [&](float (&xq)[4], const void* sig, int64_t off, int idx, bool have) {
+  // For the same reason the raw registers are converted only where they are used (q4_values), a round later.
+  using Q4Raw = typename std::conditional<DTYPE == 0, KsF4, KsS4>::type;
+  using Q1Raw = typename std::conditional<DTYPE == 0, float, int16_t>::type;
+  auto load_q4 = [&](const void* sig, int64_t off, int idx, bool have) -> Q4Raw {
+    using T = Q1Raw;
+    const T* src = have ? reinterpret_cast<const T*>(sig) + off + idx : reinterpret_cast<const T*>(kKsBig4);
+    return ks_global_load<Q4Raw>(src);
+  };
+  auto q4_values = [&](float (&xq)[4], const Q4Raw& t, bool have) {
     if constexpr (DTYPE == 0) {
-      const float* src = have ? reinterpret_cast<const float*>(sig) + off + idx : kKsBig4;
-      const KsF4 t = ks_global_load<KsF4>(src);
+      (void)have;                                   // the dummy block already holds FLT_MAX
       xq[0] = t.x; xq[1] = t.y; xq[2] = t.z; xq[3] = t.w;
     } else {
-      const int16_t* src = have ? reinterpret_cast<const int16_t*>(sig) + off + idx : reinterpret_cast<const int16_t*>(kKsBig4);
-      const KsS4 t = ks_global_load<KsS4>(src);
       xq[0] = have ? (float)t.x : big; xq[1] = have ? (float)t.y : big;
       xq[2] = have ? (float)t.z : big; xq[3] = have ? (float)t.w : big;
     }
   };
-  auto load_q1 = [&](const void* sig, int64_t off, int idx, bool have) {
-    if constexpr (DTYPE == 0) {
-      return ks_global_load<float>(have ? reinterpret_cast<const float*>(sig) + off + idx : kKsBig4);
-    } else {
-      const int16_t v = ks_global_load<int16_t>(have ? reinterpret_cast<const int16_t*>(sig) + off + idx : reinterpret_cast<const int16_t*>(kKsBig4));
-      return have ? (float)v : big;
-    }
+  auto load_q1 = [&](const void* sig, int64_t off, int idx, bool have) -> Q1Raw {
+    using T = Q1Raw;
+    return ks_global_load<T>(have ? reinterpret_cast<const T*>(sig) + off + idx : reinterpret_cast<const T*>(kKsBig4));
+  };
+  auto q1_value = [&](Q1Raw v, bool have) -> float {
+    if constexpr (DTYPE == 0) { (void)have; return v; }
+    else return have ? (float)v : big;
   };
 
   // Software pipeline: the S rows of the NEXT item are requested while this item's Q is ranked, and every
@@ -344,13 +349,8 @@ void ks_rank_kernel(RankStatsArgs args) {
     const Item nxt = describe(it + wave_stride);
     KsRows<R, LG, DTYPE> rows_next;
     rows_next.request(nxt.swap ? args.sig1 : args.sig0, nxt.off_s, nxt.m, gl);
-    float xa[4] = {big, big, big, big};          // the round being ranked next
-    float xt = big;                              // first one-per-lane round
-    if (!coop) {
-      load_q4(xa, sig_q, off_q, 4 * gl, 0 < full);
-      const int idx = full * (4 * LG) + gl;
-      xt = load_q1(sig_q, off_q, idx, idx < q);
-    }
+    Q4Raw ra = load_q4(sig_q, off_q, 4 * gl, !coop && 0 < full);              // the round being ranked next (raw)
+    Q1Raw rt = load_q1(sig_q, off_q, full * (4 * LG) + gl, !coop && full * (4 * LG) + gl < q);   // first one-per-lane round
 
 #if !(defined(NMOD_EXP) && (NMOD_EXP & 1))
     seg_sort_any<R, LG>(x, sel, lane);
@@ -428,21 +428,21 @@ void ks_rank_kernel(RankStatsArgs args) {
     if (!coop) {
 #pragma unroll 1
       for (int c = 0; c < full_w; ++c) {
-        float xb[4];
-        load_q4(xb, sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
+        const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
+        float xa[4];
+        q4_values(xa, ra, c < full);
 #if !(defined(NMOD_EXP) && (NMOD_EXP & 2))
         rank_and_count(std::integral_constant<int, 4>{}, keys, xa);
 #else
         if (xa[0] + xa[1] + xa[2] + xa[3] == 12345.f) atomicAdd(hist, 1u);
 #endif
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xa[e] = xb[e];
+        ra = rb;
       }
 #pragma unroll 1
       for (int c = 0; c < tail_w; ++c) {
-        float xq[1] = {xt};
+        float xq[1] = {q1_value(rt, full * (4 * LG) + c * LG + gl < q)};
         const int idx = full * (4 * LG) + (c + 1) * LG + gl;
-        xt = load_q1(sig_q, off_q, idx, idx < q);
+        rt = load_q1(sig_q, off_q, idx, idx < q);
         rank_and_count(std::integral_constant<int, 1>{}, keys, xq);
       }
     } else {
@@ -467,13 +467,13 @@ void ks_rank_kernel(RankStatsArgs args) {
         for (int c = 0; c < fs; ++c) {
           const int idx = c * 256 + 4 * lane;
           float xq[4];
-          load_q4(xq, sigs, offs, idx, true);
+          q4_values(xq, load_q4(sigs, offs, idx, true), true);
           rank_and_count(std::integral_constant<int, 4>{}, kb, xq);
         }
 #pragma unroll 1
         for (int c = 0; c < ts; ++c) {
           const int idx = fs * 256 + c * 64 + lane;
-          float xq[1] = {load_q1(sigs, offs, idx, idx < qs)};
+          float xq[1] = {q1_value(load_q1(sigs, offs, idx, idx < qs), idx < qs)};
           rank_and_count(std::integral_constant<int, 1>{}, kb, xq);
         }
       }

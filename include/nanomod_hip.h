@@ -29,8 +29,14 @@ extern "C" {
 /* sample dtype of sig0 / sig1 */
 enum {
   NMOD_DTYPE_F32 = 0,       /* canonical: float32 (values up-cast exactly to the fp64 the reference sees) */
-  NMOD_DTYPE_I16_MILLI = 1  /* int16 = round(norm_mean*1000): NanoMod's Events are 3-dp rounded
+  NMOD_DTYPE_I16_MILLI = 1, /* int16 = round(norm_mean*1000): NanoMod's Events are 3-dp rounded
                                (myRefBaseSignalAnnotation.py:1108); value = k/1000.0 in fp64 */
+  NMOD_DTYPE_F64 = 2        /* float64 as the reference holds it (lists of numpy.float64, myDetect.py:124).  The
+                               library re-encodes it on the device without changing a value the reference would
+                               see: float32 if every sample of the batch is float32-exact, else int16 milli-units
+                               if every sample is k/1000.0 with |k| <= 32767; anything else is
+                               NMOD_ERR_INVALID_ARG (a 64-bit-key path is not built).  One extra pass over the
+                               samples and one host round trip. */
 };
 
 /* where the caller's buffers live */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libnanomod_hip.so')
 
 NMOD_ABI_VERSION = 1
-DTYPE_F32, DTYPE_I16_MILLI = 0, 1
+DTYPE_F32, DTYPE_I16_MILLI, DTYPE_F64 = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 METHOD_KS, METHOD_STOUFFER, METHOD_FISHER = 0, 1, 2
 TEST_KS, TEST_MWU, TEST_WELCH, TEST_ALL = 1, 2, 4, 7

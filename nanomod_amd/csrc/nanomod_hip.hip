@@ -198,10 +198,33 @@ __global__ __launch_bounds__(256) void scatter_kernel(BinArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- float64 input (NMOD_DTYPE_F64)
+// flags[0] stays 1 while every sample is float32-exact, flags[1] while every sample is k/1000.0, |k| <= 32767
+__global__ __launch_bounds__(256) void f64_probe_kernel(const double* a, int64_t na, const double* b, int64_t nb, int32_t* flags) {
+  bool f32_ok = true, grid_ok = true;
+  const int64_t n = na + nb;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double v = i < na ? a[i] : b[i - na];
+    f32_ok = f32_ok && ((double)(float)v == v);
+    const double k = rint(v * 1000.0);
+    grid_ok = grid_ok && (fabs(k) <= 32767.0) && (k / 1000.0 == v);
+  }
+  if (__ballot(!f32_ok) != 0ull && (threadIdx.x & 63) == 0) atomicAnd(&flags[0], 0);
+  if (__ballot(!grid_ok) != 0ull && (threadIdx.x & 63) == 0) atomicAnd(&flags[1], 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void f64_encode_kernel(const double* in, int64_t n, T* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if constexpr (sizeof(T) == 4) out[i] = (T)in[i];
+    else out[i] = (T)rint(in[i] * 1000.0);
+  }
+}
+
 // ---------------------------------------------------------------- helpers
 static int check_params(const nmod_params* prm) {
   if (!prm || prm->struct_size != (int32_t)sizeof(nmod_params)) return NMOD_ERR_INVALID_ARG;
-  if (prm->dtype != NMOD_DTYPE_F32 && prm->dtype != NMOD_DTYPE_I16_MILLI) return NMOD_ERR_INVALID_ARG;
+  if (prm->dtype != NMOD_DTYPE_F32 && prm->dtype != NMOD_DTYPE_I16_MILLI && prm->dtype != NMOD_DTYPE_F64) return NMOD_ERR_INVALID_ARG;
   if (prm->memspace != NMOD_MEM_HOST && prm->memspace != NMOD_MEM_DEVICE) return NMOD_ERR_INVALID_ARG;
   if (prm->method < NMOD_METHOD_KS || prm->method > NMOD_METHOD_FISHER) return NMOD_ERR_INVALID_ARG;
   if (prm->nb < 0 || prm->nb > NMOD_MAX_NB) return NMOD_ERR_INVALID_ARG;
@@ -402,8 +425,10 @@ struct DevBuf {
   hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
 };
 
+// sig_on_device: the samples are already device-resident (the float64 front end), everything else is host memory
 static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, const int64_t* off0,
-                       const void* sig1, const int64_t* off1, const int32_t* run_id, nmod_out* out) {
+                       const void* sig1, const int64_t* off1, const int32_t* run_id, nmod_out* out,
+                       bool sig_on_device = false) {
   if (npos == 0) return NMOD_OK;
   if (!sig0 || !sig1 || !out) return NMOD_ERR_INVALID_ARG;
   if ((prm->stride0 <= 0 && !off0) || (prm->stride1 <= 0 && !off1)) return NMOD_ERR_INVALID_ARG;
@@ -421,10 +446,15 @@ static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, c
   dp.max_n0 = (int32_t)std::max<int64_t>(m0, 1); dp.max_n1 = (int32_t)std::max<int64_t>(m1, 1);
 
   DevBuf d_sig0, d_sig1, d_off0, d_off1, d_run, d_ws, d_out;
-  NMOD_HIP(d_sig0.alloc(tot0 * esz)); NMOD_HIP(d_sig1.alloc(tot1 * esz));
   const int64_t base0 = prm->stride0 > 0 ? 0 : off0[0], base1 = prm->stride1 > 0 ? 0 : off1[0];
-  NMOD_HIP(hipMemcpyAsync(d_sig0.p, (const char*)sig0 + base0 * esz, tot0 * esz, hipMemcpyHostToDevice, stream));
-  NMOD_HIP(hipMemcpyAsync(d_sig1.p, (const char*)sig1 + base1 * esz, tot1 * esz, hipMemcpyHostToDevice, stream));
+  const void* ds0 = (const char*)sig0 + base0 * esz;
+  const void* ds1 = (const char*)sig1 + base1 * esz;
+  if (!sig_on_device) {
+    NMOD_HIP(d_sig0.alloc(tot0 * esz)); NMOD_HIP(d_sig1.alloc(tot1 * esz));
+    NMOD_HIP(hipMemcpyAsync(d_sig0.p, ds0, tot0 * esz, hipMemcpyHostToDevice, stream));
+    NMOD_HIP(hipMemcpyAsync(d_sig1.p, ds1, tot1 * esz, hipMemcpyHostToDevice, stream));
+    ds0 = d_sig0.p; ds1 = d_sig1.p;
+  }
   std::vector<int64_t> r0, r1;             // offsets rebased to the staged copy
   if (prm->stride0 <= 0) {
     r0.resize(npos + 1); for (int64_t i = 0; i <= npos; ++i) r0[i] = off0[i] - base0;
@@ -451,7 +481,7 @@ static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, c
   for (int k = 0; k < 12; ++k) dpv[k] = hp[k] ? slab + (int64_t)k * npos : nullptr;
   dout.status = out->status ? (uint8_t*)(slab + 12 * npos) : nullptr;
 
-  int rc = detect_device(&dp, npos, d_sig0.p, (const int64_t*)d_off0.p, d_sig1.p, (const int64_t*)d_off1.p,
+  int rc = detect_device(&dp, npos, ds0, (const int64_t*)d_off0.p, ds1, (const int64_t*)d_off1.p,
                          (const int32_t*)d_run.p, d_ws.p, wsb, &dout);
   if (rc != NMOD_OK) { hipStreamSynchronize(stream); return rc; }
   const bool no_comb = prm->method == NMOD_METHOD_KS;
@@ -467,6 +497,77 @@ static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, c
   if (out->status) NMOD_HIP(hipMemcpyAsync(out->status, dout.status, npos, hipMemcpyDeviceToHost, stream));
   NMOD_HIP(hipStreamSynchronize(stream));
   return NMOD_OK;
+}
+
+// ---------------------------------------------------------------- float64 front end
+// Re-encodes float64 samples to the dtype the kernels sort (see NMOD_DTYPE_F64) and runs the batch on the result.
+static int detect_f64(const nmod_params* prm, int64_t npos, const void* sig0, const int64_t* off0,
+                      const void* sig1, const int64_t* off1, const int32_t* run_id, void* workspace,
+                      int64_t workspace_bytes, nmod_out* out) {
+  if (npos == 0) return NMOD_OK;
+  if (!sig0 || !sig1 || !out) return NMOD_ERR_INVALID_ARG;
+  if ((prm->stride0 <= 0 && !off0) || (prm->stride1 <= 0 && !off1)) return NMOD_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)prm->stream;
+  const bool host = prm->memspace == NMOD_MEM_HOST;
+  // sample counts and the first sample of each array (offsets need not start at 0)
+  int64_t b0 = 0, e0 = prm->stride0 * npos, b1 = 0, e1 = prm->stride1 * npos;
+  if (prm->stride0 <= 0) {
+    if (host) { b0 = off0[0]; e0 = off0[npos]; }
+    else { int64_t t[2]; NMOD_HIP(hipMemcpyAsync(&t[0], off0, 8, hipMemcpyDeviceToHost, stream));
+           NMOD_HIP(hipMemcpyAsync(&t[1], off0 + npos, 8, hipMemcpyDeviceToHost, stream)); NMOD_HIP(hipStreamSynchronize(stream)); b0 = t[0]; e0 = t[1]; }
+  }
+  if (prm->stride1 <= 0) {
+    if (host) { b1 = off1[0]; e1 = off1[npos]; }
+    else { int64_t t[2]; NMOD_HIP(hipMemcpyAsync(&t[0], off1, 8, hipMemcpyDeviceToHost, stream));
+           NMOD_HIP(hipMemcpyAsync(&t[1], off1 + npos, 8, hipMemcpyDeviceToHost, stream)); NMOD_HIP(hipStreamSynchronize(stream)); b1 = t[0]; e1 = t[1]; }
+  }
+  const int64_t n0 = e0 - b0, n1 = e1 - b1;
+  if (n0 < 0 || n1 < 0) return NMOD_ERR_INVALID_ARG;
+  DevBuf st0, st1, enc0, enc1, flg;
+  const double* d0 = (const double*)sig0 + b0;
+  const double* d1 = (const double*)sig1 + b1;
+  if (host) {
+    NMOD_HIP(st0.alloc((size_t)n0 * 8)); NMOD_HIP(st1.alloc((size_t)n1 * 8));
+    NMOD_HIP(hipMemcpyAsync(st0.p, d0, (size_t)n0 * 8, hipMemcpyHostToDevice, stream));
+    NMOD_HIP(hipMemcpyAsync(st1.p, d1, (size_t)n1 * 8, hipMemcpyHostToDevice, stream));
+    d0 = (const double*)st0.p; d1 = (const double*)st1.p;
+  }
+  NMOD_HIP(flg.alloc(8));
+  const int32_t ones[2] = {1, 1};
+  NMOD_HIP(hipMemcpyAsync(flg.p, ones, 8, hipMemcpyHostToDevice, stream));
+  const unsigned blocks = (unsigned)std::min<int64_t>((n0 + n1 + 255) / 256 + 1, 8192);
+  hipLaunchKernelGGL(f64_probe_kernel, dim3(blocks), dim3(256), 0, stream, d0, n0, d1, n1, (int32_t*)flg.p);
+  NMOD_HIP(hipGetLastError());
+  int32_t flags[2];
+  NMOD_HIP(hipMemcpyAsync(flags, flg.p, 8, hipMemcpyDeviceToHost, stream));
+  NMOD_HIP(hipStreamSynchronize(stream));
+  nmod_params ep = *prm;
+  if (flags[0]) ep.dtype = NMOD_DTYPE_F32;
+  else if (flags[1]) ep.dtype = NMOD_DTYPE_I16_MILLI;
+  else return NMOD_ERR_INVALID_ARG;                 // neither float32-exact nor on the 0.001 grid
+  const size_t esz = ep.dtype == NMOD_DTYPE_F32 ? 4 : 2;
+  NMOD_HIP(enc0.alloc((size_t)n0 * esz)); NMOD_HIP(enc1.alloc((size_t)n1 * esz));
+  const unsigned eb0 = (unsigned)std::min<int64_t>((n0 + 255) / 256 + 1, 8192), eb1 = (unsigned)std::min<int64_t>((n1 + 255) / 256 + 1, 8192);
+  if (ep.dtype == NMOD_DTYPE_F32) {
+    hipLaunchKernelGGL(f64_encode_kernel<float>, dim3(eb0), dim3(256), 0, stream, d0, n0, (float*)enc0.p);
+    hipLaunchKernelGGL(f64_encode_kernel<float>, dim3(eb1), dim3(256), 0, stream, d1, n1, (float*)enc1.p);
+  } else {
+    hipLaunchKernelGGL(f64_encode_kernel<int16_t>, dim3(eb0), dim3(256), 0, stream, d0, n0, (int16_t*)enc0.p);
+    hipLaunchKernelGGL(f64_encode_kernel<int16_t>, dim3(eb1), dim3(256), 0, stream, d1, n1, (int16_t*)enc1.p);
+  }
+  NMOD_HIP(hipGetLastError());
+  // the encoded arrays start at sample b0 / b1: present them through pointers shifted back by the first offset
+  const void* s0 = (const char*)enc0.p - (size_t)b0 * esz;
+  const void* s1 = (const char*)enc1.p - (size_t)b1 * esz;
+  int rc;
+  if (host) {
+    // offsets, run ids and outputs are still host buffers: stage them through the host path on device-resident samples
+    rc = detect_host(&ep, npos, s0, off0, s1, off1, run_id, out, true);
+  } else {
+    rc = detect_device(&ep, npos, s0, off0, s1, off1, run_id, workspace, workspace_bytes, out);
+  }
+  hipStreamSynchronize(stream);                      // the encoded buffers are freed on return
+  return rc;
 }
 
 // ---------------------------------------------------------------- self test kernels
@@ -578,6 +679,7 @@ int nmod_detect_batch(const nmod_params* prm, int64_t npos, const void* sig0, co
   if (npos < 0) return NMOD_ERR_INVALID_ARG;
   if (nmod_device_count() <= prm->device || prm->device < 0) return NMOD_ERR_NO_DEVICE;
   NMOD_HIP(hipSetDevice(prm->device));
+  if (prm->dtype == NMOD_DTYPE_F64) return detect_f64(prm, npos, sig0, off0, sig1, off1, run_id, workspace, workspace_bytes, out);
   if (prm->memspace == NMOD_MEM_DEVICE)
     return detect_device(prm, npos, sig0, off0, sig1, off1, run_id, workspace, workspace_bytes, out);
   return detect_host(prm, npos, sig0, off0, sig1, off1, run_id, out);

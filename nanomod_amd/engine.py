@@ -28,14 +28,15 @@ def detect_host(sig0, off0, sig1, off1, run_id, *, nb=2, weights_dif=2.0, method
                 tests=L.TEST_ALL, want_mstd=False, device=0, stride0=0, stride1=0):
     """Run the hot path on host-resident CSR inputs; returns a dict of numpy arrays.
 
-    sig0/sig1: float32 (canonical) or int16 (milli-units) 1-D arrays; off0/off1:
+    sig0/sig1: float32 (canonical), int16 (milli-units) or float64 1-D arrays; off0/off1:
     int64[npos+1] (or None with a fixed stride); run_id: int32[npos]."""
     lib = L.load()
     sig0 = np.ascontiguousarray(sig0)
     sig1 = np.ascontiguousarray(sig1)
-    if sig0.dtype != sig1.dtype or sig0.dtype not in (np.float32, np.int16):
-        raise ValueError('sig0/sig1 must both be float32 or both int16 (milli-units)')
-    dtype = L.DTYPE_F32 if sig0.dtype == np.float32 else L.DTYPE_I16_MILLI
+    if sig0.dtype != sig1.dtype or sig0.dtype not in (np.float32, np.int16, np.float64):
+        raise ValueError('sig0/sig1 must both be float32, both int16 (milli-units) or both float64')
+    # float64 (what the reference holds): the library re-encodes it on the device, NMOD_DTYPE_F64
+    dtype = {np.dtype(np.float32): L.DTYPE_F32, np.dtype(np.int16): L.DTYPE_I16_MILLI, np.dtype(np.float64): L.DTYPE_F64}[sig0.dtype]
     if off0 is not None:
         npos = len(off0) - 1
     elif off1 is not None:
@@ -159,7 +160,9 @@ class DeviceDetector:
             return L.DTYPE_F32
         if t.dtype == torch.int16:
             return L.DTYPE_I16_MILLI
-        raise ValueError('signals must be float32 or int16 (milli-units)')
+        if t.dtype == torch.float64:
+            return L.DTYPE_F64
+        raise ValueError('signals must be float32, int16 (milli-units) or float64')
 
     def workspace(self, prm, npos):
         need = self.lib.nmod_workspace_bytes(C.byref(prm), npos)

@@ -494,3 +494,46 @@ def test_welch_p_value_grid(nm):
     H.assert_close_stat(got['t_t'], exp['t_t'], 1e-11, 1e-15, 't_t')
     H.assert_close_p(got['t_p'], exp['t_p'], 1e-9, 't_p')
     assert (exp['t_p'] < 1e-200).any() and (exp['t_p'] > 0.5).any()
+
+
+def test_float64_input_dtype(nm):
+    """NMOD_DTYPE_F64: float64 samples as the reference holds them are re-encoded on the device — float32 when every
+    value is float32-exact, int16 milli-units when every value is k/1000, NMOD_ERR_INVALID_ARG otherwise — in host
+    and device memory, CSR with a non-zero first offset and fixed stride"""
+    import torch
+    import nanomod_oracle as orc
+    L = nm._lib
+    rng = np.random.default_rng(11)
+    npos = 70
+    n0 = rng.integers(3, 300, npos); n1 = rng.integers(3, 300, npos)
+    pad = 5                                                            # the CSR arrays start at sample 5
+    off0 = np.zeros(npos + 1, np.int64); off0[1:] = np.cumsum(n0); off0 += pad
+    off1 = np.zeros(npos + 1, np.int64); off1[1:] = np.cumsum(n1); off1 += pad
+    rid = (np.arange(npos) // 9).astype(np.int32)
+    a32 = rng.normal(0, 1, off0[-1]).astype(np.float32); b32 = rng.normal(0.2, 1, off1[-1]).astype(np.float32)
+    a3 = np.round(rng.normal(0, 1, off0[-1]), 3); b3 = np.round(rng.normal(0.2, 1, off1[-1]), 3)
+    for a, b, same_as in ((a32.astype(np.float64), b32.astype(np.float64), (a32, b32)),
+                          (a3, b3, (np.rint(a3 * 1000).astype(np.int16), np.rint(b3 * 1000).astype(np.int16)))):
+        got = nm.detect_host(a, off0, b, off1, rid, nb=2, weights_dif=2.0, method='stouffer')
+        ref = nm.detect_host(same_as[0], off0, same_as[1], off1, rid, nb=2, weights_dif=2.0, method='stouffer')
+        for k in ref:
+            assert np.array_equal(got[k], ref[k], equal_nan=True), k
+        exp = orc.detect_batch(a[pad:], off0 - pad, b[pad:], off1 - pad, rid, 2, 2.0, orc.METHOD_STOUFFER)
+        H.compare_outputs(got, exp, True)
+        # device-resident float64 tensors through the same entry point
+        det = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer')
+        r = det.run(torch.as_tensor(a, device='cuda:0'), torch.as_tensor(b, device='cuda:0'), torch.as_tensor(rid, device='cuda:0'),
+                    off0=torch.as_tensor(off0, device='cuda:0'), off1=torch.as_tensor(off1, device='cuda:0'))
+        torch.cuda.synchronize()
+        for k in ('ks_p', 'mwu_p', 't_p', 'comb_p'):
+            assert np.array_equal(r[k].cpu().numpy(), ref[k], equal_nan=True), k
+    # fixed stride, KS-only
+    s0 = np.round(rng.normal(0, 1, 40 * 50), 3); s1 = np.round(rng.normal(0, 1, 40 * 60), 3)
+    g = nm.detect_host(s0, None, s1, None, np.zeros(40, np.int32), stride0=50, stride1=60, tests=L.TEST_KS, method='ks')
+    r = nm.detect_host(np.rint(s0 * 1000).astype(np.int16), None, np.rint(s1 * 1000).astype(np.int16), None, np.zeros(40, np.int32),
+                       stride0=50, stride1=60, tests=L.TEST_KS, method='ks')
+    assert np.array_equal(g['ks_p'], r['ks_p'])
+    # neither float32-exact nor on the grid
+    bad = rng.normal(0, 1, off0[-1])
+    with pytest.raises(L.NanomodLibraryError, match='invalid argument'):
+        nm.detect_host(bad, off0, b3, off1, rid)

@@ -118,7 +118,11 @@ int64_t nmod_workspace_bytes(const nmod_params* prm, int64_t npos);
 /* Replaces the two hot loops of mtest2 (myDetect.py:427-436 per-position
  * getKStest, :443 combin_pvalues).  NMOD_MEM_DEVICE: all pointers are device
  * pointers, `workspace` must hold nmod_workspace_bytes(), everything is
- * enqueued on prm->stream and the call returns without synchronising.
+ * enqueued on prm->stream and the call returns without synchronising — except
+ * for one host round trip each when (i) max_n0 / max_n1 are unknown for CSR
+ * inputs, (ii) the maxima allow groups beyond NMOD_MAX_GROUP (the scratch of the
+ * large-position pass is sized from the classifier's totals and allocated
+ * stream-ordered), (iii) dtype is NMOD_DTYPE_F64 (the probe's verdict).
  * NMOD_MEM_HOST: pointers are host memory; the library stages through device
  * memory it allocates and frees inside the call (workspace may be NULL) and
  * returns after the results are back. */

@@ -2,8 +2,8 @@
 //
 // ks_2samp (myDetect.py:341 -> scipy 1.2.1) needs D = max_v |F0(v) - F1(v)| over the pooled points.
 // D is symmetric in the two groups, so call the smaller one S (m samples) and the other Q (q samples):
-//   1. S is sorted in registers exactly like the packed kernel (R registers x LG lanes, bitonic
-//      network, DPP + v_med3 across lanes) and written to wave-private LDS;
+//   1. S is sorted in registers (R registers x LG lanes, rank_stats_packed.hpp: bitonic network, DPP +
+//      v_med3 across lanes) and written to wave-private LDS;
 //   2. every sample x of Q finds L(x) = #{s < x} by a branchless 1+log2(C)-step binary search in LDS
 //      and, only when x ties with an S value, U(x) = #{s <= x} by a second search;
 //   3. one ds_add_u32 per sample builds the histograms of L and U (two 16-bit halves of a word);
@@ -15,8 +15,8 @@
 //      is the exact integer max|c0*n1 - c1*n0| over the pooled points.
 //      Without ties cumL == cumU and the maximum collapses to max_{k<m} max(a_k, q - a_k),
 //      a_k = cumU(k)*m - k*q: five VALU instructions per histogram bin.
-// Against the two-sort + merge-path form this removes one sort and the whole sequential merge:
-// ~300 instead of ~500 VALU instructions per 200 v 200 position (rocprof SQ_INSTS_VALU).
+// Against sorting both groups and walking the pooled sample this removes one sort and the whole sequential
+// merge: ~400 instead of ~500 VALU instructions per 200 v 200 position (rocprof SQ_INSTS_VALU).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -389,7 +389,7 @@ void ks_rank_kernel(RankStatsArgs args) {
 #pragma unroll
       for (int e = 0; e < NV; ++e) lp[e] = ks_search<R, LG, false>(kbase, xq[e], &lcol[e]);
 #pragma unroll
-      for (int e = 0; e < NV; ++e) tie_here = tie_here || (*lp[e] == xq[e]);      // keys[skew(C)] is +inf
+      for (int e = 0; e < NV; ++e) tie_here = tie_here || (*lp[e] == xq[e]);      // key C is +inf
       if (__ballot(tie_here) != 0ull) {          // ties with S: common for 3-dp rounded signals and the synthetic grid
         any_tie = true;
         // a tied sample almost always ties with ONE key: U = L + 1 (the next row of the column, or row 0 of the

@@ -170,6 +170,14 @@ int nmod_write_sign_test(const char* path, int64_t npos, const int32_t* chrom_id
                          const double* t_t, const double* t_p, const double* ks_d, const double* ks_p,
                          const double* comb_st, const double* comb_p, int32_t with_comb);
 
+/* Replaces the ranking of the result records (myDetect.py:447-462): order_out[i] = index of the i-th record of
+ * sorted(records, key = (key_primary, key_second, key_third)) — Python's stable tuple sort, ascending, -0.0 tied
+ * with 0.0, NaN last — reversed as a whole when `descending` (rankUse == 'st': the reference reverses the sorted
+ * list).  The reference's keys are (combined p, KS p, MWU p) or the three statistics.  Device radix sort (rocPRIM),
+ * three stable passes; synchronises before returning. */
+int nmod_rank_order(const nmod_params* prm, int64_t npos, const double* key_primary, const double* key_second,
+                    const double* key_third, int32_t descending, int32_t* order_out);
+
 /* Lane-permutation self test of the wave primitives the sort is built from
  * (runs tiny kernels; returns NMOD_OK or the number of the first failing primitive). */
 int nmod_selftest(int32_t device);

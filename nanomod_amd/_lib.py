@@ -65,6 +65,7 @@ _SIGNATURES = {
     'nmod_selftest': (C.c_int, [C.c_int32]),
     'nmod_write_sign_test': (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_void_p,
                                        C.c_char_p] + [C.c_void_p] * 10 + [C.c_int32]),
+    'nmod_rank_order': (C.c_int, [C.POINTER(NmodParams), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 
 

@@ -149,7 +149,7 @@ def run_detect(a, log=print):
                     mw.write('%s %s %d %s %.3f %.3f %.3f %.3f\n' % (chrom[i], strand[i], pos[i], base[i], res['mean0'][i],
                                                                     res['std0'][i], res['mean1'][i], res['std1'][i]))
     if a.RegionRankbyST == 0:
-        order = rank_order(res, method, a.rankUse)
+        order = rank_order(res, method, a.rankUse, a.device)
     else:                                                                              # myDetect.py:463-515
         recs = []
         for i in range(npos):
@@ -163,13 +163,12 @@ def run_detect(a, log=print):
     return meta, res, order
 
 
-def rank_order(res, method, rank_use):
+def rank_order(res, method, rank_use, device=0):
     """myDetect.py:447-462: stable ascending sort by (combined, KS, MWU) p-value (or statistic, reversed)."""
     pind = 'p' if rank_use == 'pv' else 'st'
     first = ('comb_p' if pind == 'p' else 'comb_st') if method != 'ks' else ('ks_p' if pind == 'p' else 'ks_d')
-    keys = (res['mwu_p' if pind == 'p' else 'mwu_u'], res['ks_p' if pind == 'p' else 'ks_d'], res[first])
-    order = np.lexsort(keys)                       # last key is the primary one; lexsort is stable
-    return order[::-1] if rank_use == 'st' else order
+    return engine.rank_order_host(res[first], res['ks_p' if pind == 'p' else 'ks_d'], res['mwu_p' if pind == 'p' else 'mwu_u'],
+                                  descending=(rank_use == 'st'), device=device)
 
 
 def write_sign_test(path, meta, res, with_comb):

@@ -331,10 +331,17 @@ def mtest2(moptions):
     if method != 'ks' and nb < 0:
         raise IndexError('list index out of range')            # the reference indexes mpv[1][3] here
     if moptions.get('RegionRankbyST', 0) == 0:
-        moptions['sorted_sign_test'] = sorted(
-            sign_test, key=lambda mpv: (mpv[1][sorted_ind][use_pind], mpv[1][2][use_pind], mpv[1][0][use_pind]))
-        if use_pind == 0:
-            moptions['sorted_sign_test'] = moptions['sorted_sign_test'][::-1]
+        # sorted(sign_test, key=(record[sorted_ind], record[2], record[0])[use_pind]), reversed for 'st': the device
+        # ranking returns exactly that order (stable, -0.0 == 0.0), the records are only permuted here
+        ks_key = res['ks_p'] if use_pind else res['ks_d']
+        mw_key = res['mwu_p'] if use_pind else res['mwu_u']
+        first = ks_key if (method == 'ks' or nb == 0) else res['comb_p' if use_pind else 'comb_st']
+        if len(sign_test):
+            order = engine.rank_order_host(first, ks_key, mw_key, descending=(use_pind == 0),
+                                           device=moptions.get('nmod_device', 0))
+            moptions['sorted_sign_test'] = [sign_test[i] for i in order.tolist()]
+        else:
+            moptions['sorted_sign_test'] = []
     else:
         moptions['sorted_sign_test'] = region_rank(moptions, sorted_ind, use_pind)
 

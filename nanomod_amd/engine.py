@@ -95,6 +95,19 @@ def combine_host(ks_d, ks_p, run_id, *, nb=2, weights_dif=2.0, method='stouffer'
     return st, pv
 
 
+def rank_order_host(key_primary, key_second, key_third, descending=False, device=0):
+    """myDetect.py:447-462 on the device: the order of Python's stable sorted() by the tuple
+    (key_primary, key_second, key_third), reversed as a whole when `descending` (rankUse == 'st')."""
+    lib = L.load()
+    ks = [np.ascontiguousarray(k, dtype=np.float64) for k in (key_primary, key_second, key_third)]
+    n = ks[0].shape[0]
+    order = np.empty(n, dtype=np.int32)
+    prm = L.make_params(device=device, memspace=L.MEM_HOST)
+    rc = lib.nmod_rank_order(C.byref(prm), n, _np_ptr(ks[0]), _np_ptr(ks[1]), _np_ptr(ks[2]), 1 if descending else 0, _np_ptr(order))
+    L.check(rc, 'nmod_rank_order')
+    return order
+
+
 class EventTimer:
     """HIP-event timer handle (nmod_evtimer_*): per-kernel elapsed ms measured on the launch stream."""
 

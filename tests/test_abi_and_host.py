@@ -157,8 +157,6 @@ def test_cli_position_selection_and_table_writer_cpu():
             out = os.path.join(tmp, 't.txt')
             cli.write_sign_test(out, meta, exp, True)
             assert open(out).read() == table
-            order = cli.rank_order(exp, 'stouffer', 'pv')
-            assert np.array_equal(order, exp['sorted_index'])
 
 
 def test_cli_argument_validation():

@@ -537,3 +537,28 @@ def test_float64_input_dtype(nm):
     bad = rng.normal(0, 1, off0[-1])
     with pytest.raises(L.NanomodLibraryError, match='invalid argument'):
         nm.detect_host(bad, off0, b3, off1, rid)
+
+
+def test_rank_order_entry_point(nm):
+    """nmod_rank_order against Python's stable tuple sort: heavy ties in every key, -0.0 / 0.0, the reversed 'st' form"""
+    rng = np.random.default_rng(4)
+    n = 20000
+    k1 = np.round(rng.normal(0, 1, n), 1); k2 = np.round(rng.normal(0, 1, n), 0); k3 = rng.normal(0, 1, n)
+    k1[::7] = 0.0; k1[3::7] = -0.0
+    k3[::5] = 1e-300; k3[1::5] = 2.2250738585072014e-308
+    recs = list(zip(k1.tolist(), k2.tolist(), k3.tolist(), range(n)))
+    exp = [r[3] for r in sorted(recs, key=lambda r: (r[0], r[1], r[2]))]
+    got = nm.engine.rank_order_host(k1, k2, k3)
+    assert got.tolist() == exp
+    assert nm.engine.rank_order_host(k1, k2, k3, descending=True).tolist() == exp[::-1]
+    assert nm.engine.rank_order_host(k1[:1], k2[:1], k3[:1]).tolist() == [0]
+    assert nm.engine.rank_order_host(k1[:0], k2[:0], k3[:0]).tolist() == []
+
+
+@pytest.mark.parametrize('name', ['g50_stouffer', 'ragged_stouffer'])
+def test_rank_order_matches_reference_ranking(nm, name):
+    """the device ranking reproduces the reference's sorted_sign_test order on the golden numbers"""
+    from nanomod_amd import cli
+    exp, _ = H.load_expected(name)
+    order = cli.rank_order(exp, 'stouffer', 'pv')
+    assert np.array_equal(order, exp['sorted_index'])

@@ -178,6 +178,16 @@ int nmod_write_sign_test(const char* path, int64_t npos, const int32_t* chrom_id
 int nmod_rank_order(const nmod_params* prm, int64_t npos, const double* key_primary, const double* key_second,
                     const double* key_third, int32_t descending, int32_t* order_out);
 
+/* Replaces the window ranking of --RegionRankbyST 1 (myDetect.py:463-515) on array-shaped records in the
+ * reference's record order (sorted (chrom, strand), ascending position).  strand_lo[i] / strand_hi[i]: index of the
+ * first / last record of record i's (chrom, strand); value[i]: the p-value or statistic the ranking uses
+ * (record[sorted_ind][use_pind]); w: the window half-width AFTER the reference's in-place increment (window + 1);
+ * movesize: 1 when WindOvlp == 1, else w; na: base filter ('\0' = none).  Writes the indices of the ranked window
+ * centres to ranked_out (capacity npos) and their number to *n_ranked.  Host memory only; synchronises. */
+int nmod_region_rank(const nmod_params* prm, int64_t npos, const int32_t* strand_lo, const int32_t* strand_hi,
+                     const int64_t* pos, const char* base, const double* value, int32_t w, int32_t movesize,
+                     char na, double percentile, int32_t wind_ovlp, int32_t* ranked_out, int64_t* n_ranked);
+
 /* Lane-permutation self test of the wave primitives the sort is built from
  * (runs tiny kernels; returns NMOD_OK or the number of the first failing primitive). */
 int nmod_selftest(int32_t device);

@@ -66,6 +66,8 @@ _SIGNATURES = {
     'nmod_write_sign_test': (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_void_p,
                                        C.c_char_p] + [C.c_void_p] * 10 + [C.c_int32]),
     'nmod_rank_order': (C.c_int, [C.POINTER(NmodParams), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'nmod_region_rank': (C.c_int, [C.POINTER(NmodParams), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p,
+                                   C.c_int32, C.c_int32, C.c_char, C.c_double, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
 

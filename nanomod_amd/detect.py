@@ -212,52 +212,29 @@ def region_rank(moptions, sorted_ind, use_pind):
     the distance of the window minimum from the centre.  Only bases equal to moptions['NA'] contribute
     when that option is set; windows with <= 5 contributing values are dropped.  With WindOvlp == 1 the
     windows slide by one position and a window is suppressed when a better-ranked one on the same strand
-    lies closer than w.  Host-side: the p-value track comes from the GPU, this is a few passes over it."""
+    lies closer than w.  The window keys and the ranking run on the device (nmod_region_rank); the records must
+    be in the reference's order (sorted (chrom, strand), ascending position), which is how mtest2 builds them."""
     moptions['window'] = moptions['window'] + 1
     w = moptions['window']
     movesize = 1 if moptions['WindOvlp'] == 1 else w
-    na = moptions.get('NA', '')
-    pct = moptions['percentile']
-    by_strand = {}
-    order = []
-    for rec in moptions['sign_test']:
-        sk = (rec[0][0], rec[0][1])
-        if sk not in by_strand:
-            by_strand[sk] = {}
-            order.append(sk)
-        by_strand[sk][rec[0][2]] = rec
-    windseg = []
-    for sk in sorted(by_strand.keys()):
-        d = by_strand[sk]
-        pmax = None
-        for rec in moptions['sign_test']:           # the reference keeps the LAST position seen (= the largest: sorted input)
-            if (rec[0][0], rec[0][1]) == sk:
-                pmax = rec[0][2]
-        pmin = min(d.keys())
-        for pk in range(pmin, pmax, movesize):
-            vals = []
-            complete = True
-            for wind in range(-w, w + 1):
-                cur = pk + wind
-                if cur < 0 or cur >= pmax or cur not in d:
-                    complete = False
-                    break
-                rec = d[cur]
-                if (not na) or na == rec[0][3]:
-                    vals.append(rec[1][sorted_ind][use_pind])
-            if complete and len(vals) > 5:
-                windseg.append((d[pk], sorted(vals), vals))
-    windseg.sort(key=lambda ws: (ws[1][int(pct * (len(ws[1]) - 1) + 0.5)], abs(w - ws[2].index(ws[1][0]))))
-    ranked = []
-    kept = []
-    for ws in windseg:
-        key = ws[0][0]
-        if moptions['WindOvlp'] == 1:
-            if any(k[0] == key[0] and k[1] == key[1] and abs(k[2] - key[2]) < w for k in kept):
-                continue
-            kept.append(key)
-        ranked.append(ws[0])
-    return ranked
+    recs = moptions['sign_test']
+    n = len(recs)
+    if n == 0:
+        return []
+    keys = [(r[0][0], r[0][1]) for r in recs]
+    pos = np.fromiter((r[0][2] for r in recs), dtype=np.int64, count=n)
+    rank_of = {k: i for i, k in enumerate(sorted(set(keys)))}
+    sid = np.fromiter((rank_of[k] for k in keys), dtype=np.int64, count=n)
+    if np.any(np.diff(sid) < 0) or np.any((np.diff(sid) == 0) & (np.diff(pos) <= 0)):
+        raise ValueError('region_rank: sign_test must be ordered by (chrom, strand) and ascending position')
+    starts = np.flatnonzero(np.r_[True, np.diff(sid) != 0])
+    ends = np.r_[starts[1:], n] - 1
+    seg = np.searchsorted(starts, np.arange(n), side='right') - 1
+    value = np.fromiter((r[1][sorted_ind][use_pind] for r in recs), dtype=np.float64, count=n)
+    base = ''.join((r[0][3][:1] or ' ') for r in recs).encode('latin-1')
+    idx = engine.region_rank_host(starts[seg], ends[seg], pos, base, value, w, movesize, moptions.get('NA', ''),
+                                  moptions['percentile'], moptions['WindOvlp'], device=moptions.get('nmod_device', 0))
+    return [recs[i] for i in idx.tolist()]
 
 
 # myDetect.py:416-462

@@ -108,6 +108,23 @@ def rank_order_host(key_primary, key_second, key_third, descending=False, device
     return order
 
 
+def region_rank_host(strand_lo, strand_hi, pos, base, value, w, movesize, na, percentile, wind_ovlp, device=0):
+    """myDetect.py:463-515 on array-shaped records (see nmod_region_rank): indices of the ranked window centres."""
+    lib = L.load()
+    n = len(pos)
+    lo = np.ascontiguousarray(strand_lo, dtype=np.int32); hi = np.ascontiguousarray(strand_hi, dtype=np.int32)
+    pos = np.ascontiguousarray(pos, dtype=np.int64); value = np.ascontiguousarray(value, dtype=np.float64)
+    base = bytes(base)
+    assert len(base) == n
+    out = np.empty(n, dtype=np.int32)
+    cnt = C.c_int64(0)
+    prm = L.make_params(device=device, memspace=L.MEM_HOST)
+    rc = lib.nmod_region_rank(C.byref(prm), n, _np_ptr(lo), _np_ptr(hi), _np_ptr(pos), base, _np_ptr(value), int(w), int(movesize),
+                              (na or '\0').encode()[:1], float(percentile), int(wind_ovlp), _np_ptr(out), C.byref(cnt))
+    L.check(rc, 'nmod_region_rank')
+    return out[:cnt.value]
+
+
 class EventTimer:
     """HIP-event timer handle (nmod_evtimer_*): per-kernel elapsed ms measured on the launch stream."""
 

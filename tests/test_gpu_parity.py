@@ -562,3 +562,26 @@ def test_rank_order_matches_reference_ranking(nm, name):
     exp, _ = H.load_expected(name)
     order = cli.rank_order(exp, 'stouffer', 'pv')
     assert np.array_equal(order, exp['sorted_index'])
+
+
+@pytest.mark.parametrize('tag', ['w10_o0', 'w10_o1', 'w3_o1_A', 'w5_o0_ks', 'w4_o1_st'])
+def test_region_rank_matches_reference(nm, tag):
+    """RegionRankbyST=1 (myDetect.py:463-515) on the reference's own per-position numbers (golden): same ranked
+    window centres in the same order (window keys and ranking on the device, nmod_region_rank)"""
+    import nanomod_amd.detect as D
+    z = np.load(os.path.join(H.GOLDEN, 'g50_regionrank_%s.npz' % tag))
+    method = str(z['method'])
+    exp, _ = H.load_expected('g50_' + method)
+    recs = []
+    for i in range(len(exp['pos'])):
+        tests = [(exp['mwu_u'][i], exp['mwu_p'][i]), (exp['t_t'][i], exp['t_p'][i]), (exp['ks_d'][i], exp['ks_p'][i])]
+        if method != 'ks':
+            tests.append((exp['comb_st'][i], exp['comb_p'][i]))
+        recs.append(((str(exp['chrom'][i]), str(exp['strand'][i]), int(exp['pos'][i]), str(exp['base'][i]),
+                      int(exp['n0'][i]), int(exp['n1'][i])), tests))
+    mo = {'sign_test': recs, 'window': int(z['window']), 'WindOvlp': int(z['WindOvlp']), 'percentile': float(z['percentile']),
+          'NA': str(z['NA'])}
+    ranked = D.region_rank(mo, 2 if method == 'ks' else 3, 1 if str(z['rankUse']) == 'pv' else 0)
+    assert mo['window'] == int(z['window_after'])
+    assert [r[0][2] for r in ranked] == list(z['pos'])
+    assert [r[0][3] for r in ranked] == list(z['base'])

@@ -43,6 +43,9 @@ def build_parser():
     d.add_argument('--percentile', type=float, default=0.1)                            # NanoMod.py:364
     d.add_argument('--WindOvlp', type=int, default=0, choices=[0, 1])                  # NanoMod.py:365
     d.add_argument('--NA', type=str, default='', choices=['', 'A', 'C', 'G', 'T'])     # NanoMod.py:366
+    d.add_argument('--Pos', default='', help="region of interest chr:pos[:pos2] (1-based)")        # NanoMod.py:377
+    d.add_argument('--plotType', default='Density', choices=['Violin', 'Density'],
+                   help='accepted for compatibility: the R plots are outside this build')  # NanoMod.py:385
     d.add_argument('--downsampling_quantile', type=float, default=0.25)                # NanoMod.py:389
     d.add_argument('--downsampling', type=int, default=100)                            # NanoMod.py:390
     d.add_argument('--coverages', type=str, default='0-0')                             # NanoMod.py:392
@@ -67,6 +70,24 @@ def validate(a):
     if (a.window - 1) // 2 < 1:                                                        # NanoMod.py:51-53
         errs.append('Window size (%d) is too small' % a.window)
     a.percentile = 0.0 if a.percentile < 0 else (0.99 if a.percentile >= 1 else a.percentile)   # NanoMod.py:91-92
+    a.roi = {}                                                                         # NanoMod.py:117-129
+    if a.Pos != '':
+        mpos = a.Pos.split(':')
+        a.roi['Chr'] = mpos[0]
+        if len(mpos) > 1:
+            a.roi['Pos'] = int(mpos[1]) - 1
+            if a.roi['Pos'] < 0:
+                errs.append('The position (%d) of interest should not be less than 0' % a.roi['Pos'])
+        if len(mpos) > 2:
+            a.roi['Pos2'] = int(mpos[2]) - 1
+            if a.roi['Pos2'] < 0:
+                errs.append('The position (%d) of interest should not be less than 0' % a.roi['Pos2'])
+            if a.roi['Pos2'] - a.roi['Pos'] < 1:
+                errs.append('The end position (%d) is not larger than the start position (%d)' % (a.roi['Pos2'], a.roi['Pos']))
+        if 'Pos' in a.roi and 'Pos2' not in a.roi:                                     # myDetect.py:550-558
+            neighbors = (a.window - 1) // 2
+            a.roi['start_pos'] = max(a.roi['Pos'] - neighbors, 0)
+            a.roi['end_pos'] = a.roi['Pos'] + neighbors
     for f in (a.wrkBase1, a.wrkBase2):
         if not (os.path.isfile(f) or os.path.isdir(f)):
             errs.append('Error: input %s does not exist' % f)
@@ -111,8 +132,21 @@ def load_input(path, a, log=print):
     """A `.npz` container, or a folder of resquiggled FAST5 files read like ReadAllFast5 (myDetect.py:547-633)."""
     if os.path.isdir(path):
         from . import fast5_ingest
-        return fast5_ingest.ingest_folder(path, {'min_lr': a.min_lr, 'min_lr_nb': a.min_lr_nb}, log=log)
-    return container.load_group(path)
+        opts = {'min_lr': a.min_lr, 'min_lr_nb': a.min_lr_nb}
+        opts.update(getattr(a, 'roi', {}))                                              # read- and event-level filters
+        return fast5_ingest.ingest_folder(path, opts, log=log)
+    g = container.load_group(path)
+    roi = getattr(a, 'roi', {})
+    if roi:
+        # a container holds aggregated positions: only the position-level part of the region filter applies
+        # (myDetect.py:72,112-114); the read-level parts need the reads (FAST5 folders)
+        keep = g['chrom'] == roi['Chr']
+        if 'start_pos' in roi:
+            keep &= (g['pos'] >= roi['start_pos']) & (g['pos'] <= roi['end_pos'])
+        rows = np.flatnonzero(keep)
+        sig, off = container.gather_rows(g['sig'], g['off'], rows)
+        g = dict(chrom=g['chrom'][rows], strand=g['strand'][rows], pos=g['pos'][rows], base=g['base'][rows], off=off, sig=sig)
+    return g
 
 
 def run_detect(a, log=print):

@@ -161,11 +161,29 @@ def test_cli_position_selection_and_table_writer_cpu():
 
 def test_cli_argument_validation():
     from nanomod_amd import cli
+    from nanomod_amd import container as container_mod
     a = cli.build_parser().parse_args(['detect', '--wrkBase1', '/nonexistent1', '--wrkBase2', '/nonexistent2',
                                        '--MinCoverage', '2', '--WeightsDif', '0.5'])
     errs = cli.validate(a)
     assert any('MinCoverage' in e for e in errs) and sum('does not exist' in e for e in errs) == 2
     assert a.WeightsDif == 1.0                      # floor, NanoMod.py:76-78
+    # --Pos chr:pos (NanoMod.py:117-129, myDetect.py:550-558): 0-based position, +-(window-1)/2 region; --plotType accepted
+    a = cli.build_parser().parse_args(['detect', '--wrkBase1', 'x', '--wrkBase2', 'y', '--Pos', 'chrA:100', '--window', '21',
+                                       '--plotType', 'Violin'])
+    cli.validate(a)
+    assert a.roi == {'Chr': 'chrA', 'Pos': 99, 'start_pos': 89, 'end_pos': 109}
+    a = cli.build_parser().parse_args(['detect', '--wrkBase1', 'x', '--wrkBase2', 'y', '--Pos', 'chrA:100:90'])
+    assert any('not larger than the start' in e for e in cli.validate(a))
+    # the position-level part of the filter on a container
+    with tempfile.TemporaryDirectory() as tmp:
+        p0, _ = _fixture_containers('g50', tmp)
+        g = container_mod.load_group(p0)
+        a = cli.build_parser().parse_args(['detect', '--wrkBase1', p0, '--wrkBase2', p0, '--Pos', '%s:%d' % (g['chrom'][0], g['pos'][3] + 1),
+                                           '--window', '5'])
+        cli.validate(a)
+        sub = cli.load_input(p0, a)
+        assert set(sub['chrom']) == {g['chrom'][0]} and sub['pos'].min() >= g['pos'][3] - 2 and sub['pos'].max() <= g['pos'][3] + 2
+        assert sub['off'][-1] == len(sub['sig']) and len(sub['pos']) > 0
 
 
 def test_fast5_ingest_matches_reference_reader():

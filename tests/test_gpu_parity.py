@@ -585,3 +585,31 @@ def test_region_rank_matches_reference(nm, tag):
     assert mo['window'] == int(z['window_after'])
     assert [r[0][2] for r in ranked] == list(z['pos'])
     assert [r[0][3] for r in ranked] == list(z['base'])
+
+
+def test_full_size_properties(nm):
+    """BASELINE.json's full size (4.6 M positions x 200 v 200) through size-independent properties: swapping the groups
+    leaves D, U and every p-value unchanged and negates t; KS-only and all-tests mode agree on D to one rounding; the
+    planted positions (and only a handful of others) reach the combined p-value the plant implies"""
+    import torch
+    L = nm._lib
+    P, n = 4_600_000, 200
+    dev = 'cuda:0'
+    a = torch.empty(P * n, dtype=torch.float32, device=dev); b = torch.empty(P * n, dtype=torch.float32, device=dev)
+    det = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_ALL)
+    det.synth_fill(a, 7, 0, P, 0, n, 10000, 0.8); det.synth_fill(b, 7, 0, P, 1, n, 10000, 0.8)
+    rid = torch.zeros(P, dtype=torch.int32, device=dev)
+    r1 = {k: v.clone() for k, v in det.run(a, b, rid, stride0=n, stride1=n, npos=P).items()}
+    r2 = det.run(b, a, rid, stride0=n, stride1=n, npos=P)
+    torch.cuda.synchronize()
+    for k in ('ks_d', 'ks_p', 'mwu_u', 'mwu_p', 't_p', 'comb_p', 'comb_st'):
+        assert torch.equal(r1[k], r2[k]), k
+    assert torch.equal(r1['t_t'], -r2['t_t'])
+    assert int(r1['status'].max().item()) == 0
+    ks = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS).run(a, b, rid, stride0=n, stride1=n, npos=P)
+    torch.cuda.synchronize()
+    assert float((ks['ks_d'] - r1['ks_d']).abs().max().item()) <= 2.3e-16
+    assert float(((ks['comb_p'] - r1['comb_p']).abs() / r1['comb_p']).max().item()) <= 1e-9
+    planted = torch.arange(10000, P, 10000, device=dev)                 # (position 0 sits at the run edge: padded window, p = 1)
+    assert float(r1['comb_p'][planted].max().item()) < 1e-10
+    assert int((r1['comb_p'] < 1e-10).sum().item()) <= 5 * len(planted) + 10       # the window spreads a plant over its neighbours

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the HIP path against the C oracle (run on the GPU box: python tools/fuzz_gpu.py [rounds]).
+"""Differential fuzz of the HIP path against the C oracle (run on the GPU box: python tests/fuzz_gpu.py [rounds]).
 Random ragged batches: group sizes from 1 to ~9000 with random size ranges per batch, continuous / gridded /
 heavily tied values, optional int16 input, both test masks.  Test infrastructure, like everything under oracle/."""
 import os
@@ -7,9 +7,9 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tests'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import nanomod_amd as nm            # noqa: E402
 import oracle_c                     # noqa: E402
 import helpers as H                 # noqa: E402

@@ -19,6 +19,22 @@ def shard_bounds(npos, world, rank):
     return lo, hi
 
 
+def balanced_bounds(off0, off1, world, rank):
+    """Contiguous blocks of about equal WORK for ragged coverage (equal sum of n0 + n1, not equal
+    position counts): rank r takes the positions whose cumulative sample count falls in its 1/world share.
+    off0 / off1: the CSR offsets (host arrays, npos + 1 each)."""
+    import numpy as np
+    cum = (np.asarray(off0, dtype=np.int64) - off0[0]) + (np.asarray(off1, dtype=np.int64) - off1[0])   # samples before position i
+    npos = len(cum) - 1
+    total = int(cum[-1])
+    cuts = [int(np.searchsorted(cum, total * r // world, side='left')) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, npos
+    cuts = [min(max(c, 0), npos) for c in cuts]
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts[rank], cuts[rank + 1]
+
+
 def halo_bounds(lo, hi, nb, npos):
     return max(lo - nb, 0), min(hi + nb, npos)
 

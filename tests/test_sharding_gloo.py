@@ -67,3 +67,17 @@ def test_sharded_equals_unsharded(npos, nb, method):
     for r in range(world):
         for k in ('ks_p', 'comb_p', 'comb_st'):
             assert np.array_equal(results[r][k], full[k], equal_nan=True), (r, k)
+
+
+def test_balanced_bounds_cover_and_balance():
+    """size-balanced cut for ragged coverage: the blocks tile [0, npos) and carry about equal sample counts"""
+    from nanomod_amd import sharding
+    rng = np.random.default_rng(3)
+    n0 = np.round(rng.lognormal(np.log(1000), 0.5, 5000)).astype(np.int64); n1 = np.round(rng.lognormal(np.log(50), 0.5, 5000)).astype(np.int64)
+    off0 = np.r_[0, np.cumsum(n0)]; off1 = np.r_[0, np.cumsum(n1)] + 17
+    for world in (1, 2, 8):
+        cuts = [sharding.balanced_bounds(off0, off1, world, r) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == 5000 and all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        work = [int((n0 + n1)[lo:hi].sum()) for lo, hi in cuts]
+        assert max(work) - min(work) <= 2 * int((n0 + n1).max())
+    assert sharding.balanced_bounds(np.zeros(1, np.int64), np.zeros(1, np.int64), 4, 2) == (0, 0)

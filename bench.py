@@ -52,10 +52,21 @@ def cpu_baseline(a, b, threads, target_seconds=15.0, max_positions=1_000_000):
     sample = int(min(max_positions, a.shape[0], max(probe, rate * target_seconds)))
     reps = max(1, int(round(rate * target_seconds / sample)))
     dt = sum(run(sample) for _ in range(reps))
+    # the reference's own shape of the computation — one scipy-style call sequence per position, one core
+    #  — on a small sample of the same rows, for scale: all three tests, as getKStest always does
+    import nanomod_oracle as orc
+    npy = min(400, a.shape[0])
+    t0 = time.perf_counter()
+    ksp = [orc.getKStest(a[i].astype(np.float64), b[i].astype(np.float64))[2][1] for i in range(npy)]
+    orc.combine_track(np.zeros(npy), np.array(ksp), np.zeros(npy, np.int32), NB, WDIF, orc.METHOD_STOUFFER)
+    dpy = time.perf_counter() - t0
     return {'value': sample * reps / dt, 'unit': 'positions/s', 'cores': threads, 'kind': 'port',
             'sample': 'first %d positions of the same workload (200 v 200, KS + Stouffer window 5) x %d passes, '
                       'oracle/nanomod_oracle.c with OpenMP on %d threads (cgroup CPU quota), %.1f s'
-                      % (sample, reps, threads, dt)}
+                      % (sample, reps, threads, dt),
+            'reference_shaped_python': {'value': npy / dpy, 'unit': 'positions/s', 'cores': 1,
+                                        'sample': 'oracle/nanomod_oracle.py getKStest + combine per position on the first %d '
+                                                  'positions (the reference computes MWU, Welch and KS for every position)' % npy}}
 
 
 def usable_cpus():

@@ -18,7 +18,7 @@
 namespace nmod {
 
 constexpr int kBigThreads = 256;          // (1024 threads per block: 1.5x slower, the barriers dominate)
-constexpr int kBigLdsKeys = 8192;           // 32 KB: groups up to this size are sorted in LDS
+constexpr int kBigLdsBytes = 32768;         // groups whose padded keys fit are sorted in LDS (8 192 fp32 / 4 096 fp64 keys)
 
 struct BigArgs {
   const void* sig0; const void* sig1;
@@ -28,7 +28,7 @@ struct BigArgs {
   const int32_t* class_meta;                // [kBigClass] count, [kClassStride + kBigClass] offset into pos_list
   int32_t big_class;
   int32_t all;                              // 1: MWU / Welch / float-form D; 0: KS numerator only
-  float* scratch;                           // slab of sum (pow2(n0) + pow2(n1)) floats
+  void* scratch;                            // slab of sum (pow2(n0) + pow2(n1)) keys (fp32, or fp64 for DTYPE 2)
   unsigned long long* cursor;               // bump allocator over the slab
   uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments; double* ks_d_ref;
 };
@@ -39,10 +39,16 @@ __host__ __device__ inline int64_t big_pow2_ceil(int64_t n) {
   return p;
 }
 
+// DTYPE 0: fp32 samples, 1: int16 milli-units (fp32 keys), 2: fp64 samples with fp64 keys — the path for float64
+// input that is neither float32-exact nor on the 0.001 grid (NMOD_DTYPE_F64): every position then comes here
+template <int DTYPE> struct BigKey { typedef float type; };
+template <> struct BigKey<2> { typedef double type; };
+
 template <int DTYPE>
-__device__ __forceinline__ float big_load(const void* sig, int64_t i) {
+__device__ __forceinline__ typename BigKey<DTYPE>::type big_load(const void* sig, int64_t i) {
   if constexpr (DTYPE == 0) return reinterpret_cast<const float*>(sig)[i];
-  else return (float)reinterpret_cast<const int16_t*>(sig)[i];
+  else if constexpr (DTYPE == 1) return (float)reinterpret_cast<const int16_t*>(sig)[i];
+  else return reinterpret_cast<const double*>(sig)[i];
 }
 
 __device__ __forceinline__ double big_block_sum(double v, double* red) {
@@ -58,14 +64,15 @@ __device__ __forceinline__ double big_block_sum(double v, double* red) {
 }
 
 // bitonic network over P keys (P a power of two) by the whole block; `keys` is LDS or global memory
-__device__ __forceinline__ void big_bitonic(float* keys, int P) {
+template <typename K>
+__device__ __forceinline__ void big_bitonic(K* keys, int P) {
   for (int k = 2; k <= P; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = threadIdx.x; t < (P >> 1); t += kBigThreads) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // the element of the pair with bit j clear
         const int p = i | j;
         const bool up = (i & k) == 0;
-        const float a = keys[i], b = keys[p];
+        const K a = keys[i], b = keys[p];
         if ((a > b) == up) { keys[i] = b; keys[p] = a; }
       }
       __syncthreads();
@@ -73,12 +80,14 @@ __device__ __forceinline__ void big_bitonic(float* keys, int P) {
   }
 }
 
-__device__ __forceinline__ int big_lower_bound(const float* s, int n, float x) {   // #{s < x}
+template <typename K>
+__device__ __forceinline__ int big_lower_bound(const K* s, int n, K x) {   // #{s < x}
   int lo = 0, hi = n;
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (s[mid] < x) lo = mid + 1; else hi = mid; }
   return lo;
 }
-__device__ __forceinline__ int big_upper_bound(const float* s, int n, float x) {   // #{s <= x}
+template <typename K>
+__device__ __forceinline__ int big_upper_bound(const K* s, int n, K x) {   // #{s <= x}
   int lo = 0, hi = n;
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (s[mid] <= x) lo = mid + 1; else hi = mid; }
   return lo;
@@ -87,13 +96,15 @@ __device__ __forceinline__ int big_upper_bound(const float* s, int n, float x) {
 template <int DTYPE>
 __global__ __launch_bounds__(kBigThreads)
 void big_rank_kernel(BigArgs a) {
-  __shared__ float lds_keys[kBigLdsKeys];
+  typedef typename BigKey<DTYPE>::type K;
+  constexpr int kBigLdsKeys = kBigLdsBytes / (int)sizeof(K);
+  __shared__ K lds_keys[kBigLdsKeys];
   __shared__ double red[kBigThreads / 64];
   __shared__ unsigned long long sh_base, sh_s, sh_t, sh_best;
   const int tid = threadIdx.x;
   const int64_t count = a.class_meta[a.big_class];
   const int32_t* list = a.pos_list + a.class_meta[kClassStride + a.big_class];
-  const float inf = __builtin_inff();
+  const K inf = (K)__builtin_inff();
 
   for (int64_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
     const int64_t pos = list[bi];
@@ -106,15 +117,15 @@ void big_rank_kernel(BigArgs a) {
       sh_s = 0ull; sh_t = 0ull; sh_best = 0ull;
     }
     __syncthreads();
-    float* A = a.scratch + sh_base;
-    float* B = A + P0;
+    K* A = reinterpret_cast<K*>(a.scratch) + sh_base;
+    K* B = A + P0;
 
     // ---- moments (two-pass, fp64) and the sorted copies
     for (int g = 0; g < 2; ++g) {
       const void* sig = g ? a.sig1 : a.sig0;
       const int64_t off = g ? o1 : o0;
       const int n = g ? n1 : n0, P = g ? P1 : P0;
-      float* dst = g ? B : A;
+      K* dst = g ? B : A;
       if (a.all) {
         double s = 0.0;
         for (int i = tid; i < n; i += kBigThreads) s += (double)big_load<DTYPE>(sig, off + i);
@@ -125,8 +136,8 @@ void big_rank_kernel(BigArgs a) {
         q = big_block_sum(q, red);
         if (tid == 0) {
           double* mo = a.moments + pos * 4 + 2 * g;
-          if constexpr (DTYPE == 0) { mo[0] = mu; mo[1] = q; }
-          else { mo[0] = s / 1000.0 / (double)n; mo[1] = q * 1e-6; }
+          if constexpr (DTYPE == 1) { mo[0] = s / 1000.0 / (double)n; mo[1] = q * 1e-6; }
+          else { mo[0] = mu; mo[1] = q; }
         }
       }
       if (P <= kBigLdsKeys) {
@@ -148,7 +159,7 @@ void big_rank_kernel(BigArgs a) {
     unsigned long long s_acc = 0ull, t_acc = 0ull, best = 0ull;
     double dmax = 0.0;
     for (int j = tid; j < q; j += kBigThreads) {
-      const float x = B[j];
+      const K x = B[j];
       if (j + 1 < q && B[j + 1] == x) continue;                     // not the end of its run
       const int js = (j > 0 && B[j - 1] == x) ? big_lower_bound(B, q, x) : j, je = j + 1;   // a run of one: no search
       const int L = big_lower_bound(A, m, x);
@@ -169,7 +180,7 @@ void big_rank_kernel(BigArgs a) {
     }
     if (a.all) {
       for (int i = tid; i < m; i += kBigThreads) {                   // runs of group 1: a^3 - a each
-        const float x = A[i];
+        const K x = A[i];
         if (i + 1 < m && A[i + 1] == x) continue;
         if (i == 0 || A[i - 1] != x) continue;                       // a run of one adds 1^3 - 1 = 0
         const unsigned long long ta = (unsigned long long)(i + 1 - big_lower_bound(A, m, x));

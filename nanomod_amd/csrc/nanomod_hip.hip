@@ -84,7 +84,7 @@ static Workspace carve(void* base, int64_t npos) {
 // ---------------------------------------------------------------- binning kernels
 struct BinArgs {
   int64_t npos; const int64_t* off0; const int64_t* off1; int64_t stride0, stride1;
-  int cmax0, cmax1; int ks_only; int allow_big; int64_t lim0, lim1; uint8_t* cls; int32_t* meta; int32_t* order;
+  int cmax0, cmax1; int ks_only; int allow_big; int force_big; int64_t lim0, lim1; uint8_t* cls; int32_t* meta; int32_t* order;
 };
 
 
@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void classify_kernel(BinArgs a) {
     // beyond what the caller promised (or the format allows): skipped, NMOD_STATUS_TOO_LARGE
     const bool over = n0 > a.lim0 || n1 > a.lim1 || n0 > NMOD_MAX_RANKED || n1 > NMOD_MAX_RANKED;
     // beyond the wave-resident kernels: KS-only sorts the smaller group only, all-tests mode sorts both
-    const bool big = a.ks_only ? (c0 < c1 ? c0 : c1) >= kNumSizeClasses : (c0 >= kNumSizeClasses || c1 >= kNumSizeClasses);
+    const bool big = a.force_big ||                                   // fp64 keys: every position takes big_rank_kernel
+                     (a.ks_only ? (c0 < c1 ? c0 : c1) >= kNumSizeClasses : (c0 >= kNumSizeClasses || c1 >= kNumSizeClasses));
     int cid;
     if (over || n0 <= 0 || n1 <= 0 || (big && !a.allow_big)) cid = 255;
     else if (big) cid = kBigClass;
@@ -324,8 +325,9 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   int cmax0 = size_class_of(std::max<int64_t>(max0, 1)), cmax1 = size_class_of(std::max<int64_t>(max1, 1));
   // positions beyond the wave-resident kernels (both groups sorted in all-tests mode, the smaller one in KS-only
   // mode) go to big_rank_kernel; the maxima tell whether any can exist
-  const bool big_possible = all ? (cmax0 >= kNumSizeClasses || cmax1 >= kNumSizeClasses)
-                                : (std::min(cmax0, cmax1) >= kNumSizeClasses);
+  const bool f64_keys = prm->dtype == NMOD_DTYPE_F64;       // (reached through detect_f64 only: samples no narrower type holds)
+  const bool big_possible = f64_keys || (all ? (cmax0 >= kNumSizeClasses || cmax1 >= kNumSizeClasses)
+                                             : (std::min(cmax0, cmax1) >= kNumSizeClasses));
   cmax0 = std::min(cmax0, kNumSizeClasses - 1); cmax1 = std::min(cmax1, kNumSizeClasses - 1);
 
   RankStatsArgs ra;
@@ -349,7 +351,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   } else {
     BinArgs ba;
     ba.npos = npos; ba.off0 = off0; ba.off1 = off1; ba.stride0 = ra.stride0; ba.stride1 = ra.stride1;
-    ba.cmax0 = cmax0; ba.cmax1 = cmax1; ba.ks_only = all ? 0 : 1; ba.allow_big = 1; ba.lim0 = std::max<int64_t>(max0, 1); ba.lim1 = std::max<int64_t>(max1, 1);
+    ba.cmax0 = cmax0; ba.cmax1 = cmax1; ba.ks_only = all ? 0 : 1; ba.allow_big = 1; ba.force_big = f64_keys ? 1 : 0; ba.lim0 = std::max<int64_t>(max0, 1); ba.lim1 = std::max<int64_t>(max1, 1);
     ba.cls = ws.cls; ba.meta = ws.meta; ba.order = ws.order;
     unsigned blocks = (unsigned)std::min<int64_t>((npos + 255) / 256, 4096);
     hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, stream, ba);
@@ -360,7 +362,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     bool wanted[kNumClasses] = {false};
     for (int c0 = 0; c0 <= cmax0; ++c0)
       for (int c1 = 0; c1 <= cmax1; ++c1) wanted[all ? launch_class_of(c0, c1) : kKsClassBase + std::min(c0, c1)] = true;
-    for (int cls = 0; cls < kNumClasses; ++cls) {
+    for (int cls = 0; cls < kNumClasses && !f64_keys; ++cls) {
       if (!wanted[cls]) continue;
       ra.pos_list = ws.order; ra.class_meta = ws.meta; ra.class_id = cls;
       NMOD_HIP(launch(cls, npos));
@@ -375,17 +377,18 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
       unsigned long long total;
       memcpy(&total, &head[2], 8);
       if (nbig > 0) {
-        NMOD_HIP(big_scratch.alloc((size_t)total * 4, stream));
+        NMOD_HIP(big_scratch.alloc((size_t)total * (f64_keys ? 8 : 4), stream));
         BigArgs bg;
         memset(&bg, 0, sizeof(bg));
         bg.sig0 = sig0; bg.sig1 = sig1; bg.off0 = off0; bg.off1 = off1; bg.stride0 = ra.stride0; bg.stride1 = ra.stride1;
         bg.pos_list = ws.order; bg.class_meta = ws.meta; bg.big_class = kBigClass; bg.all = all ? 1 : 0;
-        bg.scratch = (float*)big_scratch.p;
+        bg.scratch = big_scratch.p;
         bg.cursor = reinterpret_cast<unsigned long long*>(ws.meta + kMetaBigCursor);
         bg.ks_num = ws.ks_num; bg.mwu_s = ws.mwu_s; bg.tie = ws.tie; bg.moments = ws.moments; bg.ks_d_ref = ws.ks_d_ref;
         const unsigned blocks = (unsigned)std::min<int64_t>(nbig, (int64_t)num_cus * 4);   // 4 x 33 KB of LDS per CU
         if (prm->dtype == NMOD_DTYPE_F32) hipLaunchKernelGGL(big_rank_kernel<0>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
-        else hipLaunchKernelGGL(big_rank_kernel<1>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
+        else if (prm->dtype == NMOD_DTYPE_I16_MILLI) hipLaunchKernelGGL(big_rank_kernel<1>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
+        else hipLaunchKernelGGL(big_rank_kernel<2>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
         NMOD_HIP(hipGetLastError());
         NMOD_HIP(big_scratch.release(stream));
       }
@@ -433,7 +436,7 @@ static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, c
   if (!sig0 || !sig1 || !out) return NMOD_ERR_INVALID_ARG;
   if ((prm->stride0 <= 0 && !off0) || (prm->stride1 <= 0 && !off1)) return NMOD_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)prm->stream;
-  const size_t esz = prm->dtype == NMOD_DTYPE_F32 ? 4 : 2;
+  const size_t esz = prm->dtype == NMOD_DTYPE_F32 ? 4 : (prm->dtype == NMOD_DTYPE_F64 ? 8 : 2);
   const int64_t tot0 = prm->stride0 > 0 ? prm->stride0 * npos : off0[npos] - off0[0];
   const int64_t tot1 = prm->stride1 > 0 ? prm->stride1 * npos : off1[npos] - off1[0];
   nmod_params dp = *prm;
@@ -544,7 +547,16 @@ static int detect_f64(const nmod_params* prm, int64_t npos, const void* sig0, co
   nmod_params ep = *prm;
   if (flags[0]) ep.dtype = NMOD_DTYPE_F32;
   else if (flags[1]) ep.dtype = NMOD_DTYPE_I16_MILLI;
-  else return NMOD_ERR_INVALID_ARG;                 // neither float32-exact nor on the 0.001 grid
+  else {
+    // neither float32-exact nor on the 0.001 grid: sort the fp64 samples themselves — every position through the
+    // workgroup-per-position kernel with 64-bit keys (correct for any input, ~1e5 positions/s)
+    const void* s0 = (const char*)d0 - (size_t)b0 * 8;
+    const void* s1 = (const char*)d1 - (size_t)b1 * 8;
+    int rc = host ? detect_host(&ep, npos, s0, off0, s1, off1, run_id, out, true)
+                  : detect_device(&ep, npos, s0, off0, s1, off1, run_id, workspace, workspace_bytes, out);
+    hipStreamSynchronize(stream);
+    return rc;
+  }
   const size_t esz = ep.dtype == NMOD_DTYPE_F32 ? 4 : 2;
   NMOD_HIP(enc0.alloc((size_t)n0 * esz)); NMOD_HIP(enc1.alloc((size_t)n1 * esz));
   const unsigned eb0 = (unsigned)std::min<int64_t>((n0 + 255) / 256 + 1, 8192), eb1 = (unsigned)std::min<int64_t>((n1 + 255) / 256 + 1, 8192);

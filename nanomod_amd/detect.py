@@ -59,7 +59,8 @@ def encode_signals(values):
     """Pick the device dtype for a float64 sample vector without changing a
     single value the reference would see: float32 if every value is
     float32-exact, else int16 milli-units if every value is k/1000.0 (NanoMod's
-    Events are 3-dp rounded, myRefBaseSignalAnnotation.py:1108)."""
+    Events are 3-dp rounded, myRefBaseSignalAnnotation.py:1108), else the
+    float64 values themselves (NMOD_DTYPE_F64: sorted as 64-bit keys, slower)."""
     v = np.asarray(values, dtype=np.float64)
     f32 = v.astype(np.float32)
     if np.array_equal(f32.astype(np.float64), v):
@@ -67,8 +68,7 @@ def encode_signals(values):
     k = np.rint(v * 1000.0)
     if np.all(np.abs(k) <= 32767) and np.array_equal(k / 1000.0, v):
         return k.astype(np.int16)
-    raise ValueError('signal values are neither float32-exact nor on the 0.001 grid; '
-                     'the fp64-key path is not implemented (DESIGN.md, out of scope)')
+    return v
 
 
 def _coverage_threshold(moptions, m_str):

@@ -498,7 +498,7 @@ def test_welch_p_value_grid(nm):
 
 def test_float64_input_dtype(nm):
     """NMOD_DTYPE_F64: float64 samples as the reference holds them are re-encoded on the device — float32 when every
-    value is float32-exact, int16 milli-units when every value is k/1000, NMOD_ERR_INVALID_ARG otherwise — in host
+    value is float32-exact, int16 milli-units when every value is k/1000, sorted as 64-bit keys otherwise — in host
     and device memory, CSR with a non-zero first offset and fixed stride"""
     import torch
     import nanomod_oracle as orc
@@ -533,10 +533,25 @@ def test_float64_input_dtype(nm):
     r = nm.detect_host(np.rint(s0 * 1000).astype(np.int16), None, np.rint(s1 * 1000).astype(np.int16), None, np.zeros(40, np.int32),
                        stride0=50, stride1=60, tests=L.TEST_KS, method='ks')
     assert np.array_equal(g['ks_p'], r['ks_p'])
-    # neither float32-exact nor on the grid
-    bad = rng.normal(0, 1, off0[-1])
-    with pytest.raises(L.NanomodLibraryError, match='invalid argument'):
-        nm.detect_host(bad, off0, b3, off1, rid)
+    # neither float32-exact nor on the grid: the fp64 samples themselves are sorted (64-bit keys, every position through
+    # the workgroup-per-position kernel) — any float64 input the reference accepts is accepted, with ties between
+    # doubles that differ below float32 resolution kept apart
+    a64 = rng.normal(0, 1, off0[-1]); b64 = rng.normal(0.2, 1, off1[-1])
+    a64[off0[3]:off0[3] + 2] = [0.1, 0.1 + 1e-12]; b64[off1[3]:off1[3] + 2] = [0.1 + 1e-12, 0.1 + 2e-12]   # equal as float32
+    b64[off1[5]:off1[6]] = np.resize(a64[off0[5]:off0[6]], n1[5])                                         # exact cross ties
+    for tests in (L.TEST_ALL, L.TEST_KS):
+        got = nm.detect_host(a64, off0, b64, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=tests)
+        exp = orc.detect_batch(a64[pad:], off0 - pad, b64[pad:], off1 - pad, rid, 2, 2.0, orc.METHOD_STOUFFER)
+        if tests == L.TEST_ALL:
+            H.compare_outputs(got, exp, True)
+        else:
+            H.assert_close_stat(got['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+            H.assert_close_p(got['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
+    r = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer').run(
+        torch.as_tensor(a64, device='cuda:0'), torch.as_tensor(b64, device='cuda:0'), torch.as_tensor(rid, device='cuda:0'),
+        off0=torch.as_tensor(off0, device='cuda:0'), off1=torch.as_tensor(off1, device='cuda:0'))
+    torch.cuda.synchronize()
+    assert np.array_equal(r['mwu_p'].cpu().numpy(), got0 := nm.detect_host(a64, off0, b64, off1, rid, nb=2, weights_dif=2.0, method='stouffer')['mwu_p'])
 
 
 def test_rank_order_entry_point(nm):
@@ -639,3 +654,27 @@ def test_logical_shards_equal_unsharded(nm, G):
     torch.cuda.synchronize()
     for k in got:
         assert torch.equal(got[k], full[k]), k
+
+
+def test_mtest2_on_arbitrary_float64(nm):
+    """the drop-in accepts signals that are neither float32-exact nor 3-dp rounded (the reference does): same numbers as
+    the oracle through mtest2"""
+    import nanomod_oracle as orc
+    rng = np.random.default_rng(21)
+    npos = 40
+    ca = [rng.normal(0, 1, int(rng.integers(6, 90))) for _ in range(npos)]
+    cb = [rng.normal(0.3, 1, int(rng.integers(6, 90))) for _ in range(npos)]
+    with tempfile.TemporaryDirectory() as tmp:
+        mo = {'ds2': ['A', 'B'], 'outLevel': 3, 'mstd': 0, 'coverages': [0, 0], 'downsampling': 100, 'downsampling_quantile': 0.25,
+              'neighborPvalues': 2, 'WeightsDif': 2.0, 'testMethod': 'stouffer', 'rankUse': 'pv', 'SaveTest': 0, 'RegionRankbyST': 0,
+              'outFolder': tmp, 'FileID': 'f64', 'MinCoverage': 5}
+        for ds, ch in (('A', ca), ('B', cb)):
+            mo[ds] = {'norm_mean': {('c', '+'): {10 + i: [np.float64(v) for v in ch[i]] for i in range(npos)}},
+                      'base': {('c', '+'): {10 + i: 'A' for i in range(npos)}}, 'basedict': {}}
+        nm.mfilter_coverage(mo)
+        nm.mtest2(mo)
+    for i, rec in enumerate(mo['sign_test']):
+        e = orc.getKStest(ca[i], cb[i])
+        assert rec[1][0][0] == e[0][0] and abs(rec[1][0][1] - e[0][1]) <= 1e-9 * e[0][1]
+        assert abs(rec[1][1][1] - e[1][1]) <= 1e-9 * e[1][1] and abs(rec[1][2][0] - e[2][0]) <= 4.5e-16
+        assert abs(rec[1][2][1] - e[2][1]) <= 1e-9 * e[2][1]

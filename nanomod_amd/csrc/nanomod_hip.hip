@@ -549,7 +549,7 @@ static int detect_f64(const nmod_params* prm, int64_t npos, const void* sig0, co
   else if (flags[1]) ep.dtype = NMOD_DTYPE_I16_MILLI;
   else {
     // neither float32-exact nor on the 0.001 grid: sort the fp64 samples themselves — every position through the
-    // workgroup-per-position kernel with 64-bit keys (correct for any input, ~1e5 positions/s)
+    // workgroup-per-position kernel with 64-bit keys (correct for any input; ~3e7 positions/s at 200 v 200)
     const void* s0 = (const char*)d0 - (size_t)b0 * 8;
     const void* s1 = (const char*)d1 - (size_t)b1 * 8;
     int rc = host ? detect_host(&ep, npos, s0, off0, s1, off1, run_id, out, true)

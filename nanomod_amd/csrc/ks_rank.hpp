@@ -405,11 +405,11 @@ void ks_rank_kernel(RankStatsArgs args) {
           const int step = (dl == (unsigned)((R - 1) * ROW * 4)) ? 1 - (R - 1) * ROW : ROW;
           up[e] = eq ? lp[e] + step : lp[e];
         }
+        // (per sample slot: only the slots in which some lane needs it pay for the second search)
 #pragma unroll
-        for (int e = 0; e < NV; ++e) again = again || (*up[e] == xq[e]);
-        if (__ballot(again) != 0ull) {
-#pragma unroll
-          for (int e = 0; e < NV; ++e) up[e] = ks_search<R, LG, true>(kbase, xq[e]);
+        for (int e = 0; e < NV; ++e) {
+          again = (*up[e] == xq[e]);
+          if (__ballot(again) != 0ull) up[e] = ks_search<R, LG, true>(kbase, xq[e]);
         }
 #pragma unroll
         for (int e = 0; e < NV; ++e) {

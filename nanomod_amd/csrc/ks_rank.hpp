@@ -385,41 +385,30 @@ void ks_rank_kernel(RankStatsArgs args) {
       constexpr int NV = decltype(nv_tag)::value;
       const float* lp[NV];
       const float* lcol[NV];
-      bool tie_here = false;
 #pragma unroll
       for (int e = 0; e < NV; ++e) lp[e] = ks_search<R, LG, false>(kbase, xq[e], &lcol[e]);
+      bool eq[NV];
 #pragma unroll
-      for (int e = 0; e < NV; ++e) tie_here = tie_here || (*lp[e] == xq[e]);      // key C is +inf
-      if (__ballot(tie_here) != 0ull) {          // ties with S: common for 3-dp rounded signals and the synthetic grid
-        any_tie = true;
-        // a tied sample almost always ties with ONE key: U = L + 1 (the next row of the column, or row 0 of the
-        // next column when L is in the last row); only if that next key ties again (duplicates inside S) fall
-        // back to the full upper-bound search
-        const float* up[NV];
-        bool again = false;
+      for (int e = 0; e < NV; ++e) eq[e] = (*lp[e] == xq[e]);                       // key C is +inf
+      // Per sample slot: a slot in which no lane ties with S (the usual case) adds L and U in one go; a slot with
+      // ties — common for 3-dp rounded signals and the synthetic grid — takes U = L + 1 (the next row of the
+      // column, or row 0 of the next column when L is in the last row), and only if that next key ties again
+      // (duplicates inside S) the full upper-bound search.
 #pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          const bool eq = (*lp[e] == xq[e]);
+      for (int e = 0; e < NV; ++e) {
+        unsigned* bin = reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF;
+        if (__ballot(eq[e]) == 0ull) {
+          atomicAdd(bin, 0x10001u);
+        } else {
+          any_tie = true;
           // (32-bit LDS offsets: a generic-pointer difference would be computed in 64 bits)
           const unsigned dl = (unsigned)(uintptr_t)lp[e] - (unsigned)(uintptr_t)lcol[e];
           const int step = (dl == (unsigned)((R - 1) * ROW * 4)) ? 1 - (R - 1) * ROW : ROW;
-          up[e] = eq ? lp[e] + step : lp[e];
+          const float* up = eq[e] ? lp[e] + step : lp[e];
+          if (__ballot(*up == xq[e]) != 0ull) up = ks_search<R, LG, true>(kbase, xq[e]);
+          atomicAdd(bin, 0x10000u);
+          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up)) + HIST_OFF, 1u);
         }
-        // (per sample slot: only the slots in which some lane needs it pay for the second search)
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          again = (*up[e] == xq[e]);
-          if (__ballot(again) != 0ull) up[e] = ks_search<R, LG, true>(kbase, xq[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, 0x10000u);
-          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up[e])) + HIST_OFF, 1u);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < NV; ++e)
-          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, 0x10001u);
       }
     };
 

@@ -509,20 +509,22 @@ void ks_rank_kernel(RankStatsArgs args) {
       for (int r = 0; r < R; ++r) s_own[r] = keys[r * ROW + gl];
       const float s_next = keys[gl + 1];                 // key e0 + R (or the +inf sentinel)
       // Pads are +inf, so "s_{k-1} != s_k" alone marks the run ends: it holds at k = m and fails for k > m.
-      int cl = (int)(cum >> 16), cu = (int)(cum & 0xffffu);   // cumL(k-1), cumU(k-1) entering bin k = e0 + 1
-      int hi = (gl == 0) ? cu * m : 0, lo = 0;                  // k = 0: (cumU(0), 0)
-      int kq = e0 * q;
-      int clm = __mul24(cl, m);
+      // both counts stay packed (cumL << 16 | cumU: neither half exceeds q <= 65 535, so no carry crosses) and
+      // each candidate is one multiply-add against the running -k*q
+      unsigned c2 = cum;                                            // cumL(k-1) | cumU(k-1) entering bin k = e0 + 1
+      int cl = (int)(c2 >> 16);
+      int hi = (gl == 0) ? (int)(c2 & 0xffffu) * m : 0, lo = 0;     // k = 0: (cumU(0), 0)
+      int nkq = -(e0 * q);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float up = (r == R - 1) ? s_next : s_own[r + 1];
         const bool run_end = s_own[r] != up;
-        kq += q;
-        const int cand_b = clm - kq;                             // v = the S value with upper rank k: cumL(k-1)*m - k*q
-        cu += (int)(h[r] & 0xffffu);
-        cl += (int)(h[r] >> 16);
-        clm = __mul24(cl, m);
-        const int cand_a = __mul24(cu, m) - kq;                  // v = largest Q sample with U = k: cumU(k)*m - k*q
+        nkq -= q;
+        const int cand_b = __mul24(cl, m) + nkq;                   // v = the S value with upper rank k: cumL(k-1)*m - k*q
+        c2 += h[r];
+        const int cu = (int)(c2 & 0xffffu);
+        cl = (int)(c2 >> 16);
+        const int cand_a = __mul24(cu, m) + nkq;                   // v = largest Q sample with U = k: cumU(k)*m - k*q
         const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
         hi = max(hi, max(ca, cb));
         lo = min(lo, min(ca, cb));

@@ -180,12 +180,17 @@ __device__ __forceinline__ void seg_sort_any(float (&x)[R], const LaneSel& sel, 
 
 // branchless binary search: returns the pointer to key L (LE = false: L = #{s < x}) or key U (LE = true:
 // U = #{s <= x}); `base` points at key 0.  *col gets the pointer to row 0 of the column that holds the rank.
-template <int R, int LG, bool LE>
+// FULL = false: the caller knows the array holds at least one +inf pad (fewer than C real keys), so rank C cannot
+// occur and the check of the last key is skipped.
+template <int R, int LG, bool LE, bool FULL = true>
 __device__ __forceinline__ const float* ks_search(const float* base, float x, const float** col = nullptr) {
   using Lay = KsLayout<R, LG>;
   const float* p = base;
-  const float last = base[Lay::LAST];
-  const bool all = LE ? (last <= x) : (last < x);                 // rank C: every key is below x
+  bool all = false;
+  if constexpr (FULL) {
+    const float last = base[Lay::LAST];
+    all = LE ? (last <= x) : (last < x);                          // rank C: every key is below x
+  }
 #pragma unroll
   for (int hc = LG / 2; hc >= 1; hc >>= 1) {                       // h = hc * R keys: along row R - 1
     const float t = p[(R - 1) * Lay::ROW + hc - 1];
@@ -379,14 +384,17 @@ void ks_rank_kernel(RankStatsArgs args) {
 
     // ---- rank every Q sample into S
     bool any_tie = false;
+    // a sorted group that fills its capacity exactly has no +inf pad: only then can a sample rank above every key
+    const bool s_full = __ballot(m == Lay::C) != 0ull;
 
     // rank NV samples (xq) and add them to the histograms
-    auto rank_and_count = [&](auto nv_tag, const float* kbase, const float* xq) {
+    auto rank_and_count = [&](auto nv_tag, auto full_tag, const float* kbase, const float* xq) {
       constexpr int NV = decltype(nv_tag)::value;
+      constexpr bool FULL = decltype(full_tag)::value;
       const float* lp[NV];
       const float* lcol[NV];
 #pragma unroll
-      for (int e = 0; e < NV; ++e) lp[e] = ks_search<R, LG, false>(kbase, xq[e], &lcol[e]);
+      for (int e = 0; e < NV; ++e) lp[e] = ks_search<R, LG, false, FULL>(kbase, xq[e], &lcol[e]);
       bool eq[NV];
 #pragma unroll
       for (int e = 0; e < NV; ++e) eq[e] = (*lp[e] == xq[e]);                       // key C is +inf
@@ -405,7 +413,7 @@ void ks_rank_kernel(RankStatsArgs args) {
           const unsigned dl = (unsigned)(uintptr_t)lp[e] - (unsigned)(uintptr_t)lcol[e];
           const int step = (dl == (unsigned)((R - 1) * ROW * 4)) ? 1 - (R - 1) * ROW : ROW;
           const float* up = eq[e] ? lp[e] + step : lp[e];
-          if (__ballot(*up == xq[e]) != 0ull) up = ks_search<R, LG, true>(kbase, xq[e]);
+          if (__ballot(*up == xq[e]) != 0ull) up = ks_search<R, LG, true, FULL>(kbase, xq[e]);
           atomicAdd(bin, 0x10000u);
           atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up)) + HIST_OFF, 1u);
         }
@@ -421,7 +429,8 @@ void ks_rank_kernel(RankStatsArgs args) {
         float xa[4];
         q4_values(xa, ra, c < full);
 #if !(defined(NMOD_EXP) && (NMOD_EXP & 2))
-        rank_and_count(std::integral_constant<int, 4>{}, keys, xa);
+        if (s_full) rank_and_count(std::integral_constant<int, 4>{}, std::true_type{}, keys, xa);
+        else rank_and_count(std::integral_constant<int, 4>{}, std::false_type{}, keys, xa);
 #else
         if (xa[0] + xa[1] + xa[2] + xa[3] == 12345.f) atomicAdd(hist, 1u);
 #endif
@@ -432,7 +441,8 @@ void ks_rank_kernel(RankStatsArgs args) {
         float xq[1] = {q1_value(rt, full * (4 * LG) + c * LG + gl < q)};
         const int idx = full * (4 * LG) + (c + 1) * LG + gl;
         rt = load_q1(sig_q, off_q, idx, idx < q);
-        rank_and_count(std::integral_constant<int, 1>{}, keys, xq);
+        if (s_full) rank_and_count(std::integral_constant<int, 1>{}, std::true_type{}, keys, xq);
+        else rank_and_count(std::integral_constant<int, 1>{}, std::false_type{}, keys, xq);
       }
     } else {
       const int cfull = q / 256;
@@ -457,13 +467,13 @@ void ks_rank_kernel(RankStatsArgs args) {
           const int idx = c * 256 + 4 * lane;
           float xq[4];
           q4_values(xq, load_q4(sigs, offs, idx, true), true);
-          rank_and_count(std::integral_constant<int, 4>{}, kb, xq);
+          rank_and_count(std::integral_constant<int, 4>{}, std::true_type{}, kb, xq);
         }
 #pragma unroll 1
         for (int c = 0; c < ts; ++c) {
           const int idx = fs * 256 + c * 64 + lane;
           float xq[1] = {q1_value(load_q1(sigs, offs, idx, idx < qs), idx < qs)};
-          rank_and_count(std::integral_constant<int, 1>{}, kb, xq);
+          rank_and_count(std::integral_constant<int, 1>{}, std::true_type{}, kb, xq);
         }
       }
     }

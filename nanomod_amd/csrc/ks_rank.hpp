@@ -362,19 +362,6 @@ void ks_rank_kernel(RankStatsArgs args) {
 #endif
 #pragma unroll
     for (int r = 0; r < R; ++r) keys[r * ROW + gl] = x[r];
-    // ties inside S: the smallest gap between neighbours is exactly 0.  Between two +inf pads the gap is NaN,
-    // which min() drops.  (A gap that underflows to 0 would only send the wave down the general evaluation path.)
-    bool s_tie;
-    {
-      const float nxt = lane_next(x[0], inf);
-      float gap = inf;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float up = (r == R - 1) ? ((gl == LG - 1) ? inf : nxt) : x[r + 1];
-        gap = fminf(gap, up - x[r]);
-      }
-      s_tie = gap == 0.0f;
-    }
     // clear this lane's bins e0 .. e0 + R - 1; the last lane also clears bin C
 #pragma unroll
     for (int r = 0; r < R; ++r) hist[r * ROW + gl] = 0u;
@@ -493,7 +480,21 @@ void ks_rank_kernel(RankStatsArgs args) {
     for (int r = 0; r < R; ++r) tot += h[r];
     const unsigned cum = seg_exscan_add_u32<LG>(tot, gl) + hist[0];      // both cumulative counts up to bin e0
     unsigned best = 0;
-    const bool slow = __ballot(s_tie || any_tie) != 0ull;
+    // Which evaluation: the general one as soon as a sample tied with S; otherwise look for ties INSIDE S — only
+    // then, from the keys in LDS (the general path reloads them anyway): the smallest gap between neighbours is
+    // exactly 0.  Between two +inf pads the gap is NaN, which min() drops.  (A gap that underflows to 0 would only
+    // send the wave down the general path.)
+    float s_own[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) s_own[r] = keys[r * ROW + gl];
+    const float s_next = keys[gl + 1];                   // key e0 + R (or the +inf sentinel)
+    bool slow = __ballot(any_tie) != 0ull;
+    if (!slow) {
+      float gap = inf;
+#pragma unroll
+      for (int r = 0; r < R; ++r) gap = fminf(gap, ((r == R - 1) ? s_next : s_own[r + 1]) - s_own[r]);
+      slow = __ballot(gap == 0.0f) != 0ull;
+    }
     if (!slow) {
       // no ties in this wave: cumL == cumU; D_num = max_{k < m} max(a_k, q - a_k), a_k = cumU(k)*m - k*q.
       // Q samples above every s sit in bin m; clamping k*q at (m-1)*q and the running count at
@@ -514,10 +515,6 @@ void ks_rank_kernel(RankStatsArgs args) {
       best = (unsigned)max(hi, q - lo);
     } else {
       // general form with the run ends of S as masks
-      float s_own[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) s_own[r] = keys[r * ROW + gl];
-      const float s_next = keys[gl + 1];                 // key e0 + R (or the +inf sentinel)
       // Pads are +inf, so "s_{k-1} != s_k" alone marks the run ends: it holds at k = m and fails for k > m.
       // both counts stay packed (cumL << 16 | cumU: neither half exceeds q <= 65 535, so no carry crosses) and
       // each candidate is one multiply-add against the running -k*q

@@ -253,11 +253,12 @@ void ks_rank_kernel(RankStatsArgs args) {
     const int64_t li = it * PW + slot;
     d.valid = it < items && li < count;
     d.pos = d.valid ? (list ? (int64_t)list[li] : li) : 0;
+    // (positions are < 2^31 and strides <= 65 535: one 32 x 32 -> 64-bit multiply each)
     int64_t o0 = 0, o1 = 0; int n0 = 0, n1 = 0;
     if (d.valid) {
-      if (args.stride0 > 0) { o0 = d.pos * args.stride0; n0 = (int)args.stride0; }
+      if (args.stride0 > 0) { o0 = (int64_t)((uint64_t)(uint32_t)d.pos * (uint64_t)(uint32_t)args.stride0); n0 = (int)args.stride0; }
       else { o0 = args.off0[d.pos]; n0 = (int)(args.off0[d.pos + 1] - o0); }
-      if (args.stride1 > 0) { o1 = d.pos * args.stride1; n1 = (int)args.stride1; }
+      if (args.stride1 > 0) { o1 = (int64_t)((uint64_t)(uint32_t)d.pos * (uint64_t)(uint32_t)args.stride1); n1 = (int)args.stride1; }
       else { o1 = args.off1[d.pos]; n1 = (int)(args.off1[d.pos + 1] - o1); }
     }
     d.swap = n1 < n0;

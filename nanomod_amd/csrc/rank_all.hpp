@@ -182,9 +182,9 @@ void rank_all_kernel(RankStatsArgs args) {
     int64_t o0 = 0, o1 = 0;
     d.n0 = 0; d.n1 = 0;
     if (d.valid) {
-      if (args.stride0 > 0) { o0 = d.pos * args.stride0; d.n0 = (int)args.stride0; }
+      if (args.stride0 > 0) { o0 = (int64_t)((uint64_t)(uint32_t)d.pos * (uint64_t)(uint32_t)args.stride0); d.n0 = (int)args.stride0; }
       else { o0 = args.off0[d.pos]; d.n0 = (int)(args.off0[d.pos + 1] - o0); }
-      if (args.stride1 > 0) { o1 = d.pos * args.stride1; d.n1 = (int)args.stride1; }
+      if (args.stride1 > 0) { o1 = (int64_t)((uint64_t)(uint32_t)d.pos * (uint64_t)(uint32_t)args.stride1); d.n1 = (int)args.stride1; }
       else { o1 = args.off1[d.pos]; d.n1 = (int)(args.off1[d.pos + 1] - o1); }
     }
     d.my_off = is_b ? o1 : o0;

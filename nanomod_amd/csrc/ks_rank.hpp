@@ -48,7 +48,7 @@ struct KsLayout {
   static constexpr int REGION = R * ROW;             // keys or bins of one position
   static constexpr int LAST = (R - 1) * ROW + LG - 1;   // key C - 1
   static constexpr int END = LG;                      // key / bin C
-  __device__ static __forceinline__ int word(int i) { return (i & (R - 1)) * ROW + i / R; }
+  __device__ static __forceinline__ int word(int i) { return __mul24(i & (R - 1), ROW) + i / R; }
 };
 
 // words of one position (keys + histogram), padded so that the positions sharing a 32-lane half
@@ -467,7 +467,7 @@ void ks_rank_kernel(RankStatsArgs args) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (gl == 0) hist[Lay::word(m)] -= (unsigned)(slots - q) * 0x10001u;   // the FLT_MAX slots
+    if (gl == 0) { const unsigned extra = (unsigned)(slots - q); hist[Lay::word(m)] -= (extra << 16) + extra; }   // the FLT_MAX slots
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -500,8 +500,8 @@ void ks_rank_kernel(RankStatsArgs args) {
       // no ties in this wave: cumL == cumU; D_num = max_{k < m} max(a_k, q - a_k), a_k = cumU(k)*m - k*q.
       // Q samples above every s sit in bin m; clamping k*q at (m-1)*q and the running count at
       // cumU(m-1) makes every bin >= m repeat a_{m-1}.
-      const int kq_max = (m - 1) * q;
-      int kq = min(e0 * q, kq_max);
+      const int kq_max = __mul24(m - 1, q);                              // (24-bit operands: m <= 2 048, q <= 65 535)
+      int kq = min(__mul24(e0, q), kq_max);
       const int cmax = q - (int)(hist[Lay::word(m)] & 0xffffu);          // cumU(m-1)
       int c = min((int)(cum & 0xffffu), cmax);
       int hi = __mul24(c, m) - kq, lo = hi;                              // bin e0 itself: a valid a_k
@@ -521,8 +521,8 @@ void ks_rank_kernel(RankStatsArgs args) {
       // each candidate is one multiply-add against the running -k*q
       unsigned c2 = cum;                                            // cumL(k-1) | cumU(k-1) entering bin k = e0 + 1
       int cl = (int)(c2 >> 16);
-      int hi = (gl == 0) ? (int)(c2 & 0xffffu) * m : 0, lo = 0;     // k = 0: (cumU(0), 0)
-      int nkq = -(e0 * q);
+      int hi = (gl == 0) ? __mul24((int)(c2 & 0xffffu), m) : 0, lo = 0;     // k = 0: (cumU(0), 0)
+      int nkq = -__mul24(e0, q);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float up = (r == R - 1) ? s_next : s_own[r + 1];

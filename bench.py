@@ -161,7 +161,7 @@ def main():
         value = total_positions * args.steps / elapsed
         k1_avg_s = (k1_ms / max(k1_n, 1)) * 1e-3
         # measured for the default N=1 workload only (4.6 M positions, KS mode)
-        traffic = 7.395e9 if (P == P_ECOLI and world == 1 and not args.all_tests) else None
+        traffic = 7.393e+09 if (P == P_ECOLI and world == 1 and not args.all_tests) else None
         algo_bytes = ALGO_BYTES_PER_POS + (32 if args.all_tests else 0)          # 16 B x 2 more (stat, p) pairs
         achieved = algo_bytes * n_local / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
         line = {

@@ -242,6 +242,7 @@ void rank_all_kernel(RankStatsArgs args) {
     const double dm = (double)m, dq = (double)q;
     const double rm = 1.0 / dm, rq = 1.0 / dq;
     const int two_m = 2 * m;
+    const bool a_full = __ballot(m == C) != 0ull;       // no +inf pad in some group 1 of the wave: rank C can occur
     unsigned s_lane = 0;
     unsigned long long tie3 = 0;
     double dmax = 0.0;
@@ -253,7 +254,7 @@ void rank_all_kernel(RankStatsArgs args) {
       const int rb = reinterpret_cast<const int*>(keysB + REGION)[wq];
       const int rb_s = rb & 0xffff, rb_e = (int)((unsigned)rb >> 16);
       const bool cand = (jq < q) && (rb_e == jq + 1);               // the end of a run of B
-      const float* p = ks_search<R, LG, false>(keysA, xq);
+      const float* p = a_full ? ks_search<R, LG, false, true>(keysA, xq) : ks_search<R, LG, false, false>(keysA, xq);
       const int ra = *reinterpret_cast<const int*>(p + REGION);      // p is the first key of its run: start == L
       const bool tie = (*p == xq);
       const int L = ra & 0xffff;
@@ -261,7 +262,7 @@ void rank_all_kernel(RankStatsArgs args) {
       const int a = U - L, b = rb_e - rb_s;
       s_lane += cand ? (unsigned)__mul24(b, two_m - U - L) : 0u;
       const unsigned ab = cand ? (unsigned)__mul24(a, b) : 0u;
-      tie3 += (unsigned long long)ab * (unsigned long long)(unsigned)(a + b);
+      if (__ballot(ab != 0u) != 0ull) tie3 += (unsigned long long)ab * (unsigned long long)(unsigned)(a + b);   // (a 64-bit multiply-add)
       const double d_at = exact_quot(U, dm, rm) - exact_quot(rb_e, dq, rq);
       const double d_before = exact_quot(L, dm, rm) - exact_quot(rb_s, dq, rq);
       const double dd = fmax(fabs(d_at), fabs(d_before));
@@ -301,6 +302,7 @@ __device__ __forceinline__ void rank_pair_phase(const float* keysT, const float*
   const int steps = __builtin_amdgcn_readfirstlane((nE + 63) >> 6);
   const double dT = (double)nT, dE = (double)nE;
   const double rT = 1.0 / dT, rE = 1.0 / dE;
+  const bool t_full = nT == 64 * RT;                   // (one position per wave: uniform)
 #pragma unroll 1
   for (int s = 0; s < steps; ++s) {
     const int jq = s * 64 + lane;
@@ -309,7 +311,7 @@ __device__ __forceinline__ void rank_pair_phase(const float* keysT, const float*
     const int re = reinterpret_cast<const int*>(keysE + LE::REGION)[wq];
     const int js = re & 0xffff, je = (int)((unsigned)re >> 16);
     const bool cand = (jq < nE) && (je == jq + 1);                 // the end of a run of E
-    const float* p = ks_search<RT, 64, false>(keysT, xq);
+    const float* p = t_full ? ks_search<RT, 64, false, true>(keysT, xq) : ks_search<RT, 64, false, false>(keysT, xq);
     const int rt = *reinterpret_cast<const int*>(p + LT::REGION);   // p is the first key of its run: start == L
     const bool tie = (*p == xq);
     const int L = rt & 0xffff;
@@ -318,7 +320,7 @@ __device__ __forceinline__ void rank_pair_phase(const float* keysT, const float*
     const int w = T_IS_A ? 2 * nT - U - L : L + U;
     s_lane += cand ? (unsigned)__mul24(e, w) : 0u;
     const unsigned te = cand ? (unsigned)__mul24(t, e) : 0u;
-    tie3 += (unsigned long long)te * (unsigned long long)(unsigned)(t + e);
+    if (__ballot(te != 0u) != 0ull) tie3 += (unsigned long long)te * (unsigned long long)(unsigned)(t + e);
     const double d_at = exact_quot(U, dT, rT) - exact_quot(je, dE, rE);      // |F_T - F_E|: the sign does not matter
     const double d_before = exact_quot(L, dT, rT) - exact_quot(js, dE, rE);
     const double dd = fmax(fabs(d_at), fabs(d_before));

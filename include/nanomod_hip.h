@@ -5,7 +5,12 @@
  * this path is the Python function level of bin/scripts/myDetect.py
  * (SURVEY.md §8b).  Each entry point below names the reference lines it
  * replaces.  Plain pointers and sizes only; no exceptions cross the ABI; the
- * library keeps no global mutable state and never retains caller buffers.
+ * library never retains caller buffers.  Process-wide state it does keep, all
+ * of it thread-safe and none of it result-affecting: per-device caches of the
+ * CU count and of each kernel's occupancy (atomics, idempotent), and one HIP
+ * memory pool per device, owned by the library, from which the scratch of the
+ * large-position pass is allocated stream-ordered (freed slabs stay cached in
+ * that pool until nmod_trim_scratch(); the device's default pool is not touched).
  *
  * Data layout: the tested positions, in the
  * reference's iteration order (sorted (chrom,strand), then ascending
@@ -133,6 +138,19 @@ int nmod_detect_batch(const nmod_params* prm, int64_t npos,
                       const int32_t* run_id,
                       void* workspace, int64_t workspace_bytes,
                       nmod_out* out);
+
+/* KS statistic, exact form: with tests == NMOD_TEST_KS only (a mode the reference itself never runs — getKStest always
+ * computes all three tests) ks_d is the correctly rounded exact rational max|c0*n1 - c1*n0| / (n0*n1); ks_2samp forms
+ * max|fl(c0/n0) - fl(c1/n1)|, which can differ from it by <= 2 ulp (<= 4.5e-16 absolute).  With any other test in the
+ * mask (what mtest2 / getKStest / the CLI use) ks_d is the reference's float form bit for bit. */
+
+/* Name of the K1 kernel instance a position with n0 / n1 samples is dispatched to under prm's dtype / tests / method
+ * (e.g. "ks_rank_kernel<16,16,f32>"), from the same size-class functions the dispatcher uses: what bench.py prints as
+ * roofline.kernel and what the rocprofv3 kernel trace shows.  No device work. */
+int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char* buf, int32_t buflen);
+
+/* Returns the slabs cached in the library's scratch pool of `device` to the driver (see the header comment). */
+int nmod_trim_scratch(int32_t device);
 
 /* Replaces combin_pvalues / get_combin_pvalue on a whole KS track
  * (myDetect.py:373-414).  ks_d is only read when nb == 0 (:413). */

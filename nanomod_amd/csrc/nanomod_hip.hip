@@ -9,6 +9,8 @@
 #include <vector>
 #include <string>
 #include <stdio.h>
+#include <atomic>
+#include <mutex>
 
 #include "../../include/nanomod_hip.h"
 #include "rank_stats.hpp"
@@ -35,13 +37,21 @@ struct EvTimer {
   int used[NMOD_KERNEL_COUNT];
 };
 
+// A slot counts only when BOTH of its events were recorded: a failed hipEventRecord drops the sample (and is
+// remembered in g_last_hip) instead of leaving an event pair that nmod_evtimer_read would fail on.
 struct ScopedKernelTimer {
   EvTimer* t; int k; hipStream_t s; int slot;
   ScopedKernelTimer(void* timer, int kernel, hipStream_t stream) : t((EvTimer*)timer), k(kernel), s(stream), slot(-1) {
-    if (t && t->used[k] < t->capacity) { slot = t->used[k]; hipEventRecord(t->start[k][slot], s); }
+    if (t && t->used[k] < t->capacity) {
+      const hipError_t e = hipEventRecord(t->start[k][t->used[k]], s);
+      if (e == hipSuccess) slot = t->used[k]; else g_last_hip = e;
+    }
   }
   ~ScopedKernelTimer() {
-    if (slot >= 0) { hipEventRecord(t->stop[k][slot], s); t->used[k] = slot + 1; }
+    if (slot >= 0) {
+      const hipError_t e = hipEventRecord(t->stop[k][slot], s);
+      if (e == hipSuccess) t->used[k] = slot + 1; else g_last_hip = e;
+    }
   }
 };
 
@@ -262,23 +272,39 @@ static int launch_combine(const nmod_params* prm, hipStream_t stream, int64_t np
   return NMOD_OK;
 }
 
-// scratch slab of the large-position pass: stream-ordered allocation, plain hipMalloc as the fallback
+// Scratch slab of the large-position pass: stream-ordered allocation from a memory pool the LIBRARY owns (one per
+// device, created on first use).  Freed slabs stay in that pool (release threshold = max: with the default
+// threshold every batch would return its slab to the OS at the next synchronisation and map it again — measured
+// 20 ms per 1.3 GB); the device's default pool, which the caller's own hipMallocAsync traffic uses, is never
+// touched.  nmod_trim_scratch() returns the cached slabs to the driver.
+constexpr int kMaxDevices = 64;
+static std::mutex g_pool_mutex;
+static hipMemPool_t g_pool[kMaxDevices] = {nullptr};        // guarded by g_pool_mutex
+
+static hipMemPool_t scratch_pool(int dev) {
+  if (dev < 0 || dev >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  if (!g_pool[dev]) {
+    hipMemPoolProps props;
+    memset(&props, 0, sizeof(props));
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipMemPool_t pool = nullptr;
+    if (hipMemPoolCreate(&pool, &props) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    uint64_t keep = UINT64_MAX;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    g_pool[dev] = pool;
+  }
+  return g_pool[dev];
+}
+
 struct DevScratch {
   void* p = nullptr; bool async = false;
-  hipError_t alloc(size_t bytes, hipStream_t s) {
-    // keep freed slabs in the device's default pool: with the default release threshold (0) every batch would
-    // return its slab to the OS at the next synchronisation and map it again (measured: 20 ms per 1.3 GB)
-    static bool pool_tuned[16] = {false};
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && !pool_tuned[dev]) {
-      hipMemPool_t pool;
-      if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-        uint64_t keep = UINT64_MAX;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-      }
-      pool_tuned[dev] = true;
-    }
-    if (hipMallocAsync(&p, bytes ? bytes : 4, s) == hipSuccess) { async = true; return hipSuccess; }
+  hipError_t alloc(size_t bytes, hipStream_t s, int dev) {
+    hipMemPool_t pool = scratch_pool(dev);
+    if (pool && hipMallocFromPoolAsync(&p, bytes ? bytes : 4, pool, s) == hipSuccess) { async = true; return hipSuccess; }
     (void)hipGetLastError();
     p = nullptr;
     return hipMalloc(&p, bytes ? bytes : 4);
@@ -306,12 +332,13 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   Workspace ws = carve(workspace, npos);
   if (!workspace || workspace_bytes < ws.bytes) return NMOD_ERR_WORKSPACE;
 
-  // CU count per device, looked up once (hipGetDeviceProperties is not cheap and this runs every batch)
-  static int cu_cache[64] = {0};
-  int num_cus = (prm->device >= 0 && prm->device < 64) ? cu_cache[prm->device] : 0;
+  // CU count per device, looked up once (the attribute query is not cheap and this runs every batch); an atomic
+  // per device: concurrent first calls both query and store the same value
+  static std::atomic<int> cu_cache[kMaxDevices];
+  int num_cus = (prm->device >= 0 && prm->device < kMaxDevices) ? cu_cache[prm->device].load(std::memory_order_relaxed) : 0;
   if (num_cus <= 0) {
     NMOD_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, prm->device));
-    if (prm->device >= 0 && prm->device < 64) cu_cache[prm->device] = num_cus;
+    if (prm->device >= 0 && prm->device < kMaxDevices) cu_cache[prm->device].store(num_cus, std::memory_order_relaxed);
   }
 
   int tests = prm->tests;
@@ -389,7 +416,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
       unsigned long long total;
       memcpy(&total, &head[2], 8);
       if (nbig > 0) {
-        NMOD_HIP(big_scratch.alloc((size_t)total * (f64_keys ? 8 : 4), stream));
+        NMOD_HIP(big_scratch.alloc((size_t)total * (f64_keys ? 8 : 4), stream, prm->device));
         BigArgs bg;
         memset(&bg, 0, sizeof(bg));
         bg.sig0 = sig0; bg.sig1 = sig1; bg.off0 = off0; bg.off1 = off1; bg.stride0 = ra.stride0; bg.stride1 = ra.stride1;
@@ -413,9 +440,10 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   fa.npos = npos; fa.off0 = off0; fa.off1 = off1; fa.stride0 = ra.stride0; fa.stride1 = ra.stride1;
   fa.ks_num = ws.ks_num; fa.mwu_s = ws.mwu_s; fa.tie = ws.tie; fa.moments = ws.moments; fa.ks_d_ref = all ? ws.ks_d_ref : nullptr;
   fa.tests = tests; fa.want_mstd = prm->want_mstd; fa.out = *out;
-  // what K1 covered: the promised maxima (large positions included); without a large-position pass the class capacity
-  fa.max_n0 = (all && !big_possible) ? (64LL << cmax0) : std::max<int64_t>(max0, 1);
-  fa.max_n1 = (all && !big_possible) ? (64LL << cmax1) : std::max<int64_t>(max1, 1);
+  // what K1 covered: exactly the limits the classifier used (the promised / measured maxima), in every mode —
+  // a position beyond them was skipped by K1 and must be flagged TOO_LARGE here, never read from the workspace
+  fa.max_n0 = std::max<int64_t>(max0, 1);
+  fa.max_n1 = std::max<int64_t>(max1, 1);
   fa.min_cap = 0;
   if (want_comb) {                       // the combine needs the KS track even if the caller does not
     if (!fa.out.ks_d) fa.out.ks_d = ws.tmp_ks_d;
@@ -499,14 +527,16 @@ static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, c
   int rc = detect_device(&dp, npos, ds0, (const int64_t*)d_off0.p, ds1, (const int64_t*)d_off1.p,
                          (const int32_t*)d_run.p, d_ws.p, wsb, &dout);
   if (rc != NMOD_OK) { hipStreamSynchronize(stream); return rc; }
-  const bool no_comb = prm->method == NMOD_METHOD_KS;
+  // copy back exactly the tracks detect_device wrote (same predicate: the KS pair exists iff KS was asked for or
+  // the combine ran, and the combine runs only when both of its outputs were given)
+  const bool want_comb = prm->method != NMOD_METHOD_KS && out->comb_st && out->comb_p;
   for (int k = 0; k < 12; ++k) {
     if (!hp[k]) continue;
-    if (no_comb && (k == 6 || k == 7)) continue;                       // comb_* untouched
+    if (!want_comb && (k == 6 || k == 7)) continue;                    // comb_* untouched
     if (!prm->want_mstd && k >= 8) continue;
     if (k < 2 && !(prm->tests & NMOD_TEST_MWU)) continue;
     if ((k == 2 || k == 3) && !(prm->tests & NMOD_TEST_WELCH)) continue;
-    if ((k == 4 || k == 5) && !(prm->tests & NMOD_TEST_KS) && no_comb) continue;
+    if ((k == 4 || k == 5) && !(prm->tests & NMOD_TEST_KS) && !want_comb) continue;
     NMOD_HIP(hipMemcpyAsync(hp[k], dpv[k], npos * 8, hipMemcpyDeviceToHost, stream));
   }
   if (out->status) NMOD_HIP(hipMemcpyAsync(out->status, dout.status, npos, hipMemcpyDeviceToHost, stream));
@@ -756,15 +786,65 @@ int nmod_synth_fill(const nmod_params* prm, uint64_t seed, int64_t pos_begin, in
   return NMOD_OK;
 }
 
+int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char* buf, int32_t buflen) {
+  int rc = check_params(prm);
+  if (rc != NMOD_OK) return rc;
+  if (!buf || buflen < 8 || n0 <= 0 || n1 <= 0) return NMOD_ERR_INVALID_ARG;
+  if (std::max(n0, n1) > NMOD_MAX_RANKED) return NMOD_ERR_TOO_LARGE;
+  const bool want_comb = prm->method != NMOD_METHOD_KS;
+  int tests = prm->tests | (want_comb ? NMOD_TEST_KS : 0);
+  const bool all = (tests & (NMOD_TEST_MWU | NMOD_TEST_WELCH)) != 0 || prm->want_mstd;
+  const char* dt = prm->dtype == NMOD_DTYPE_F32 ? "f32" : (prm->dtype == NMOD_DTYPE_I16_MILLI ? "i16" : "f64");
+  const int c0 = size_class_of(n0), c1 = size_class_of(n1);
+  // the same decisions classify_kernel / detect_device take (NMOD_DTYPE_F64: the narrower dtype is a property of the data)
+  const bool big = all ? (c0 >= kNumSizeClasses || c1 >= kNumSizeClasses) : (std::min(c0, c1) >= kNumSizeClasses);
+  if (big || prm->dtype == NMOD_DTYPE_F64) { snprintf(buf, buflen, "big_rank_kernel<%s>", dt); return NMOD_OK; }
+  if (!all) {
+    const int cs = std::min(c0, c1);
+    const int LG = ks_lanes_per_group(cs), R = (64 << cs) / LG;
+    snprintf(buf, buflen, "ks_rank_kernel<%d,%d,%s>", R, LG, dt);
+    return NMOD_OK;
+  }
+  const int cls = launch_class_of(c0, c1);
+  if (cls >= kNumGeneralClasses) {
+    const int cm = cls - kNumGeneralClasses;
+    const int LG = 32 / packed_positions_per_wave(cm), R = (64 << cm) / LG;
+    snprintf(buf, buflen, "rank_all_kernel<%d,%d,%s>", R, LG, dt);
+  } else {
+    snprintf(buf, buflen, "rank_pair_kernel<%d,%d,%s>", 1 << c0, 1 << c1, dt);
+  }
+  return NMOD_OK;
+}
+
+int nmod_trim_scratch(int32_t device) {
+  if (device < 0 || device >= kMaxDevices) return NMOD_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  if (g_pool[device]) NMOD_HIP(hipMemPoolTrimTo(g_pool[device], 0));
+  return NMOD_OK;
+}
+
 int nmod_evtimer_create(int32_t capacity_per_kernel, void** timer) {
   if (!timer || capacity_per_kernel <= 0) return NMOD_ERR_INVALID_ARG;
   EvTimer* t = new EvTimer();
   t->capacity = capacity_per_kernel;
   for (int k = 0; k < NMOD_KERNEL_COUNT; ++k) {
     t->used[k] = 0;
-    t->start[k].resize(capacity_per_kernel); t->stop[k].resize(capacity_per_kernel);
+    t->start[k].assign(capacity_per_kernel, nullptr); t->stop[k].assign(capacity_per_kernel, nullptr);
+  }
+  for (int k = 0; k < NMOD_KERNEL_COUNT; ++k) {
     for (int i = 0; i < capacity_per_kernel; ++i) {
-      if (hipEventCreate(&t->start[k][i]) != hipSuccess || hipEventCreate(&t->stop[k][i]) != hipSuccess) return NMOD_ERR_HIP;
+      hipError_t e = hipEventCreate(&t->start[k][i]);
+      if (e == hipSuccess) e = hipEventCreate(&t->stop[k][i]);
+      if (e != hipSuccess) {                       // free what was created so far
+        g_last_hip = e;
+        for (int kk = 0; kk < NMOD_KERNEL_COUNT; ++kk)
+          for (int ii = 0; ii < capacity_per_kernel; ++ii) {
+            if (t->start[kk][ii]) hipEventDestroy(t->start[kk][ii]);
+            if (t->stop[kk][ii]) hipEventDestroy(t->stop[kk][ii]);
+          }
+        delete t;
+        return NMOD_ERR_HIP;
+      }
     }
   }
   *timer = t;

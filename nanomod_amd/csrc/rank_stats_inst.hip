@@ -1,5 +1,6 @@
 // Instantiates K1 for every (R0, R1) size class of one (dtype, tests) pair.
 // Built four times by the Makefile: -DNMOD_INST_DTYPE={0,1} -DNMOD_INST_ALL={0,1}.
+#include <atomic>
 #include "rank_stats.hpp"
 #include "rank_stats_packed.hpp"
 #include "ks_rank.hpp"
@@ -89,10 +90,11 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
     work_items = (work_items + pw - 1) / pw;
   }
   // the dynamic-LDS attribute and the occupancy of a kernel are looked up once per (device, class), not on every launch
-  static int per_cu_cache[16][kClassStride] = {{0}};
+  // (atomics: concurrent first launches of a class both run the queries and store the same number)
+  static std::atomic<int> per_cu_cache[64][kClassStride];
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 15;      // (slot 15 is never trusted)
-  int per_cu = dev < 15 ? per_cu_cache[dev][cls] : 0;
+  const bool cacheable = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+  int per_cu = cacheable ? per_cu_cache[dev][cls].load(std::memory_order_relaxed) : 0;
   if (per_cu <= 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -100,7 +102,7 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kWavesPerBlock, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
-    per_cu_cache[dev][cls] = per_cu;
+    if (cacheable) per_cu_cache[dev][cls].store(per_cu, std::memory_order_relaxed);
   }
   int64_t blocks = (work_items + kWavesPerBlock - 1) / kWavesPerBlock;
   int64_t cap = (int64_t)num_cus * per_cu;

@@ -44,6 +44,18 @@ def _worker(rank, world, port, npos, nb, method, q):
     for k, v in mine.items():
         got = np.zeros(0) if v is None else v.numpy()
         assert got.shape[0] == hi - lo and np.array_equal(got, out[k].numpy()[lo:hi], equal_nan=True), (rank, k)
+    # block-cyclic pipeline (what bench.py --gpus N times): rounds of `world` blocks, the all-gather of a round issued
+    # asynchronously behind its kernels; two steps on one state object (buffer reuse across steps)
+    tracks = ('ks_p', 'comb_p', 'comb_st')
+    for chunks in (1, 3):
+        state = sharding.PipelinedGather(npos, world, chunks, tracks, 'cpu')
+        for _ in range(2):
+            sharding.pipelined_detect(lambda c, lo, hi: compute(lo, hi), state, nb)
+        piped = state.result()
+        for k in tracks:
+            assert np.array_equal(piped[k].numpy(), out[k].numpy(), equal_nan=True), (rank, chunks, k)
+        parts = sharding.pipelined_detect(lambda c, lo, hi: compute(lo, hi), state, nb, gather=False)
+        assert len(parts) == chunks
     q.put((rank, {k: v.numpy().copy() for k, v in out.items()}))
     dist.barrier()
     dist.destroy_process_group()
@@ -67,6 +79,16 @@ def test_sharded_equals_unsharded(npos, nb, method):
     for r in range(world):
         for k in ('ks_p', 'comb_p', 'comb_st'):
             assert np.array_equal(results[r][k], full[k], equal_nan=True), (r, k)
+
+
+def test_cyclic_blocks_tile_the_genome():
+    from nanomod_amd import sharding
+    for npos, world, chunks in ((1000, 2, 4), (1001, 8, 3), (5, 4, 2), (4600000, 8, 4)):
+        B = sharding.cyclic_block_len(npos, world, chunks)
+        cuts = [sharding.cyclic_block(npos, world, r, chunks, c) for c in range(chunks) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == npos
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(len(cuts) - 1))
+        assert all(hi - lo <= B for lo, hi in cuts)
 
 
 def test_balanced_bounds_cover_and_balance():

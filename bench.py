@@ -245,7 +245,16 @@ def main():
             ab = float(np.max(np.abs(g[fin] - e[fin]))) if fin.any() else 0.0
             verify['max_rel_err_' + k] = rel
             verify['max_abs_err_' + k] = ab
-            ok = ok and same_special and (ab <= 1e-6 if k.endswith('_p') else rel <= 1e-9 or ab <= 4.5e-16)
+            # the gates of tests/helpers.py: p-values 1e-9 relative and 1e-6 absolute (north_star), statistics 1e-9
+            # relative + 1e-12 absolute, D within 4.5e-16 (KS-only mode: the exact rational; bit-exact with all tests)
+            err = np.abs(g[fin] - e[fin])
+            if k.endswith('_p'):
+                good = bool(np.all(err <= 1e-9 * np.abs(e[fin]) + 1e-300)) and ab <= 1e-6
+            elif k == 'ks_d':
+                good = ab <= 4.5e-16
+            else:
+                good = bool(np.all(err <= 1e-9 * np.abs(e[fin]) + 1e-12))
+            ok = ok and same_special and good
         if gather:                                   # the gathered track holds rank 0's first block at its natural place
             full = state.result()
             ok = ok and bool(torch.equal(full['ks_p'][blocks[0]['lo_h']:blocks[0]['lo_h'] + vn], blocks[0]['out']['ks_p'][:vn]))
@@ -339,10 +348,18 @@ def main():
         }
         if not args.no_cpu and world == 1:           # the CPU baseline is an N=1 figure
             line['cpu_baseline'] = cpu_baseline(cpu_rows[0], cpu_rows[1], n0, n1, method, 7 if args.all_tests else 1, usable_cpus())
-        print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the last line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':

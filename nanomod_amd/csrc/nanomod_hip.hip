@@ -808,8 +808,8 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
   const int cls = launch_class_of(c0, c1);
   if (cls >= kNumGeneralClasses) {
     const int cm = cls - kNumGeneralClasses;
-    const int LG = 32 / packed_positions_per_wave(cm), R = (64 << cm) / LG;
-    snprintf(buf, buflen, "rank_all_kernel<%d,%d,%s>", R, LG, dt);
+    const int LG = ks_lanes_per_group(cm), R = (64 << cm) / LG;
+    snprintf(buf, buflen, "rank_hist_kernel<%d,%d,%s>", R, LG, dt);
   } else {
     snprintf(buf, buflen, "rank_pair_kernel<%d,%d,%s>", 1 << c0, 1 << c1, dt);
   }

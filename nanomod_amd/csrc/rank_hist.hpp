@@ -1,0 +1,529 @@
+// K1, all-tests form for positions whose two groups fall in the same capacity class (+-1)
+// (tests mask = MWU | Welch | KS: what getKStest computes for every position, myDetect.py:327-343).
+//
+// Same skeleton as the KS-only kernel (ks_rank.hpp): the smaller group S (m samples) is sorted in registers and
+// written to wave-private LDS, every sample x of the other group Q (q samples) finds L = #{s < x} and
+// U = #{s <= x} by binary search, and one LDS atomic per sample builds the histograms of L and U.  With
+// cumL / cumU their prefix sums everything the three tests need follows without sorting Q against S:
+//   * KS          exact integer max |c0 n1 - c1 n0| over the pooled points from the two candidates per run end
+//                 k of S, (cumL(k-1), k) and (cumU(k), k)  (derivation: ks_rank.hpp).  ks_2samp forms D as
+//                 max |fl(c0/n0) - fl(c1/n1)|; a larger integer numerator always gives a larger float value
+//                 (they differ by >= 1/(n0 n1) >> ulp), so the float form is evaluated ONLY for the candidates
+//                 that reach the integer maximum — the maximum of those is the reference's D bit for bit.
+//   * Mann-Whitney sum_{x in Q} (L(x) + U(x)) = sum_{k=1..C} (2q - cumL(k-1) - cumU(k-1))   [Abel summation]
+//                 = sum_{a in group 1} (#{b < a} + #{b <= a}) when Q is group 1, and 2mq minus it when Q is group 2.
+//   * tie term    sum over pooled tie groups of t^3 - t = 3 pp(S) + 3 pp(Q) + 3 sum_{runs of S tied with Q} a b (a + b),
+//                 pp(X) = sum over the elements of X of p (p - 1), p = place of the element in its run of equal keys;
+//                 a = length of the run of S, b = cumL(k-1) - cumU(k-1) at its end k = the samples of Q equal to it.
+//   * Welch       fp64 shifted one-pass moments of both groups on the way (S from the registers before the sort,
+//                 Q as its samples stream through the ranking rounds).
+// pp(S) comes from the sorted registers.  pp(Q) needs equal samples of Q next to each other, but not a second
+// sort: S acts as the splitter set of a sample sort.  Samples with different L are already ordered, so
+// Q is scattered to index cumL(L - 1) + (arrival number within its bin, returned by the histogram atomic) —
+// into the LDS words of S's keys, which are dead by then — read back R consecutive keys per lane, and finished
+// by as many odd-even transposition phases as the fullest bin holds samples (~1 sample per bin: 8-10 phases of
+// 2 instructions per key against the 44 of a full network); tie-heavy batches (a bin above kMaxCleanPhases)
+// run the full network on the scattered keys instead.
+// Against rank_all_kernel (both groups sorted by one network, 2 positions per wave, a 72-instruction ranking
+// step per sample of group 2 with four exact fp64 quotients): 4 positions per wave and ~700 instead of ~1000
+// VALU instructions per 200 v 200 position.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ks_rank.hpp"
+#include "rank_all.hpp"      // pad_run_pp
+
+namespace nmod {
+
+constexpr int kMaxCleanPhases = 24;
+
+// sum over the lane's elements of p (p - 1), p = 1-based place of the element in its run of equal keys; y = the
+// sorted keys of a group in the blocked layout (element gl * R + r in register r of lane gl)
+template <int R, int LG>
+__device__ __forceinline__ unsigned seg_tie_pp(float (&y)[R], int gl, int lane) {
+  constexpr int N = R * LG;
+  // LG == 8: two groups share one DPP row: the second group's scan values are biased by N, so whatever leaks in
+  // from the first group (< N) can never win a max
+  const int bias = (LG == 8 && (lane & 8)) ? N : 0;
+  const float nanv = __builtin_nanf("");
+  float prev_last = lane_prev(y[R - 1], nanv);
+  prev_last = (gl == 0) ? nanv : prev_last;
+  int run = bias;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float p = (r == 0) ? prev_last : y[r - 1];
+    run = (y[r] != p) ? (gl * R + r + bias) : run;
+  }
+  int carry = lane_prev_i(seg_scan_max_i32<LG>(run), 0);
+  carry = (gl == 0) ? bias : carry;
+#pragma unroll
+  for (int r = 0; r < R; ++r) asm volatile("" : "+v"(y[r]));     // (keeps the first sweep's comparison masks out of SGPRs)
+  run = carry;
+  unsigned acc = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float p = (r == 0) ? prev_last : y[r - 1];
+    const int e = gl * R + r + bias;
+    run = (y[r] != p) ? e : run;
+    const unsigned pm1 = (unsigned)(e - run);
+    acc += __umul24(pm1, pm1) + pm1;
+  }
+  return acc;
+}
+
+// `phases` odd-even transposition phases over the R x LG keys of every group of the wave (blocked layout): enough to
+// sort a sequence whose elements are at most phases - 1 places from home
+template <int R, int LG>
+__device__ __forceinline__ void seg_oddeven_phases(float (&y)[R], int gl, int phases) {
+  const float inf = __builtin_inff();
+#pragma unroll 1
+  for (int ph = 0; ph < phases; ph += 2) {
+#pragma unroll
+    for (int r = 0; r + 1 < R; r += 2) ce(y[r], y[r + 1]);
+#pragma unroll
+    for (int r = 1; r + 1 < R; r += 2) ce(y[r], y[r + 1]);
+    float nx = lane_next(y[0], inf);                    // key 0 of the next lane / key R - 1 of the previous one
+    float pv = lane_prev(y[R - 1], -inf);
+    nx = (gl == LG - 1) ? inf : nx;                     // (group boundaries)
+    pv = (gl == 0) ? -inf : pv;
+    const float lo = fmaxf(y[0], pv), hi = fminf(y[R - 1], nx);
+    y[0] = lo; y[R - 1] = hi;
+  }
+}
+
+template <int LG>
+__device__ __forceinline__ unsigned pos_allsum_u32(unsigned v) {     // sum over the LG lanes of a group, in every lane
+  v += (unsigned)dpp_i<NMOD_QP(1, 0, 3, 2), 0xf, 0xf, true>(0, (int)v);
+  v += (unsigned)dpp_i<NMOD_QP(2, 3, 0, 1), 0xf, 0xf, true>(0, (int)v);
+  v += (unsigned)dpp_i<kDppRowHalfMirror, 0xf, 0xf, true>(0, (int)v);
+  if constexpr (LG >= 16) v += (unsigned)dpp_i<kDppRowMirror, 0xf, 0xf, true>(0, (int)v);
+  if constexpr (LG >= 32) v += (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
+  return v;
+}
+
+template <int LG>
+__device__ __forceinline__ double seg_allmax_f64(double v) {
+  v = fmax(v, dpp_f64_row(v, 0)); v = fmax(v, dpp_f64_row(v, 1)); v = fmax(v, dpp_f64_row(v, 2));
+  if constexpr (LG >= 16) v = fmax(v, dpp_f64_row(v, 3));
+  if constexpr (LG >= 32) v = fmax(v, xor16_f64(v));
+  return v;
+}
+
+// fl(c / n) for an integer 0 <= c <= n <= 4096, r = fl(1 / n): correctly rounded (checked exhaustively on the host)
+__device__ __forceinline__ double hist_exact_quot(int c, double n, double r) {
+  const double dc = (double)c;
+  const double q0 = __dmul_rn(dc, r);
+  const double rem = __fma_rn(-q0, n, dc);
+  return __fma_rn(rem, r, q0);
+}
+
+template <int R, int LG, int DTYPE>
+__global__ __launch_bounds__(64 * kWavesPerBlock, (R <= 16 ? 4 : 2))
+void rank_hist_kernel(RankStatsArgs args) {
+  static_assert(LG == 8 || LG == 16 || LG == 32, "lanes per sorted group");
+  static_assert(R >= 8 && R <= 32 && (R & (R - 1)) == 0, "registers per lane");
+  static_assert(R * LG <= 1024, "32-bit tie sums and 15-bit counts need groups of at most 1024 samples");
+  constexpr int PW = 64 / LG;                  // positions per wave
+  constexpr int C = R * LG;
+  constexpr int LOG_R = (R == 8) ? 3 : (R == 16) ? 4 : 5;
+  using Lay = KsLayout<R, LG>;
+  constexpr int ROW = Lay::ROW;
+  constexpr int POS_WORDS = ks_rank_pos_words(R, LG);
+  constexpr int HIST_OFF = Lay::REGION;        // words from key 0 to bin 0
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gl = lane & (LG - 1);
+  const int slot = lane / LG;
+  const int seg_base = lane & ~(LG - 1);
+  float* keys = lds_all + (wave * PW + slot) * POS_WORDS;        // sorted S of this lane's position (KsLayout)
+  unsigned* hist = reinterpret_cast<unsigned*>(keys + HIST_OFF);    // bin k: (#L == k) << 16 | (#U == k); later the prefix table
+  const int e0 = gl * R;                                             // first key / bin this lane owns
+
+  const float inf = __builtin_inff();
+  const float big = 3.4028234663852886e38f;
+  LaneSel sel;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) sel.s[b] = ((lane >> b) & 1) ? inf : -inf;
+  for (int r = gl; r < R; r += LG) keys[r * ROW + Lay::END] = inf;   // the spare column: key C (and beyond) = +inf
+
+  int64_t count = args.npos;
+  const int32_t* list = nullptr;
+  if (args.pos_list) {
+    count = args.class_meta[args.class_id];
+    list = args.pos_list + args.class_meta[kClassStride + args.class_id];
+  }
+  const int64_t items = (count + PW - 1) / PW;
+  const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
+
+  // One work item = the PW positions of a wave.  S = the smaller group (ties: group 1).
+  struct Item { bool valid, swap; int m, q; int64_t pos, off_s, off_q; };
+  auto describe = [&](int64_t it) {
+    Item d;
+    const int64_t li = it * PW + slot;
+    d.valid = it < items && li < count;
+    d.pos = d.valid ? (list ? (int64_t)list[li] : li) : 0;
+    int64_t o0 = 0, o1 = 0; int n0 = 0, n1 = 0;
+    if (d.valid) {
+      if (args.stride0 > 0) { o0 = (int64_t)((uint64_t)(uint32_t)d.pos * (uint64_t)(uint32_t)args.stride0); n0 = (int)args.stride0; }
+      else { o0 = args.off0[d.pos]; n0 = (int)(args.off0[d.pos + 1] - o0); }
+      if (args.stride1 > 0) { o1 = (int64_t)((uint64_t)(uint32_t)d.pos * (uint64_t)(uint32_t)args.stride1); n1 = (int)args.stride1; }
+      else { o1 = args.off1[d.pos]; n1 = (int)(args.off1[d.pos + 1] - o1); }
+    }
+    d.swap = n1 < n0;
+    d.m = d.swap ? n1 : n0; d.q = d.swap ? n0 : n1;
+    d.off_s = d.swap ? o1 : o0; d.off_q = d.swap ? o0 : o1;
+    return d;
+  };
+  using Q4Raw = typename std::conditional<DTYPE == 0, KsF4, KsS4>::type;
+  using Q1Raw = typename std::conditional<DTYPE == 0, float, int16_t>::type;
+  // unconditional loads (see ks_rank_kernel): lanes without samples read a block of FLT_MAX
+  auto load_q4 = [&](const void* sig, int64_t off, int idx, bool have) -> Q4Raw {
+    const Q1Raw* src = have ? reinterpret_cast<const Q1Raw*>(sig) + off + idx : reinterpret_cast<const Q1Raw*>(kKsBig4);
+    return ks_global_load<Q4Raw>(src);
+  };
+  auto load_q1 = [&](const void* sig, int64_t off, int idx, bool have) -> Q1Raw {
+    return ks_global_load<Q1Raw>(have ? reinterpret_cast<const Q1Raw*>(sig) + off + idx : reinterpret_cast<const Q1Raw*>(kKsBig4));
+  };
+
+  // fixed-stride batches: every position has the same sizes, fl(1/m) and fl(1/q) are taken once
+  const bool uniform = args.stride0 > 0 && args.stride1 > 0;
+  double rm_u = 0.0, rq_u = 0.0;
+  if (uniform) {
+    const int64_t a0 = args.stride0 < args.stride1 ? args.stride0 : args.stride1;
+    const int64_t a1 = args.stride0 < args.stride1 ? args.stride1 : args.stride0;
+    rm_u = 1.0 / (double)a0; rq_u = 1.0 / (double)a1;
+  }
+
+  Item cur = describe(wave_global);
+  float x[R];
+  {
+    KsRows<R, LG, DTYPE> first;
+    first.request(cur.swap ? args.sig1 : args.sig0, cur.off_s, cur.m, gl);
+    first.finish(x, cur.m, gl);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+
+  for (int64_t it = wave_global; it < items; it += wave_stride) {
+    const bool valid = cur.valid;
+    const int64_t pos = cur.pos;
+    const int m = cur.m, q = cur.q;
+    const bool swap = cur.swap;
+    const void* sig_q = swap ? args.sig0 : args.sig1;
+    const int64_t off_q = cur.off_q;
+
+    // ---- ranking schedule: full rounds of one 16-byte load per lane, then the remaining < 4*LG samples one per lane
+    const int full = q / (4 * LG);
+    const int tail = (q - full * (4 * LG) + LG - 1) / LG;
+    int full_w = 0, tail_w = 0;
+#pragma unroll
+    for (int s = 0; s < PW; ++s) {
+      full_w = max(full_w, __builtin_amdgcn_readlane(full, s * LG));
+      tail_w = max(tail_w, __builtin_amdgcn_readlane(tail, s * LG));
+    }
+    // requests that the sort hides: this item's first rounds of Q and its first sample
+    Q4Raw ra = load_q4(sig_q, off_q, 4 * gl, 0 < full);
+    Q1Raw rt = load_q1(sig_q, off_q, full * (4 * LG) + gl, full * (4 * LG) + gl < q);
+    const Q1Raw rk = load_q1(sig_q, off_q, 0, q > 0);                       // the shift of Q's moments
+
+    // ---- S: moments, sort, keys to LDS, ties inside S
+    {
+      double mean, m2;
+      seg_moments<R, LG, DTYPE>(x, m, mean, m2);
+      if (valid && gl == 0) {
+        double* mo = args.moments + pos * 4 + (swap ? 2 : 0);
+        mo[0] = mean; mo[1] = m2;
+      }
+    }
+    seg_sort_any<R, LG>(x, sel, lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) keys[r * ROW + gl] = x[r];
+#pragma unroll
+    for (int r = 0; r < R; ++r) hist[r * ROW + gl] = 0u;
+    if (gl == LG - 1) hist[Lay::END] = 0u;                               // bin C
+    unsigned pp = seg_tie_pp<R, LG>(x, gl, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- rank every Q sample into S and count it in the histograms; keep the sample and the LDS byte offset of its
+    // L-bin inside the position's words (16 bits, two per register) for the scatter
+    bool any_tie = false;
+    float xs[R];                                   // the samples this lane ranked (FLT_MAX where it had none)
+    unsigned la[R / 2];                            // byte offsets of their L-bins from `keys`
+#pragma unroll
+    for (int r = 0; r < R; ++r) xs[r] = big;
+#pragma unroll
+    for (int r = 0; r < R / 2; ++r) la[r] = 0u;
+
+    auto rank_one = [&](float xq, bool have) -> unsigned {
+      const float* lcol;
+      const float* lp = ks_search<R, LG, false, true>(keys, xq, &lcol);
+      const bool eq = (*lp == xq);
+      unsigned* bin = reinterpret_cast<unsigned*>(const_cast<float*>(lp)) + HIST_OFF;
+      if (__ballot(eq) == 0ull) {
+        if (have) atomicAdd(bin, 0x10001u);
+      } else {
+        any_tie = true;
+        const unsigned dl = (unsigned)(uintptr_t)lp - (unsigned)(uintptr_t)lcol;
+        const int step = (dl == (unsigned)((R - 1) * ROW * 4)) ? 1 - (R - 1) * ROW : ROW;
+        const float* up = eq ? lp + step : lp;
+        if (__ballot(*up == xq) != 0ull) up = ks_search<R, LG, true, true>(keys, xq);
+        if (have) {
+          atomicAdd(bin, 0x10000u);
+          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up)) + HIST_OFF, 1u);
+        }
+      }
+      return (unsigned)(uintptr_t)bin - (unsigned)(uintptr_t)keys;      // byte offset inside the position's LDS (< 64 KB)
+    };
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // everything requested before the sort has arrived
+#pragma unroll
+    for (int c = 0; c < R / 4; ++c) {
+      if (c < full_w) {
+        const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
+        const bool have = c < full;
+        float xa[4];
+        if constexpr (DTYPE == 0) { xa[0] = ra.x; xa[1] = ra.y; xa[2] = ra.z; xa[3] = ra.w; }
+        else { xa[0] = have ? (float)ra.x : big; xa[1] = have ? (float)ra.y : big; xa[2] = have ? (float)ra.z : big; xa[3] = have ? (float)ra.w : big; }
+        unsigned ad[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ad[e] = rank_one(xa[e], have); xs[4 * c + e] = xa[e]; }
+        la[2 * c] = ad[0] | (ad[1] << 16);
+        la[2 * c + 1] = ad[2] | (ad[3] << 16);
+        ra = rb;
+      }
+    }
+    // tail rounds: one sample per lane, kept in slot 4 * full + c of the lane (never beyond R - 1: q <= C).  Per
+    // lane: a position with fewer full rounds than the wave's longest reuses the slots of its idle vector rounds.
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < tail_w) {
+        const int idx_now = full * (4 * LG) + c * LG + gl;
+        const bool have = idx_now < q;
+        const float xq = have ? (float)rt : big;
+        const int idx = full * (4 * LG) + (c + 1) * LG + gl;
+        rt = load_q1(sig_q, off_q, idx, idx < q);
+        const unsigned ad = rank_one(xq, have);
+#pragma unroll
+        for (int f = 0; f < R / 4; ++f)
+          if (4 * f + c < R) {
+            const bool me = f == full;
+            xs[4 * f + c] = me ? xq : xs[4 * f + c];
+            unsigned& w = la[(4 * f + c) / 2];
+            w = me ? ((c & 1) ? ((w & 0xffffu) | (ad << 16)) : ((w & 0xffff0000u) | ad)) : w;
+          }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // the next item's S rows: requested here, behind the ranking rounds (16 registers that the rounds need), and
+    // covered by everything that follows
+    const Item nxt = describe(it + wave_stride);
+    KsRows<R, LG, DTYPE> rows_next;
+    rows_next.request(nxt.swap ? args.sig1 : args.sig0, nxt.off_s, nxt.m, gl);
+
+    // ---- histograms -> prefix table in their place: bin k gets  cumL(k-1) << 16 | (a run of S ends at k) << 15 | cumU(k-1)
+    unsigned cum;
+    int maxc;
+    {
+      unsigned h[R];
+#pragma unroll
+      for (int r = 0; r < R - 1; ++r) h[r] = hist[(r + 1) * ROW + gl];     // bins e0 + 1 .. e0 + R - 1
+      h[R - 1] = hist[gl + 1];                                              // bin e0 + R: row 0 of the next column
+      const unsigned h0 = hist[0];
+      unsigned tot = 0, hmax = h0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { tot += h[r]; hmax = max(hmax, h[r]); }
+      cum = seg_exscan_add_u32<LG>(tot, gl) + h0;                           // cumL(e0) << 16 | cumU(e0)
+      maxc = (int)(wave_max_u32(hmax) >> 16);                               // fullest L-bin of the wave's positions
+      unsigned c2 = cum;
+      float sk = keys[gl];                                                  // key e0
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float up = (r == R - 1) ? keys[gl + 1] : keys[(r + 1) * ROW + gl];   // key e0 + r + 1 (or the +inf sentinel)
+        const unsigned w = c2 | ((sk != up) ? 0x8000u : 0u);
+        if (r < R - 1) hist[(r + 1) * ROW + gl] = w; else hist[gl + 1] = w;       // bin e0 + r + 1
+        c2 += h[r];
+        sk = up;
+      }
+      if (gl == 0) hist[0] = 0u;                                            // bin 0: nothing before it
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- scatter Q by bin into the key words of S (dead from here on: the table carries its run ends).  The high
+    // half of a bin's table word is its bump allocator: afterwards it holds cumL(k).  Q's moments on the way, shifted
+    // by its first sample (a slot without a sample adds 0).
+    {
+      const float kqf = (q > 0) ? (float)rk : 0.0f;
+      const double KQ = (double)kqf;
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool have = xs[r] != big;
+        const unsigned ad = (r & 1) ? (la[r / 2] >> 16) : (la[r / 2] & 0xffffu);
+        if (have) {
+          unsigned* tb = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(keys) + ad);
+          const int i = (int)(atomicAdd(tb, 0x10000u) >> 16);
+          keys[__mul24(i & (R - 1), ROW) + (i >> LOG_R)] = xs[r];
+        }
+        const double d = (double)(have ? xs[r] : kqf) - KQ;
+        s1 += d;
+        s2 = __fma_rn(d, d, s2);
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      s1 = seg_allsum_f64<LG>(s1);
+      s2 = seg_allsum_f64<LG>(s2);
+      const double dn = (double)q;
+      double mu = KQ + s1 / dn;
+      double qq = s2 - s1 * s1 / dn;
+      if constexpr (DTYPE != 0) { mu = mu / 1000.0; qq = qq * 1e-6; }
+      if (valid && gl == 0) {
+        double* mo = args.moments + pos * 4 + (swap ? 0 : 2);
+        mo[0] = mu; mo[1] = qq;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- pass over the lane's bins (from the table): KS numerator, Mann-Whitney sum, ties between S and Q
+    // table words of bins e0 .. e0 + R + 1: high half = cumL(bin) now, low 15 bits = cumU(bin - 1), bit 15 = run end
+    unsigned tw[R + 2];
+#pragma unroll
+    for (int r = 0; r < R; ++r) tw[r] = hist[r * ROW + gl];
+    tw[R] = hist[gl + 1];
+    tw[R + 1] = (gl == LG - 1) ? (unsigned)q : hist[ROW + gl + 1];          // (cumU(C) = q)
+    // start of the run of S that is open when the lane's first bin begins (only read where Q ties with S)
+    int start = 0;
+    if (__ballot(any_tie) != 0ull) {
+      int ls = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) ls = (tw[r + 1] & 0x8000u) ? (e0 + r + 1) : ls;   // a run ends at key e0 + r: the next starts at e0 + r + 1
+      const int bias = (LG == 8 && (lane & 8)) ? C + 1 : 0;
+      int sc = lane_prev_i(seg_scan_max_i32<LG>(ls + bias), 0) - bias;
+      start = (gl == 0 || sc < 0) ? 0 : sc;
+    }
+    unsigned best;
+    unsigned acc_l = 0, acc_u = 0, ab3 = 0;
+    {
+      int hi = (gl == 0) ? __mul24((int)(tw[1] & 0x7fffu), m) : 0, lo = 0;  // k = 0: (cumU(0), 0)
+      int nkq = -__mul24(e0, q);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {                                          // bin k = e0 + r + 1
+        const bool run_end = (tw[r + 1] & 0x8000u) != 0u;
+        const int cl = (int)(tw[r] >> 16), cu = (int)(tw[r + 1] & 0x7fffu);  // cumL(k-1), cumU(k-1)
+        const int cun = (int)(tw[r + 2] & 0x7fffu);                          // cumU(k)
+        const int k = e0 + r + 1;
+        nkq -= q;
+        acc_l += (unsigned)cl; acc_u += (unsigned)cu;
+        const int cand_b = __mul24(cl, m) + nkq;                             // (cumL(k-1), k)
+        const int cand_a = __mul24(cun, m) + nkq;                            // (cumU(k), k)
+        const int b = run_end ? cl - cu : 0;                                 // samples of Q equal to the run of S ending at k
+        const int a = k - start;
+        ab3 += (unsigned)__mul24(__mul24(a, b), a + b);
+        start = run_end ? k : start;
+        const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
+        hi = max(hi, max(ca, cb));
+        lo = min(lo, min(ca, cb));
+      }
+      best = (unsigned)max(hi, -lo);
+    }
+    const unsigned lbest = best;
+    best = seg_allmax_u32<LG>(best);
+
+    // ---- the float form of D, only for the candidates that reach the integer maximum: the lanes of a position
+    // take the bins of one such lane at a time from the table
+    double dmax = 0.0;
+    {
+      const double dm = (double)m, dq = (double)q;
+      double rm = rm_u, rq = rq_u;
+      if (!uniform) { rm = 1.0 / dm; rq = 1.0 / dq; }
+      unsigned long long hits = __ballot(lbest == best && best != 0u);
+      const unsigned long long seg_mask = ((1ull << LG) - 1ull) << seg_base;
+#pragma unroll 1
+      while (hits != 0ull) {
+        const unsigned long long mine = hits & seg_mask;
+        const bool act = mine != 0ull;
+        const int hl = act ? (__ffsll((long long)mine) - 1 - seg_base) : 0;   // the lane of this position whose bins are examined
+#pragma unroll
+        for (int j = 0; j < (R + LG - 1) / LG; ++j) {
+          const int rr = gl + j * LG;
+          const int k = hl * R + rr + 1;
+          const bool in = act && rr < R;
+          const unsigned wp = hist[Lay::word(in ? k - 1 : 0)];
+          const unsigned w = hist[Lay::word(in ? k : 0)];
+          const unsigned wn = hist[Lay::word((in && k < C) ? k + 1 : 0)];
+          const int cl = (int)(wp >> 16), cu = (k < C) ? (int)(wn & 0x7fffu) : q;
+          const bool run_end = (w & 0x8000u) != 0u;
+          const int nkq = -__mul24(k, q);
+          const int cand_b = __mul24(cl, m) + nkq, cand_a = __mul24(cu, m) + nkq;
+          const bool hb = in && run_end && (unsigned)abs(cand_b) == best;
+          const bool ha = in && run_end && (unsigned)abs(cand_a) == best;
+          if (__ballot(ha || hb) != 0ull) {
+            const double fk = hist_exact_quot(k, dm, rm);
+            const double db = fabs(fk - hist_exact_quot(cl, dq, rq));
+            const double da = fabs(fk - hist_exact_quot(cu, dq, rq));
+            dmax = hb ? fmax(dmax, db) : dmax;
+            dmax = ha ? fmax(dmax, da) : dmax;
+          }
+        }
+        if (act && hl == 0 && gl == 0) {                                     // the candidate (cumU(0), 0) of the first lane
+          const int cu0 = (int)(hist[Lay::word(1)] & 0x7fffu);
+          if ((unsigned)__mul24(cu0, m) == best) dmax = fmax(dmax, hist_exact_quot(cu0, dq, rq));
+        }
+        // drop the examined lane of every position
+        const unsigned long long low = mine & (0ull - mine);                  // (lowest set bit of this position's hits)
+        unsigned long long drop = 0ull;
+#pragma unroll
+        for (int s = 0; s < PW; ++s) {
+          const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)low, s * LG);
+          const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(low >> 32), s * LG);
+          drop |= ((unsigned long long)hi32 << 32) | lo32;
+        }
+        hits &= ~drop;
+      }
+      dmax = seg_allmax_f64<LG>(dmax);
+    }
+
+    // ---- Q in sorted order: read the scattered keys back, finish inside the bins, count its ties
+    __builtin_amdgcn_wave_barrier();
+    float y[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float v = keys[r * ROW + gl];
+      y[r] = (e0 + r < q) ? v : inf;                                          // words past q still hold keys of S
+    }
+    if (maxc <= kMaxCleanPhases) {
+      if (maxc > 1) seg_oddeven_phases<R, LG>(y, gl, maxc);
+    } else {
+      seg_sort_any<R, LG>(y, sel, lane);
+    }
+    pp += seg_tie_pp<R, LG>(y, gl, lane);
+
+    // ---- totals of the position
+    const unsigned PP = pos_allsum_u32<LG>(pp);
+    const unsigned AB = pos_allsum_u32<LG>(ab3);
+    const unsigned AL = pos_allsum_u32<LG>(acc_l);
+    const unsigned AU = pos_allsum_u32<LG>(acc_u);
+    if (valid && gl == 0) {
+      // the +inf pads of each group form one run of C - n keys: take its sum_{p} p (p - 1) out
+      const unsigned long long pads = (unsigned long long)pad_run_pp(C - m) + (unsigned long long)pad_run_pp(C - q);
+      // sum_{x in Q} (L + U) = sum_{k=1..C} (2q - cumL(k-1) - cumU(k-1))
+      const unsigned long long slu = 2ull * (unsigned long long)C * (unsigned long long)q - (unsigned long long)AL - (unsigned long long)AU;
+      // mwu_s = sum_{a in group 1} (#{b < a} + #{b <= a}): Q is group 1 when swapped, else count from group 2's side
+      args.mwu_s[pos] = swap ? slu : 2ull * (unsigned long long)m * (unsigned long long)q - slu;
+      args.tie[pos] = 3ull * ((unsigned long long)PP - pads) + 3ull * (unsigned long long)AB;
+      args.ks_d_ref[pos] = (m > 0 && q > 0) ? dmax : 0.0;
+      args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    rows_next.finish(x, nxt.m, gl);
+    cur = nxt;
+  }
+}
+
+}  // namespace nmod

@@ -5,6 +5,7 @@
 #include "rank_stats_packed.hpp"
 #include "ks_rank.hpp"
 #include "rank_all.hpp"
+#include "rank_hist.hpp"
 #include "rank_stats_launch.hpp"
 
 #ifndef NMOD_INST_DTYPE
@@ -46,11 +47,11 @@ KernelFn pick(int c0, int c1) {
 }
 KernelFn pick_packed(int cm) {
   switch (cm) {
-    case 0: return rank_all_kernel<8, 8, DT>;
-    case 1: return rank_all_kernel<16, 8, DT>;
-    case 2: return rank_all_kernel<16, 16, DT>;
-    case 3: return rank_all_kernel<32, 16, DT>;
-    default: return rank_all_kernel<32, 32, DT>;
+    case 0: return rank_hist_kernel<8, 8, DT>;
+    case 1: return rank_hist_kernel<16, 8, DT>;
+    case 2: return rank_hist_kernel<16, 16, DT>;
+    case 3: return rank_hist_kernel<32, 16, DT>;
+    default: return rank_hist_kernel<32, 32, DT>;
   }
 }
 #else

@@ -2,10 +2,10 @@
 //
 // Size classes.  A group of n samples needs capacity 64 << c (c = 0..5: 64 .. 2048).
 //   general class  c0 * 6 + c1      (0..35): rank_pair_kernel<1<<c0, 1<<c1> (rank_all.hpp), 64 lanes per group;
-//   packed class   36 + cm          (36..40): rank_all_kernel (rank_all.hpp), both groups in capacity 64 << cm,
+//   packed class   36 + cm          (36..40): rank_hist_kernel (rank_hist.hpp), both groups in capacity 64 << cm,
 //                  used when max(c0,c1) = cm <= 4 and min(c0,c1) >= cm - 1:
-//                  cm 0..1 -> (R, LG) = (8,8) (16,8): four positions per wave; cm 2..3 -> (16,16) (32,16): two;
-//                  cm 4 -> (32,32): one.
+//                  cm 0..1 -> (R, LG) = (8,8) (16,8): eight positions per wave; cm 2..3 -> (16,16) (32,16): four;
+//                  cm 4 -> (32,32): two.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,10 +31,11 @@ __host__ __device__ inline int launch_class_of(int c0, int c1) {
   if (cm <= 4 && cl >= cm - 1) return kNumGeneralClasses + cm;
   return c0 * kNumSizeClasses + c1;
 }
-inline int packed_positions_per_wave(int cm) { return cm <= 1 ? 4 : (cm <= 3 ? 2 : 1); }
 // KS-only classes: capacity 64 << cs sorted in (R, LG) = (8,8) (16,8) (16,16) (32,16) (32,32) (32,64)
 inline int ks_lanes_per_group(int cs) { return cs <= 1 ? 8 : (cs == 2 ? 16 : (8 << (cs - 2))); }
 inline int ks_positions_per_wave(int cs) { return 64 / ks_lanes_per_group(cs); }
+// packed all-tests classes (rank_hist.hpp): the same (R, LG) per capacity as the KS-only classes 0..4
+inline int packed_positions_per_wave(int cm) { return ks_positions_per_wave(cm); }
 inline size_t rank_stats_lds_bytes(int cls, bool all) {
   size_t words;
   if (cls >= kKsClassBase) {
@@ -45,9 +46,9 @@ inline size_t rank_stats_lds_bytes(int cls, bool all) {
     return (size_t)ks_positions_per_wave(cs) * w * 4 * 4;                   // bytes, 4 waves per block
   } else if (cls >= kNumGeneralClasses) {
     int cm = cls - kNumGeneralClasses;
-    size_t LG = 32u / (size_t)packed_positions_per_wave(cm), R = (64u << cm) / LG;
-    size_t w = 4 * R * (LG + 1);                                             // rank_all_pos_words (rank_all.hpp)
-    if (LG == 8) while ((w & 31) != 16) ++w;
+    size_t LG = (size_t)ks_lanes_per_group(cm), R = (64u << cm) / LG;
+    size_t w = 2 * R * (LG + 1);                                             // ks_rank_pos_words (ks_rank.hpp)
+    if (LG <= 16) while ((w & 31) != LG) ++w;
     return (size_t)packed_positions_per_wave(cm) * w * 4 * 4;
   } else {
     // rank_pair_kernel (rank_all.hpp): keys + runs of both groups, R x 65 words each

@@ -631,9 +631,13 @@ def test_full_size_properties(nm):
     r1 = {k: v.clone() for k, v in det.run(a, b, rid, stride0=n, stride1=n, npos=P).items()}
     r2 = det.run(b, a, rid, stride0=n, stride1=n, npos=P)
     torch.cuda.synchronize()
-    for k in ('ks_d', 'ks_p', 'mwu_u', 'mwu_p', 't_p', 'comb_p', 'comb_st'):
+    # the rank statistics are integers: bit-equal under the swap.  The moments of a group are summed in a different
+    # order when it is the sorted group (registers) and when it is the ranked one (ranking rounds): t and its p-value
+    # agree to rounding (the same 1e-11 / 1e-9 gates as against the oracle), not bit for bit
+    for k in ('ks_d', 'ks_p', 'mwu_u', 'mwu_p', 'comb_p', 'comb_st'):
         assert torch.equal(r1[k], r2[k]), k
-    assert torch.equal(r1['t_t'], -r2['t_t'])
+    assert float(((r1['t_t'] + r2['t_t']).abs() / r1['t_t'].abs().clamp_min(1e-300)).max().item()) <= 1e-11
+    assert float(((r1['t_p'] - r2['t_p']).abs() / r1['t_p'].clamp_min(1e-300)).max().item()) <= 1e-9
     assert int(r1['status'].max().item()) == 0
     ks = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS).run(a, b, rid, stride0=n, stride1=n, npos=P)
     torch.cuda.synchronize()

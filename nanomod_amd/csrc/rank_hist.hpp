@@ -22,8 +22,7 @@
 // Q is scattered to index cumL(L - 1) + (arrival number within its bin, returned by the histogram atomic) —
 // into the LDS words of S's keys, which are dead by then — read back R consecutive keys per lane, and finished
 // by as many odd-even transposition phases as the fullest bin holds samples (~1 sample per bin: 8-10 phases of
-// 2 instructions per key against the 44 of a full network); tie-heavy batches (a bin above kMaxCleanPhases)
-// run the full network on the scattered keys instead.
+// 2 instructions per key against the 44 of a full network).
 // Against rank_all_kernel (both groups sorted by one network, 2 positions per wave, a 72-instruction ranking
 // step per sample of group 2 with four exact fp64 quotients): 4 positions per wave and ~700 instead of ~1000
 // VALU instructions per 200 v 200 position.
@@ -34,8 +33,6 @@
 #include "rank_all.hpp"      // pad_run_pp
 
 namespace nmod {
-
-constexpr int kMaxCleanPhases = 24;
 
 // sum over the lane's elements of p (p - 1), p = 1-based place of the element in its run of equal keys; y = the
 // sorted keys of a group in the blocked layout (element gl * R + r in register r of lane gl)
@@ -117,8 +114,11 @@ __device__ __forceinline__ double hist_exact_quot(int c, double n, double r) {
   return __fma_rn(rem, r, q0);
 }
 
+#ifndef NMOD_HIST_WAVES
+#define NMOD_HIST_WAVES 4
+#endif
 template <int R, int LG, int DTYPE>
-__global__ __launch_bounds__(64 * kWavesPerBlock, (R <= 16 ? 4 : 2))
+__global__ __launch_bounds__(64 * kWavesPerBlock, (R <= 16 ? NMOD_HIST_WAVES : 2))
 void rank_hist_kernel(RankStatsArgs args) {
   static_assert(LG == 8 || LG == 16 || LG == 32, "lanes per sorted group");
   static_assert(R >= 8 && R <= 32 && (R & (R - 1)) == 0, "registers per lane");
@@ -136,10 +136,8 @@ void rank_hist_kernel(RankStatsArgs args) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gl = lane & (LG - 1);
   const int slot = lane / LG;
-  const int seg_base = lane & ~(LG - 1);
   float* keys = lds_all + (wave * PW + slot) * POS_WORDS;        // sorted S of this lane's position (KsLayout)
   unsigned* hist = reinterpret_cast<unsigned*>(keys + HIST_OFF);    // bin k: (#L == k) << 16 | (#U == k); later the prefix table
-  const int e0 = gl * R;                                             // first key / bin this lane owns
 
   const float inf = __builtin_inff();
   const float big = 3.4028234663852886e38f;
@@ -188,14 +186,16 @@ void rank_hist_kernel(RankStatsArgs args) {
     return ks_global_load<Q1Raw>(have ? reinterpret_cast<const Q1Raw*>(sig) + off + idx : reinterpret_cast<const Q1Raw*>(kKsBig4));
   };
 
-  // fixed-stride batches: every position has the same sizes, fl(1/m) and fl(1/q) are taken once
+  // fixed-stride batches: every position has the same sizes; fl(1/m) and fl(1/q) are taken once per block and parked
+  // in LDS behind the positions' words (four vector registers for the whole kernel otherwise)
   const bool uniform = args.stride0 > 0 && args.stride1 > 0;
-  double rm_u = 0.0, rq_u = 0.0;
-  if (uniform) {
+  double* recip = reinterpret_cast<double*>(lds_all + kWavesPerBlock * PW * POS_WORDS);
+  if (uniform && threadIdx.x == 0) {
     const int64_t a0 = args.stride0 < args.stride1 ? args.stride0 : args.stride1;
     const int64_t a1 = args.stride0 < args.stride1 ? args.stride1 : args.stride0;
-    rm_u = 1.0 / (double)a0; rq_u = 1.0 / (double)a1;
+    recip[0] = 1.0 / (double)a0; recip[1] = 1.0 / (double)a1;
   }
+  __syncthreads();
 
   Item cur = describe(wave_global);
   float x[R];
@@ -206,7 +206,15 @@ void rank_hist_kernel(RankStatsArgs args) {
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 
+  const int lane_k = lane;
   for (int64_t it = wave_global; it < items; it += wave_stride) {
+    // everything derived from the lane number is re-derived per item from an opaque copy: hoisted out of the loop
+    // the index constants of the unrolled sweeps (gl * R + r, ...) would occupy ~40 registers for the whole kernel
+    int lane = lane_k;
+    asm volatile("" : "+v"(lane));
+    const int gl = lane & (LG - 1);
+    const int e0 = gl * R;
+    const int seg_base = lane & ~(LG - 1);
     const bool valid = cur.valid;
     const int64_t pos = cur.pos;
     const int m = cur.m, q = cur.q;
@@ -244,6 +252,8 @@ void rank_hist_kernel(RankStatsArgs args) {
     for (int r = 0; r < R; ++r) hist[r * ROW + gl] = 0u;
     if (gl == LG - 1) hist[Lay::END] = 0u;                               // bin C
     unsigned pp = seg_tie_pp<R, LG>(x, gl, lane);
+    asm volatile("" : "+v"(pp));                  // (done here, while S is in registers: not sunk below the ranking rounds)
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -319,11 +329,11 @@ void rank_hist_kernel(RankStatsArgs args) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // the next item's S rows: requested here, behind the ranking rounds (16 registers that the rounds need), and
-    // covered by everything that follows
-    const Item nxt = describe(it + wave_stride);
-    KsRows<R, LG, DTYPE> rows_next;
-    rows_next.request(nxt.swap ? args.sig1 : args.sig0, nxt.off_s, nxt.m, gl);
+    // (a fresh opaque copy of the lane number for the second half of the item: otherwise the index constants of the
+    // sweep over S above stay in registers through the ranking rounds for the sweeps below)
+    asm volatile("" : "+v"(lane));
+    const int gl2 = lane & (LG - 1);
+    const int e02 = gl2 * R;
 
     // ---- histograms -> prefix table in their place: bin k gets  cumL(k-1) << 16 | (a run of S ends at k) << 15 | cumU(k-1)
     unsigned cum;
@@ -331,25 +341,25 @@ void rank_hist_kernel(RankStatsArgs args) {
     {
       unsigned h[R];
 #pragma unroll
-      for (int r = 0; r < R - 1; ++r) h[r] = hist[(r + 1) * ROW + gl];     // bins e0 + 1 .. e0 + R - 1
-      h[R - 1] = hist[gl + 1];                                              // bin e0 + R: row 0 of the next column
+      for (int r = 0; r < R - 1; ++r) h[r] = hist[(r + 1) * ROW + gl2];     // bins e02 + 1 .. e02 + R - 1
+      h[R - 1] = hist[gl2 + 1];                                              // bin e02 + R: row 0 of the next column
       const unsigned h0 = hist[0];
       unsigned tot = 0, hmax = h0;
 #pragma unroll
       for (int r = 0; r < R; ++r) { tot += h[r]; hmax = max(hmax, h[r]); }
-      cum = seg_exscan_add_u32<LG>(tot, gl) + h0;                           // cumL(e0) << 16 | cumU(e0)
+      cum = seg_exscan_add_u32<LG>(tot, gl2) + h0;                           // cumL(e02) << 16 | cumU(e02)
       maxc = (int)(wave_max_u32(hmax) >> 16);                               // fullest L-bin of the wave's positions
       unsigned c2 = cum;
-      float sk = keys[gl];                                                  // key e0
+      float sk = keys[gl2];                                                  // key e02
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float up = (r == R - 1) ? keys[gl + 1] : keys[(r + 1) * ROW + gl];   // key e0 + r + 1 (or the +inf sentinel)
+        const float up = (r == R - 1) ? keys[gl2 + 1] : keys[(r + 1) * ROW + gl2];   // key e02 + r + 1 (or the +inf sentinel)
         const unsigned w = c2 | ((sk != up) ? 0x8000u : 0u);
-        if (r < R - 1) hist[(r + 1) * ROW + gl] = w; else hist[gl + 1] = w;       // bin e0 + r + 1
+        if (r < R - 1) hist[(r + 1) * ROW + gl2] = w; else hist[gl2 + 1] = w;       // bin e02 + r + 1
         c2 += h[r];
         sk = up;
       }
-      if (gl == 0) hist[0] = 0u;                                            // bin 0: nothing before it
+      if (gl2 == 0) hist[0] = 0u;                                            // bin 0: nothing before it
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -361,19 +371,28 @@ void rank_hist_kernel(RankStatsArgs args) {
       const float kqf = (q > 0) ? (float)rk : 0.0f;
       const double KQ = (double)kqf;
       double s1 = 0.0, s2 = 0.0;
+      // (all the allocations first, then all the stores: an LDS store cannot be moved above an atomic it might alias,
+      // so interleaving them would expose one atomic round trip per sample)
+      unsigned at[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const bool have = xs[r] != big;
         const unsigned ad = (r & 1) ? (la[r / 2] >> 16) : (la[r / 2] & 0xffffu);
-        if (have) {
-          unsigned* tb = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(keys) + ad);
-          const int i = (int)(atomicAdd(tb, 0x10000u) >> 16);
-          keys[__mul24(i & (R - 1), ROW) + (i >> LOG_R)] = xs[r];
-        }
+        at[r] = 0u;
+        if (have) at[r] = atomicAdd(reinterpret_cast<unsigned*>(reinterpret_cast<char*>(keys) + ad), 0x10000u);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool have = xs[r] != big;
         const double d = (double)(have ? xs[r] : kqf) - KQ;
         s1 += d;
         s2 = __fma_rn(d, d, s2);
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int i = (int)(at[r] >> 16);
+        if (xs[r] != big) keys[__mul24(i & (R - 1), ROW) + (i >> LOG_R)] = xs[r];
       }
       s1 = seg_allsum_f64<LG>(s1);
       s2 = seg_allsum_f64<LG>(s2);
@@ -381,7 +400,7 @@ void rank_hist_kernel(RankStatsArgs args) {
       double mu = KQ + s1 / dn;
       double qq = s2 - s1 * s1 / dn;
       if constexpr (DTYPE != 0) { mu = mu / 1000.0; qq = qq * 1e-6; }
-      if (valid && gl == 0) {
+      if (valid && gl2 == 0) {
         double* mo = args.moments + pos * 4 + (swap ? 0 : 2);
         mo[0] = mu; mo[1] = qq;
       }
@@ -390,33 +409,33 @@ void rank_hist_kernel(RankStatsArgs args) {
     __builtin_amdgcn_wave_barrier();
 
     // ---- pass over the lane's bins (from the table): KS numerator, Mann-Whitney sum, ties between S and Q
-    // table words of bins e0 .. e0 + R + 1: high half = cumL(bin) now, low 15 bits = cumU(bin - 1), bit 15 = run end
+    // table words of bins e02 .. e02 + R + 1: high half = cumL(bin) now, low 15 bits = cumU(bin - 1), bit 15 = run end
     unsigned tw[R + 2];
 #pragma unroll
-    for (int r = 0; r < R; ++r) tw[r] = hist[r * ROW + gl];
-    tw[R] = hist[gl + 1];
-    tw[R + 1] = (gl == LG - 1) ? (unsigned)q : hist[ROW + gl + 1];          // (cumU(C) = q)
+    for (int r = 0; r < R; ++r) tw[r] = hist[r * ROW + gl2];
+    tw[R] = hist[gl2 + 1];
+    tw[R + 1] = (gl2 == LG - 1) ? (unsigned)q : hist[ROW + gl2 + 1];          // (cumU(C) = q)
     // start of the run of S that is open when the lane's first bin begins (only read where Q ties with S)
     int start = 0;
     if (__ballot(any_tie) != 0ull) {
       int ls = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) ls = (tw[r + 1] & 0x8000u) ? (e0 + r + 1) : ls;   // a run ends at key e0 + r: the next starts at e0 + r + 1
+      for (int r = 0; r < R; ++r) ls = (tw[r + 1] & 0x8000u) ? (e02 + r + 1) : ls;   // a run ends at key e02 + r: the next starts at e02 + r + 1
       const int bias = (LG == 8 && (lane & 8)) ? C + 1 : 0;
       int sc = lane_prev_i(seg_scan_max_i32<LG>(ls + bias), 0) - bias;
-      start = (gl == 0 || sc < 0) ? 0 : sc;
+      start = (gl2 == 0 || sc < 0) ? 0 : sc;
     }
     unsigned best;
     unsigned acc_l = 0, acc_u = 0, ab3 = 0;
     {
-      int hi = (gl == 0) ? __mul24((int)(tw[1] & 0x7fffu), m) : 0, lo = 0;  // k = 0: (cumU(0), 0)
-      int nkq = -__mul24(e0, q);
+      int hi = (gl2 == 0) ? __mul24((int)(tw[1] & 0x7fffu), m) : 0, lo = 0;  // k = 0: (cumU(0), 0)
+      int nkq = -__mul24(e02, q);
 #pragma unroll
-      for (int r = 0; r < R; ++r) {                                          // bin k = e0 + r + 1
+      for (int r = 0; r < R; ++r) {                                          // bin k = e02 + r + 1
         const bool run_end = (tw[r + 1] & 0x8000u) != 0u;
         const int cl = (int)(tw[r] >> 16), cu = (int)(tw[r + 1] & 0x7fffu);  // cumL(k-1), cumU(k-1)
         const int cun = (int)(tw[r + 2] & 0x7fffu);                          // cumU(k)
-        const int k = e0 + r + 1;
+        const int k = e02 + r + 1;
         nkq -= q;
         acc_l += (unsigned)cl; acc_u += (unsigned)cu;
         const int cand_b = __mul24(cl, m) + nkq;                             // (cumL(k-1), k)
@@ -438,9 +457,12 @@ void rank_hist_kernel(RankStatsArgs args) {
     // take the bins of one such lane at a time from the table
     double dmax = 0.0;
     {
-      const double dm = (double)m, dq = (double)q;
-      double rm = rm_u, rq = rq_u;
-      if (!uniform) { rm = 1.0 / dm; rq = 1.0 / dq; }
+      int mo = m, qo = q;
+      asm volatile("" : "+v"(mo), "+v"(qo));    // (not the (double)m of the moments, kept alive since then)
+      const double dm = (double)mo, dq = (double)qo;
+      double rm, rq;
+      if (uniform) { rm = recip[0]; rq = recip[1]; }
+      else { rm = 1.0 / dm; rq = 1.0 / dq; }
       unsigned long long hits = __ballot(lbest == best && best != 0u);
       const unsigned long long seg_mask = ((1ull << LG) - 1ull) << seg_base;
 #pragma unroll 1
@@ -450,7 +472,7 @@ void rank_hist_kernel(RankStatsArgs args) {
         const int hl = act ? (__ffsll((long long)mine) - 1 - seg_base) : 0;   // the lane of this position whose bins are examined
 #pragma unroll
         for (int j = 0; j < (R + LG - 1) / LG; ++j) {
-          const int rr = gl + j * LG;
+          const int rr = gl2 + j * LG;
           const int k = hl * R + rr + 1;
           const bool in = act && rr < R;
           const unsigned wp = hist[Lay::word(in ? k - 1 : 0)];
@@ -470,7 +492,7 @@ void rank_hist_kernel(RankStatsArgs args) {
             dmax = ha ? fmax(dmax, da) : dmax;
           }
         }
-        if (act && hl == 0 && gl == 0) {                                     // the candidate (cumU(0), 0) of the first lane
+        if (act && hl == 0 && gl2 == 0) {                                     // the candidate (cumU(0), 0) of the first lane
           const int cu0 = (int)(hist[Lay::word(1)] & 0x7fffu);
           if ((unsigned)__mul24(cu0, m) == best) dmax = fmax(dmax, hist_exact_quot(cu0, dq, rq));
         }
@@ -488,27 +510,32 @@ void rank_hist_kernel(RankStatsArgs args) {
       dmax = seg_allmax_f64<LG>(dmax);
     }
 
+    // the next item's S rows: requested as late as the rest of the iteration can still cover the round trip (they
+    // occupy 16 registers from here on)
+    const Item nxt = describe(it + wave_stride);
+    KsRows<R, LG, DTYPE> rows_next;
+    rows_next.request(nxt.swap ? args.sig1 : args.sig0, nxt.off_s, nxt.m, gl2);
+
     // ---- Q in sorted order: read the scattered keys back, finish inside the bins, count its ties
     __builtin_amdgcn_wave_barrier();
     float y[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float v = keys[r * ROW + gl];
-      y[r] = (e0 + r < q) ? v : inf;                                          // words past q still hold keys of S
+      const float v = keys[r * ROW + gl2];
+      y[r] = (e02 + r < q) ? v : inf;                                          // words past q still hold keys of S
     }
-    if (maxc <= kMaxCleanPhases) {
-      if (maxc > 1) seg_oddeven_phases<R, LG>(y, gl, maxc);
-    } else {
-      seg_sort_any<R, LG>(y, sel, lane);
-    }
-    pp += seg_tie_pp<R, LG>(y, gl, lane);
+    // (a bin is unordered inside and ordered against its neighbours: maxc phases sort every bin.  Groups far apart
+    // put many samples into one end bin — up to q phases of 2 instructions per key, against the register footprint
+    // that a second copy of the full network would add to every item)
+    if (maxc > 1) seg_oddeven_phases<R, LG>(y, gl2, maxc);
+    pp += seg_tie_pp<R, LG>(y, gl2, lane);
 
     // ---- totals of the position
     const unsigned PP = pos_allsum_u32<LG>(pp);
     const unsigned AB = pos_allsum_u32<LG>(ab3);
     const unsigned AL = pos_allsum_u32<LG>(acc_l);
     const unsigned AU = pos_allsum_u32<LG>(acc_u);
-    if (valid && gl == 0) {
+    if (valid && gl2 == 0) {
       // the +inf pads of each group form one run of C - n keys: take its sum_{p} p (p - 1) out
       const unsigned long long pads = (unsigned long long)pad_run_pp(C - m) + (unsigned long long)pad_run_pp(C - q);
       // sum_{x in Q} (L + U) = sum_{k=1..C} (2q - cumL(k-1) - cumU(k-1))

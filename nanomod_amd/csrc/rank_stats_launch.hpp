@@ -49,7 +49,7 @@ inline size_t rank_stats_lds_bytes(int cls, bool all) {
     size_t LG = (size_t)ks_lanes_per_group(cm), R = (64u << cm) / LG;
     size_t w = 2 * R * (LG + 1);                                             // ks_rank_pos_words (ks_rank.hpp)
     if (LG <= 16) while ((w & 31) != LG) ++w;
-    return (size_t)packed_positions_per_wave(cm) * w * 4 * 4;
+    return (size_t)packed_positions_per_wave(cm) * w * 4 * 4 + 16;             // + two doubles (rank_hist.hpp: recip)
   } else {
     // rank_pair_kernel (rank_all.hpp): keys + runs of both groups, R x 65 words each
     words = 2 * 65 * ((1u << (cls / kNumSizeClasses)) + (1u << (cls % kNumSizeClasses)));

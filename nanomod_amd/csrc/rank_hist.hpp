@@ -35,7 +35,8 @@
 namespace nmod {
 
 // sum over the lane's elements of p (p - 1), p = 1-based place of the element in its run of equal keys; y = the
-// sorted keys of a group in the blocked layout (element gl * R + r in register r of lane gl)
+// sorted keys of a group in the blocked layout (element gl * R + r in register r of lane gl), +inf pads at the end
+// (not counted; y is clobbered)
 template <int R, int LG>
 __device__ __forceinline__ unsigned seg_tie_pp(float (&y)[R], int gl, int lane) {
   constexpr int N = R * LG;
@@ -43,7 +44,33 @@ __device__ __forceinline__ unsigned seg_tie_pp(float (&y)[R], int gl, int lane) 
   // from the first group (< N) can never win a max
   const int bias = (LG == 8 && (lane & 8)) ? N : 0;
   const float nanv = __builtin_nanf("");
+  const float inf = __builtin_inff();
   float prev_last = lane_prev(y[R - 1], nanv);
+  prev_last = (gl == 0) ? nanv : prev_last;
+  // Usual case (continuous signals, and the occasional tie of 3-dp rounded ones): no key of the wave equals BOTH of its
+  // two predecessors, i.e. every run of equal keys is a pair and adds p (p - 1) = 2: count the keys that equal their
+  // predecessor.  The comparison results are wave masks in scalar registers; "both predecessors" is a scalar AND per
+  // key (across a lane boundary: the mask of the lane's first key against the last key's mask moved up one lane).
+  {
+    unsigned long long eq_prev = 0ull, triple = 0ull, eq_first = 0ull;
+    unsigned cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool eq = (y[r] == ((r == 0) ? prev_last : y[r - 1])) && (y[r] != inf);   // (the +inf pads are not a tie)
+      cnt += eq ? 1u : 0u;
+      const unsigned long long e = __ballot(eq);
+      if (r == 0) eq_first = e; else triple |= e & eq_prev;
+      eq_prev = e;
+    }
+    triple |= eq_first & (eq_prev << 1);                 // key 0 of a lane, key R - 1 and key R - 2.. of the lane below:
+    // (eq_prev is now the mask of key R - 1 == key R - 2; a first key that equals the previous lane's last key, which
+    // itself equals its predecessor, closes a run of three; first keys of a group never compare equal: prev_last is NaN)
+    if (triple == 0ull) return 2u * cnt;
+  }
+  // general case: pads become NaN (never equal to anything), then every key gets its place in its run
+#pragma unroll
+  for (int r = 0; r < R; ++r) y[r] = (y[r] != inf) ? y[r] : nanv;
+  prev_last = lane_prev(y[R - 1], nanv);
   prev_last = (gl == 0) ? nanv : prev_last;
   int run = bias;
 #pragma unroll
@@ -68,6 +95,14 @@ __device__ __forceinline__ unsigned seg_tie_pp(float (&y)[R], int gl, int lane) 
   return acc;
 }
 
+// compare-exchange without the canonicalising v_max x, x that fminf / fmaxf put in front of values of unknown origin
+// (here: keys read back from LDS and carried around a loop): the keys are ordinary numbers or +-inf
+__device__ __forceinline__ void ce_raw(float& lo, float& hi) {
+  float a, b;
+  asm("v_min_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3" : "=&v"(a), "=v"(b) : "v"(lo), "v"(hi));
+  lo = a; hi = b;
+}
+
 // `phases` odd-even transposition phases over the R x LG keys of every group of the wave (blocked layout): enough to
 // sort a sequence whose elements are at most phases - 1 places from home
 template <int R, int LG>
@@ -76,14 +111,21 @@ __device__ __forceinline__ void seg_oddeven_phases(float (&y)[R], int gl, int ph
 #pragma unroll 1
   for (int ph = 0; ph < phases; ph += 2) {
 #pragma unroll
-    for (int r = 0; r + 1 < R; r += 2) ce(y[r], y[r + 1]);
+    for (int r = 0; r + 1 < R; r += 2) ce_raw(y[r], y[r + 1]);
 #pragma unroll
-    for (int r = 1; r + 1 < R; r += 2) ce(y[r], y[r + 1]);
-    float nx = lane_next(y[0], inf);                    // key 0 of the next lane / key R - 1 of the previous one
-    float pv = lane_prev(y[R - 1], -inf);
+    for (int r = 1; r + 1 < R; r += 2) ce_raw(y[r], y[r + 1]);
+    float nx, pv;                                       // key 0 of the next lane / key R - 1 of the previous one
+    if constexpr (LG <= 16) {                           // (a group lies inside one DPP row)
+      nx = dpp_f<kDppRowShl + 1, 0xf, 0xf, true>(0.0f, y[0]);
+      pv = dpp_f<kDppRowShr + 1, 0xf, 0xf, true>(0.0f, y[R - 1]);
+    } else {
+      nx = lane_next(y[0], inf);
+      pv = lane_prev(y[R - 1], -inf);
+    }
     nx = (gl == LG - 1) ? inf : nx;                     // (group boundaries)
     pv = (gl == 0) ? -inf : pv;
-    const float lo = fmaxf(y[0], pv), hi = fminf(y[R - 1], nx);
+    float lo, hi;
+    asm("v_max_f32 %0, %2, %3\n\tv_min_f32 %1, %4, %5" : "=&v"(lo), "=&v"(hi) : "v"(y[0]), "v"(pv), "v"(y[R - 1]), "v"(nx));
     y[0] = lo; y[R - 1] = hi;
   }
 }
@@ -114,6 +156,9 @@ __device__ __forceinline__ double hist_exact_quot(int c, double n, double r) {
   return __fma_rn(rem, r, q0);
 }
 
+#ifndef NMOD_SKIP
+#define NMOD_SKIP 0
+#endif
 #ifndef NMOD_HIST_WAVES
 #define NMOD_HIST_WAVES 4
 #endif
@@ -237,6 +282,7 @@ void rank_hist_kernel(RankStatsArgs args) {
     const Q1Raw rk = load_q1(sig_q, off_q, 0, q > 0);                       // the shift of Q's moments
 
     // ---- S: moments, sort, keys to LDS, ties inside S
+#if !(NMOD_SKIP & 4)
     {
       double mean, m2;
       seg_moments<R, LG, DTYPE>(x, m, mean, m2);
@@ -245,13 +291,20 @@ void rank_hist_kernel(RankStatsArgs args) {
         mo[0] = mean; mo[1] = m2;
       }
     }
+#endif
+#if !(NMOD_SKIP & 16)
     seg_sort_any<R, LG>(x, sel, lane);
 #pragma unroll
     for (int r = 0; r < R; ++r) keys[r * ROW + gl] = x[r];
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) hist[r * ROW + gl] = 0u;
     if (gl == LG - 1) hist[Lay::END] = 0u;                               // bin C
+#if (NMOD_SKIP & 8)
+    unsigned pp = 0;
+#else
     unsigned pp = seg_tie_pp<R, LG>(x, gl, lane);
+#endif
     asm volatile("" : "+v"(pp));                  // (done here, while S is in registers: not sunk below the ranking rounds)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -463,49 +516,51 @@ void rank_hist_kernel(RankStatsArgs args) {
       double rm, rq;
       if (uniform) { rm = recip[0]; rq = recip[1]; }
       else { rm = 1.0 / dm; rq = 1.0 / dq; }
-      unsigned long long hits = __ballot(lbest == best && best != 0u);
-      const unsigned long long seg_mask = ((1ull << LG) - 1ull) << seg_base;
+      // hit lanes of this lane's position as a bit mask (bit j: lane j of the group reached the maximum)
+      const unsigned long long hits = __ballot(lbest == best && best != 0u);
+      unsigned mine = (unsigned)(hits >> seg_base);
+      if constexpr (LG < 32) mine &= (1u << LG) - 1u;
+#if (NMOD_SKIP & 2)
+      mine = 0;
+#endif
+      // the candidate (cumU(0), 0) belongs to lane 0 of the position
+      if (gl2 == 0 && (mine & 1u)) {
+        const int cu0 = (int)(tw[1] & 0x7fffu);
+        if ((unsigned)__mul24(cu0, mo) == best) dmax = hist_exact_quot(cu0, dq, rq);
+      }
+      // word offsets of the table entries of bins k - 1, k, k + 1 (k = hl * R + rr + 1) for hl = 0
+      int wofs[(R + LG - 1) / LG][3];
+#pragma unroll
+      for (int j = 0; j < (R + LG - 1) / LG; ++j) {
+        const int rr = gl2 + j * LG;
+        wofs[j][0] = Lay::word(rr); wofs[j][1] = Lay::word(rr + 1); wofs[j][2] = Lay::word(rr + 2);
+      }
 #pragma unroll 1
-      while (hits != 0ull) {
-        const unsigned long long mine = hits & seg_mask;
-        const bool act = mine != 0ull;
-        const int hl = act ? (__ffsll((long long)mine) - 1 - seg_base) : 0;   // the lane of this position whose bins are examined
+      while (__ballot(mine != 0u) != 0ull) {
+        const bool act = mine != 0u;
+        const int hl = act ? (__ffs((int)mine) - 1) : 0;                      // the lane of this position whose bins are examined
+        mine &= mine - 1u;
 #pragma unroll
         for (int j = 0; j < (R + LG - 1) / LG; ++j) {
           const int rr = gl2 + j * LG;
           const int k = hl * R + rr + 1;
           const bool in = act && rr < R;
-          const unsigned wp = hist[Lay::word(in ? k - 1 : 0)];
-          const unsigned w = hist[Lay::word(in ? k : 0)];
-          const unsigned wn = hist[Lay::word((in && k < C) ? k + 1 : 0)];
-          const int cl = (int)(wp >> 16), cu = (k < C) ? (int)(wn & 0x7fffu) : q;
+          // (lane hl's bins are one column to the right per unit of hl: + hl words)
+          const unsigned wp = hist[wofs[j][0] + hl];
+          const unsigned w = hist[wofs[j][1] + hl];
+          const unsigned wn = (k < C) ? hist[wofs[j][2] + hl] : (unsigned)qo;
+          const int cl = (int)(wp >> 16), cu = (int)(wn & 0x7fffu);
           const bool run_end = (w & 0x8000u) != 0u;
-          const int nkq = -__mul24(k, q);
-          const int cand_b = __mul24(cl, m) + nkq, cand_a = __mul24(cu, m) + nkq;
+          const int nkq = -__mul24(k, qo);
+          const int cand_b = __mul24(cl, mo) + nkq, cand_a = __mul24(cu, mo) + nkq;
           const bool hb = in && run_end && (unsigned)abs(cand_b) == best;
           const bool ha = in && run_end && (unsigned)abs(cand_a) == best;
-          if (__ballot(ha || hb) != 0ull) {
-            const double fk = hist_exact_quot(k, dm, rm);
-            const double db = fabs(fk - hist_exact_quot(cl, dq, rq));
-            const double da = fabs(fk - hist_exact_quot(cu, dq, rq));
-            dmax = hb ? fmax(dmax, db) : dmax;
-            dmax = ha ? fmax(dmax, da) : dmax;
-          }
+          const double fk = hist_exact_quot(k, dm, rm);
+          const double db = fabs(fk - hist_exact_quot(cl, dq, rq));
+          const double da = fabs(fk - hist_exact_quot(cu, dq, rq));
+          dmax = hb ? fmax(dmax, db) : dmax;
+          dmax = ha ? fmax(dmax, da) : dmax;
         }
-        if (act && hl == 0 && gl2 == 0) {                                     // the candidate (cumU(0), 0) of the first lane
-          const int cu0 = (int)(hist[Lay::word(1)] & 0x7fffu);
-          if ((unsigned)__mul24(cu0, m) == best) dmax = fmax(dmax, hist_exact_quot(cu0, dq, rq));
-        }
-        // drop the examined lane of every position
-        const unsigned long long low = mine & (0ull - mine);                  // (lowest set bit of this position's hits)
-        unsigned long long drop = 0ull;
-#pragma unroll
-        for (int s = 0; s < PW; ++s) {
-          const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)low, s * LG);
-          const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(low >> 32), s * LG);
-          drop |= ((unsigned long long)hi32 << 32) | lo32;
-        }
-        hits &= ~drop;
       }
       dmax = seg_allmax_f64<LG>(dmax);
     }
@@ -527,8 +582,10 @@ void rank_hist_kernel(RankStatsArgs args) {
     // (a bin is unordered inside and ordered against its neighbours: maxc phases sort every bin.  Groups far apart
     // put many samples into one end bin — up to q phases of 2 instructions per key, against the register footprint
     // that a second copy of the full network would add to every item)
+#if !(NMOD_SKIP & 1)
     if (maxc > 1) seg_oddeven_phases<R, LG>(y, gl2, maxc);
     pp += seg_tie_pp<R, LG>(y, gl2, lane);
+#endif
 
     // ---- totals of the position
     const unsigned PP = pos_allsum_u32<LG>(pp);
@@ -536,13 +593,11 @@ void rank_hist_kernel(RankStatsArgs args) {
     const unsigned AL = pos_allsum_u32<LG>(acc_l);
     const unsigned AU = pos_allsum_u32<LG>(acc_u);
     if (valid && gl2 == 0) {
-      // the +inf pads of each group form one run of C - n keys: take its sum_{p} p (p - 1) out
-      const unsigned long long pads = (unsigned long long)pad_run_pp(C - m) + (unsigned long long)pad_run_pp(C - q);
       // sum_{x in Q} (L + U) = sum_{k=1..C} (2q - cumL(k-1) - cumU(k-1))
       const unsigned long long slu = 2ull * (unsigned long long)C * (unsigned long long)q - (unsigned long long)AL - (unsigned long long)AU;
       // mwu_s = sum_{a in group 1} (#{b < a} + #{b <= a}): Q is group 1 when swapped, else count from group 2's side
       args.mwu_s[pos] = swap ? slu : 2ull * (unsigned long long)m * (unsigned long long)q - slu;
-      args.tie[pos] = 3ull * ((unsigned long long)PP - pads) + 3ull * (unsigned long long)AB;
+      args.tie[pos] = 3ull * (unsigned long long)PP + 3ull * (unsigned long long)AB;
       args.ks_d_ref[pos] = (m > 0 && q > 0) ? dmax : 0.0;
       args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;
     }

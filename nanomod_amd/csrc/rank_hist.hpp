@@ -320,28 +320,42 @@ void rank_hist_kernel(RankStatsArgs args) {
 #pragma unroll
     for (int r = 0; r < R / 2; ++r) la[r] = 0u;
 
-    auto rank_one = [&](float xq, bool have) -> unsigned {
-      const float* lcol;
-      const float* lp = ks_search<R, LG, false, true>(keys, xq, &lcol);
-      const bool eq = (*lp == xq);
-      unsigned* bin = reinterpret_cast<unsigned*>(const_cast<float*>(lp)) + HIST_OFF;
-      if (__ballot(eq) == 0ull) {
-        if (have) atomicAdd(bin, 0x10001u);
-      } else {
-        any_tie = true;
-        const unsigned dl = (unsigned)(uintptr_t)lp - (unsigned)(uintptr_t)lcol;
-        const int step = (dl == (unsigned)((R - 1) * ROW * 4)) ? 1 - (R - 1) * ROW : ROW;
-        const float* up = eq ? lp + step : lp;
-        if (__ballot(*up == xq) != 0ull) up = ks_search<R, LG, true, true>(keys, xq);
-        if (have) {
-          atomicAdd(bin, 0x10000u);
-          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up)) + HIST_OFF, 1u);
+    // rank NV samples: all the searches first (independent chains of LDS reads that the scheduler interleaves), then
+    // the histogram updates.  Per sample slot: a slot in which no lane ties with S adds L and U in one go; a slot with
+    // ties takes U = L + 1 key and only if that key ties again (duplicates inside S) the full upper-bound search.
+    auto rank_many = [&](auto nv_tag, const float* xq, bool have, unsigned* ad) {
+      constexpr int NV = decltype(nv_tag)::value;
+      const float* lp[NV];
+      const float* lcol[NV];
+#pragma unroll
+      for (int e = 0; e < NV; ++e) lp[e] = ks_search<R, LG, false, true>(keys, xq[e], &lcol[e]);
+      bool eq[NV];
+#pragma unroll
+      for (int e = 0; e < NV; ++e) eq[e] = (*lp[e] == xq[e]);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        unsigned* bin = reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF;
+        if (__ballot(eq[e]) == 0ull) {
+          if (have) atomicAdd(bin, 0x10001u);
+        } else {
+          any_tie = true;
+          const unsigned dl = (unsigned)(uintptr_t)lp[e] - (unsigned)(uintptr_t)lcol[e];
+          const int step = (dl == (unsigned)((R - 1) * ROW * 4)) ? 1 - (R - 1) * ROW : ROW;
+          const float* up = eq[e] ? lp[e] + step : lp[e];
+          if (__ballot(*up == xq[e]) != 0ull) up = ks_search<R, LG, true, true>(keys, xq[e]);
+          if (have) {
+            atomicAdd(bin, 0x10000u);
+            atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up)) + HIST_OFF, 1u);
+          }
         }
+        ad[e] = (unsigned)(uintptr_t)bin - (unsigned)(uintptr_t)keys;      // byte offset inside the position's LDS (< 64 KB)
       }
-      return (unsigned)(uintptr_t)bin - (unsigned)(uintptr_t)keys;      // byte offset inside the position's LDS (< 64 KB)
     };
 
     __builtin_amdgcn_s_waitcnt(0x0F70);            // everything requested before the sort has arrived
+#if (NMOD_SKIP & 32)
+    full_w = 0; tail_w = 0;
+#endif
 #pragma unroll
     for (int c = 0; c < R / 4; ++c) {
       if (c < full_w) {
@@ -351,8 +365,9 @@ void rank_hist_kernel(RankStatsArgs args) {
         if constexpr (DTYPE == 0) { xa[0] = ra.x; xa[1] = ra.y; xa[2] = ra.z; xa[3] = ra.w; }
         else { xa[0] = have ? (float)ra.x : big; xa[1] = have ? (float)ra.y : big; xa[2] = have ? (float)ra.z : big; xa[3] = have ? (float)ra.w : big; }
         unsigned ad[4];
+        rank_many(std::integral_constant<int, 4>{}, xa, have, ad);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ad[e] = rank_one(xa[e], have); xs[4 * c + e] = xa[e]; }
+        for (int e = 0; e < 4; ++e) xs[4 * c + e] = xa[e];
         la[2 * c] = ad[0] | (ad[1] << 16);
         la[2 * c + 1] = ad[2] | (ad[3] << 16);
         ra = rb;
@@ -368,7 +383,8 @@ void rank_hist_kernel(RankStatsArgs args) {
         const float xq = have ? (float)rt : big;
         const int idx = full * (4 * LG) + (c + 1) * LG + gl;
         rt = load_q1(sig_q, off_q, idx, idx < q);
-        const unsigned ad = rank_one(xq, have);
+        unsigned ad;
+        { const float x1[1] = {xq}; unsigned a1[1]; rank_many(std::integral_constant<int, 1>{}, x1, have, a1); ad = a1[0]; }
 #pragma unroll
         for (int f = 0; f < R / 4; ++f)
           if (4 * f + c < R) {
@@ -388,35 +404,72 @@ void rank_hist_kernel(RankStatsArgs args) {
     const int gl2 = lane & (LG - 1);
     const int e02 = gl2 * R;
 
-    // ---- histograms -> prefix table in their place: bin k gets  cumL(k-1) << 16 | (a run of S ends at k) << 15 | cumU(k-1)
+    // ---- one pass over the lane's bins: histograms -> prefix table in their place (bin k gets
+    // cumL(k-1) << 16 | (a run of S ends at k) << 15 | cumU(k-1): the scatter's bases and the float-form pass read it),
+    // and on the way the KS numerator, the Mann-Whitney sum and the ties between S and Q
     unsigned cum;
     int maxc;
+    unsigned best;
+    unsigned acc_l = 0, acc_u = 0, ab3 = 0;
     {
       unsigned h[R];
 #pragma unroll
       for (int r = 0; r < R - 1; ++r) h[r] = hist[(r + 1) * ROW + gl2];     // bins e02 + 1 .. e02 + R - 1
       h[R - 1] = hist[gl2 + 1];                                              // bin e02 + R: row 0 of the next column
       const unsigned h0 = hist[0];
+      float sk[R + 1];
+#pragma unroll
+      for (int r = 0; r < R; ++r) sk[r] = keys[r * ROW + gl2];              // keys e02 .. e02 + R - 1
+      sk[R] = keys[gl2 + 1];                                                // key e02 + R (or the +inf sentinel)
       unsigned tot = 0, hmax = h0;
 #pragma unroll
       for (int r = 0; r < R; ++r) { tot += h[r]; hmax = max(hmax, h[r]); }
       cum = seg_exscan_add_u32<LG>(tot, gl2) + h0;                           // cumL(e02) << 16 | cumU(e02)
       maxc = (int)(wave_max_u32(hmax) >> 16);                               // fullest L-bin of the wave's positions
-      unsigned c2 = cum;
-      float sk = keys[gl2];                                                  // key e02
+      // start of the run of S that is open when the lane's first bin begins (only read where Q ties with S)
+      int start = 0;
+      if (__ballot(any_tie) != 0ull) {
+        int ls = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float up = (r == R - 1) ? keys[gl2 + 1] : keys[(r + 1) * ROW + gl2];   // key e02 + r + 1 (or the +inf sentinel)
-        const unsigned w = c2 | ((sk != up) ? 0x8000u : 0u);
-        if (r < R - 1) hist[(r + 1) * ROW + gl2] = w; else hist[gl2 + 1] = w;       // bin e02 + r + 1
+        for (int r = 0; r < R; ++r) ls = (sk[r] != sk[r + 1]) ? (e02 + r + 1) : ls;   // a run ends at key e02 + r: the next starts at e02 + r + 1
+        const int bias = (LG == 8 && (lane & 8)) ? C + 1 : 0;
+        int sc = lane_prev_i(seg_scan_max_i32<LG>(ls + bias), 0) - bias;
+        start = (gl2 == 0 || sc < 0) ? 0 : sc;
+      }
+      unsigned c2 = cum;
+      int cl = (int)(c2 >> 16), cu = (int)(c2 & 0xffffu);                   // cumL(k-1), cumU(k-1) entering bin k = e02 + 1
+      int hi = (gl2 == 0) ? __mul24(cu, m) : 0, lo = 0;                     // k = 0: (cumU(0), 0)
+      int nkq = -__mul24(e02, q);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {                                          // bin k = e02 + r + 1
+        const bool run_end = sk[r] != sk[r + 1];
+        const unsigned w = c2 | (run_end ? 0x8000u : 0u);
+        if (r < R - 1) hist[(r + 1) * ROW + gl2] = w; else hist[gl2 + 1] = w;
+        const int k = e02 + r + 1;
+        nkq -= q;
+        acc_l += (unsigned)cl; acc_u += (unsigned)cu;
+        const int cand_b = __mul24(cl, m) + nkq;                             // (cumL(k-1), k)
+        const int b = run_end ? cl - cu : 0;                                 // samples of Q equal to the run of S ending at k
+        const int a = k - start;
+        ab3 += (unsigned)__mul24(__mul24(a, b), a + b);
+        start = run_end ? k : start;
         c2 += h[r];
-        sk = up;
+        cu = (int)(c2 & 0xffffu);
+        cl = (int)(c2 >> 16);
+        const int cand_a = __mul24(cu, m) + nkq;                             // (cumU(k), k)
+        const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
+        hi = max(hi, max(ca, cb));
+        lo = min(lo, min(ca, cb));
       }
       if (gl2 == 0) hist[0] = 0u;                                            // bin 0: nothing before it
+      best = (unsigned)max(hi, -lo);
     }
+    const unsigned lbest = best;
+    best = seg_allmax_u32<LG>(best);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+#if !(NMOD_SKIP & 64)
     // ---- scatter Q by bin into the key words of S (dead from here on: the table carries its run ends).  The high
     // half of a bin's table word is its bump allocator: afterwards it holds cumL(k).  Q's moments on the way, shifted
     // by its first sample (a slot without a sample adds 0).
@@ -461,51 +514,7 @@ void rank_hist_kernel(RankStatsArgs args) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // ---- pass over the lane's bins (from the table): KS numerator, Mann-Whitney sum, ties between S and Q
-    // table words of bins e02 .. e02 + R + 1: high half = cumL(bin) now, low 15 bits = cumU(bin - 1), bit 15 = run end
-    unsigned tw[R + 2];
-#pragma unroll
-    for (int r = 0; r < R; ++r) tw[r] = hist[r * ROW + gl2];
-    tw[R] = hist[gl2 + 1];
-    tw[R + 1] = (gl2 == LG - 1) ? (unsigned)q : hist[ROW + gl2 + 1];          // (cumU(C) = q)
-    // start of the run of S that is open when the lane's first bin begins (only read where Q ties with S)
-    int start = 0;
-    if (__ballot(any_tie) != 0ull) {
-      int ls = 0;
-#pragma unroll
-      for (int r = 0; r < R; ++r) ls = (tw[r + 1] & 0x8000u) ? (e02 + r + 1) : ls;   // a run ends at key e02 + r: the next starts at e02 + r + 1
-      const int bias = (LG == 8 && (lane & 8)) ? C + 1 : 0;
-      int sc = lane_prev_i(seg_scan_max_i32<LG>(ls + bias), 0) - bias;
-      start = (gl2 == 0 || sc < 0) ? 0 : sc;
-    }
-    unsigned best;
-    unsigned acc_l = 0, acc_u = 0, ab3 = 0;
-    {
-      int hi = (gl2 == 0) ? __mul24((int)(tw[1] & 0x7fffu), m) : 0, lo = 0;  // k = 0: (cumU(0), 0)
-      int nkq = -__mul24(e02, q);
-#pragma unroll
-      for (int r = 0; r < R; ++r) {                                          // bin k = e02 + r + 1
-        const bool run_end = (tw[r + 1] & 0x8000u) != 0u;
-        const int cl = (int)(tw[r] >> 16), cu = (int)(tw[r + 1] & 0x7fffu);  // cumL(k-1), cumU(k-1)
-        const int cun = (int)(tw[r + 2] & 0x7fffu);                          // cumU(k)
-        const int k = e02 + r + 1;
-        nkq -= q;
-        acc_l += (unsigned)cl; acc_u += (unsigned)cu;
-        const int cand_b = __mul24(cl, m) + nkq;                             // (cumL(k-1), k)
-        const int cand_a = __mul24(cun, m) + nkq;                            // (cumU(k), k)
-        const int b = run_end ? cl - cu : 0;                                 // samples of Q equal to the run of S ending at k
-        const int a = k - start;
-        ab3 += (unsigned)__mul24(__mul24(a, b), a + b);
-        start = run_end ? k : start;
-        const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
-        hi = max(hi, max(ca, cb));
-        lo = min(lo, min(ca, cb));
-      }
-      best = (unsigned)max(hi, -lo);
-    }
-    const unsigned lbest = best;
-    best = seg_allmax_u32<LG>(best);
-
+#endif
     // ---- the float form of D, only for the candidates that reach the integer maximum: the lanes of a position
     // take the bins of one such lane at a time from the table
     double dmax = 0.0;
@@ -525,7 +534,7 @@ void rank_hist_kernel(RankStatsArgs args) {
 #endif
       // the candidate (cumU(0), 0) belongs to lane 0 of the position
       if (gl2 == 0 && (mine & 1u)) {
-        const int cu0 = (int)(tw[1] & 0x7fffu);
+        const int cu0 = (int)(cum & 0xffffu);
         if ((unsigned)__mul24(cu0, mo) == best) dmax = hist_exact_quot(cu0, dq, rq);
       }
       // word offsets of the table entries of bins k - 1, k, k + 1 (k = hl * R + rr + 1) for hl = 0

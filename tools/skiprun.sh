@@ -1,7 +1,7 @@
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cp $R/nanomod_amd/libnanomod_hip.so /tmp/base.so
-for S in 0 1 2 8; do
+for S in 0 1 32 64 96; do
   if [ $S = 0 ]; then cp /tmp/base.so $R/nanomod_amd/libnanomod_hip.so; else cp $R/nanomod_amd/libnanomod_hip_s$S.so $R/nanomod_amd/libnanomod_hip.so; fi
   rm -rf /tmp/p$S
   rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/p$S -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --all-tests --positions 1000000 > /dev/null 2>&1

@@ -1,12 +1,12 @@
-// K1, all-tests form for positions whose two groups fall in the same size class
-// (tests mask = MWU | Welch | KS: what getKStest computes for every position, myDetect.py:327-343).
+// K1, all-tests form for positions whose two groups fall in DIFFERENT capacity classes (e.g. 1000 v 50 reads):
+// rank_pair_kernel, one position per wave, both groups sorted by the 64-lane network (tests mask = MWU | Welch | KS:
+// what getKStest computes for every position, myDetect.py:327-343).  Same-class positions take rank_hist.hpp.
 //
-// Both groups are sorted at once, each in R registers x LG lanes (the two halves of a position's
-// 2*LG lanes run the same bitonic network), the moments are taken on the way, and the run extents of
-// equal keys are written next to the keys.  Call group 1 "A" (m samples) and group 2 "B" (q samples).
-// Every lane of the position then takes B samples x (sorted index j, run [j_s, j_e)) and finds
-// L = #{a < x} by a branchless binary search in A; a tie with A gives U = #{a <= x} from A's run table.
-// At the end of every B run that is everything the three tests need:
+// Call group 1 "A" (m samples) and group 2 "B" (q samples).  Both groups are sorted, the moments are taken on the way,
+// and the run extents of equal keys are written next to the keys.  Every lane then takes samples x of the group with
+// FEWER samples (sorted index j, run [j_s, j_e)) and finds L = #{t < x} by a branchless binary search in the other
+// group; a tie gives U = #{t <= x} from that group's run table.  At the end of every run that is everything the
+// three tests need:
 //   * Mann-Whitney:  sum_{a in A} (2 #{b < a} + #{b == a}) = sum_{b in B} (2m - U(b) - L(b))
 //   * tie correction: sum over pooled tie groups of t^3 - t
 //                     = 3 sum_{elements of A and B} p (p - 1)      (p = position inside its own run)
@@ -18,8 +18,6 @@
 //          (they differ by >= 1/(n0 n1)), so the maximum of the float form over all candidates is
 //          the reference's D bit for bit.  c/n is formed as q0 = c r, q = fma(fma(-q0, n, c), r, q0)
 //          with r = fl(1/n): correctly rounded for every c <= n <= 4096 (checked exhaustively).
-// This replaces the merge-path walk of the pooled sample (one sequential step per pooled element,
-// ~80 VALU instructions each) by one search per B sample spread over all lanes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,11 +25,6 @@
 
 namespace nmod {
 
-__host__ __device__ constexpr int rank_all_pos_words(int R, int LG) {
-  int w = 4 * R * (LG + 1);                               // A keys, A runs, B keys, B runs: four KsLayout regions
-  if (LG == 8) while ((w & 31) != 16) ++w;                // two positions share a 32-lane half: 16 banks apart
-  return w;
-}
 
 // Run extents of equal keys inside each sorted group, (start | end << 16) per element at dst_lane[r * STRIDE],
 // and pp = sum over the lane's elements of p (p - 1), p = 1-based position of the element in its run.
@@ -110,14 +103,6 @@ __device__ __forceinline__ unsigned pad_run_pp(int P) {
   return a * b * c;
 }
 
-// sum of a per-lane fp64 value over the 2*LG lanes of a position
-template <int LG>
-__device__ __forceinline__ double pos_allsum_f64(double v) {
-  if constexpr (LG == 8) return seg_allsum_f64<16>(v);
-  else if constexpr (LG == 16) return seg_allsum_f64<32>(v);
-  else return wave_sum_f64(v);
-}
-
 // fl(c / n) for an integer 0 <= c <= n <= 4096, r = fl(1 / n)
 __device__ __forceinline__ double exact_quot(int c, double n, double r) {
   const double dc = (double)c;
@@ -126,168 +111,8 @@ __device__ __forceinline__ double exact_quot(int c, double n, double r) {
   return __fma_rn(rem, r, q0);
 }
 
-template <int R, int LG, int DTYPE>
-__global__ __launch_bounds__(64 * kWavesPerBlock, (R <= 16 ? 4 : 2))
-void rank_all_kernel(RankStatsArgs args) {
-  static_assert(LG == 8 || LG == 16 || LG == 32, "lanes per group");
-  static_assert(R >= 8 && R <= 32, "registers per lane");
-  constexpr int C = R * LG;                       // capacity per group
-  constexpr int LP = 2 * LG;                      // lanes per position
-  constexpr int PW = 64 / LP;                     // positions per wave
-  using Lay = KsLayout<R, LG>;
-  constexpr int ROW = Lay::ROW;
-  constexpr int REGION = Lay::REGION;             // keys or runs of one group (KsLayout: ks_rank.hpp)
-  constexpr int POS_WORDS = rank_all_pos_words(R, LG);
-  constexpr int LOG_R = (R == 8) ? 3 : (R == 16) ? 4 : 5;
-  static_assert((1 << LOG_R) == R, "registers per lane: 8, 16 or 32");
-  extern __shared__ __attribute__((aligned(16))) float lds_all[];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gl = lane & (LG - 1);                 // lane inside its group
-  const int pl = lane & (LP - 1);                 // lane inside its position
-  const int slot = lane / LP;                     // which of the wave's positions
-  const bool is_b = (lane & LG) != 0;             // second group of the position
-
-  float* keysA = lds_all + (wave * PW + slot) * POS_WORDS;      // run words at + REGION
-  float* keysB = keysA + 2 * REGION;                              // run words at + REGION
-  float* my_keys = (is_b ? keysB : keysA) + gl;                   // this lane's column: register r at + r * ROW
-  int* my_runs = reinterpret_cast<int*>(my_keys + REGION);
-
-  const float inf = __builtin_inff();
-  LaneSel sel;
-#pragma unroll
-  for (int b = 0; b < 6; ++b) sel.s[b] = ((lane >> b) & 1) ? inf : -inf;
-  for (int r = pl; r < R; r += LP) {                                              // the spare column of A
-    keysA[r * ROW + Lay::END] = inf;                                                // rank C: every key is below x
-    reinterpret_cast<int*>(keysA + REGION)[r * ROW + Lay::END] = C | (C << 16);
-  }
-
-  int64_t count = args.npos;
-  const int32_t* list = nullptr;
-  if (args.pos_list) {
-    count = args.class_meta[args.class_id];
-    list = args.pos_list + args.class_meta[kClassStride + args.class_id];
-  }
-  const int64_t items = (count + PW - 1) / PW;
-  const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
-
-  struct Item { bool valid; int n0, n1; int64_t pos, my_off; };
-  auto describe = [&](int64_t it) {
-    Item d;
-    const int64_t li = it * PW + slot;
-    d.valid = it < items && li < count;
-    d.pos = d.valid ? (list ? (int64_t)list[li] : li) : 0;
-    int64_t o0 = 0, o1 = 0;
-    d.n0 = 0; d.n1 = 0;
-    if (d.valid) {
-      if (args.stride0 > 0) { o0 = (int64_t)((uint64_t)(uint32_t)d.pos * (uint64_t)(uint32_t)args.stride0); d.n0 = (int)args.stride0; }
-      else { o0 = args.off0[d.pos]; d.n0 = (int)(args.off0[d.pos + 1] - o0); }
-      if (args.stride1 > 0) { o1 = (int64_t)((uint64_t)(uint32_t)d.pos * (uint64_t)(uint32_t)args.stride1); d.n1 = (int)args.stride1; }
-      else { o1 = args.off1[d.pos]; d.n1 = (int)(args.off1[d.pos + 1] - o1); }
-    }
-    d.my_off = is_b ? o1 : o0;
-    return d;
-  };
-  const void* my_sig = is_b ? args.sig1 : args.sig0;
-
-  // software pipeline (see ks_rank_kernel): the rows of the next item are requested at the top of the loop and
-  // turned into keys at the bottom, a whole item later
-  Item cur = describe(wave_global);
-  float x[R];
-  {
-    KsRows<R, LG, DTYPE> first;
-    first.request(my_sig, cur.my_off, is_b ? cur.n1 : cur.n0, gl);
-    first.finish(x, is_b ? cur.n1 : cur.n0, gl);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-
-  for (int64_t it = wave_global; it < items; it += wave_stride) {
-    const bool valid = cur.valid;
-    const int64_t pos = cur.pos;
-    const int n0 = cur.n0, n1 = cur.n1;
-    const Item nxt = describe(it + wave_stride);
-    KsRows<R, LG, DTYPE> rows_next;
-    rows_next.request(my_sig, nxt.my_off, is_b ? nxt.n1 : nxt.n0, gl);
-
-    {
-      double mean, m2;
-      seg_moments<R, LG, DTYPE>(x, is_b ? n1 : n0, mean, m2);
-      if (valid && gl == 0) {
-        double* mo = args.moments + pos * 4 + (is_b ? 2 : 0);
-        mo[0] = mean; mo[1] = m2;
-      }
-    }
-    seg_sort<R, LG>(x, sel, lane);
-#pragma unroll
-    for (int r = 0; r < R; ++r) my_keys[r * ROW] = x[r];
-    unsigned pp;
-    seg_runs_and_ties<R, LG, ROW>(my_runs, x, gl, is_b, pp);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- every lane of the position ranks B samples pl, pl + LP, ... into A
-    const int m = n0, q = n1;
-    const int per = (q + LP - 1) / LP;
-    int steps_w;
-    if constexpr (PW == 4) {
-      steps_w = max(max(__builtin_amdgcn_readlane(per, 0), __builtin_amdgcn_readlane(per, 16)),
-                    max(__builtin_amdgcn_readlane(per, 32), __builtin_amdgcn_readlane(per, 48)));
-    } else if constexpr (PW == 2) {
-      steps_w = max(__builtin_amdgcn_readlane(per, 0), __builtin_amdgcn_readlane(per, 32));
-    } else {
-      steps_w = __builtin_amdgcn_readfirstlane(per);
-    }
-    const double dm = (double)m, dq = (double)q;
-    const double rm = 1.0 / dm, rq = 1.0 / dq;
-    const int two_m = 2 * m;
-    const bool a_full = __ballot(m == C) != 0ull;       // no +inf pad in some group 1 of the wave: rank C can occur
-    unsigned s_lane = 0;
-    unsigned long long tie3 = 0;
-    double dmax = 0.0;
-#pragma unroll 1
-    for (int s = 0; s < steps_w; ++s) {
-      const int jq = s * LP + pl;
-      const int wq = __mul24(jq & (R - 1), ROW) + (jq >> LOG_R);
-      const float xq = keysB[wq];
-      const int rb = reinterpret_cast<const int*>(keysB + REGION)[wq];
-      const int rb_s = rb & 0xffff, rb_e = (int)((unsigned)rb >> 16);
-      const bool cand = (jq < q) && (rb_e == jq + 1);               // the end of a run of B
-      const float* p = a_full ? ks_search<R, LG, false, true>(keysA, xq) : ks_search<R, LG, false, false>(keysA, xq);
-      const int ra = *reinterpret_cast<const int*>(p + REGION);      // p is the first key of its run: start == L
-      const bool tie = (*p == xq);
-      const int L = ra & 0xffff;
-      const int U = tie ? (int)((unsigned)ra >> 16) : L;
-      const int a = U - L, b = rb_e - rb_s;
-      s_lane += cand ? (unsigned)__mul24(b, two_m - U - L) : 0u;
-      const unsigned ab = cand ? (unsigned)__mul24(a, b) : 0u;
-      if (__ballot(ab != 0u) != 0ull) tie3 += (unsigned long long)ab * (unsigned long long)(unsigned)(a + b);   // (a 64-bit multiply-add)
-      const double d_at = exact_quot(U, dm, rm) - exact_quot(rb_e, dq, rq);
-      const double d_before = exact_quot(L, dm, rm) - exact_quot(rb_s, dq, rq);
-      const double dd = fmax(fabs(d_at), fabs(d_before));
-      dmax = cand ? fmax(dmax, dd) : dmax;
-    }
-    dmax = pos_max_f64<LG>(dmax, lane);
-    const unsigned long long S = pos_sum_u32<LG>(s_lane, lane);
-    const unsigned long long PP = pos_sum_u32<LG>(pp, lane);
-    const double t3 = pos_allsum_f64<LG>((double)tie3);              // < 2^53: exact
-    if (valid && pl == 0) {
-      // the +inf pads of each group form one run of P = C - n keys: take its sum_{p<=P} p (p - 1) = (P^3 - P) / 3 out
-      const unsigned long long pads = (unsigned long long)pad_run_pp(C - m) + (unsigned long long)pad_run_pp(C - q);
-      args.mwu_s[pos] = S;
-      args.tie[pos] = 3ull * (PP - pads) + 3ull * (unsigned long long)t3;
-      args.ks_d_ref[pos] = (m > 0 && q > 0) ? dmax : 0.0;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): requested a whole item ago
-    rows_next.finish(x, is_b ? nxt.n1 : nxt.n0, gl);
-    cur = nxt;
-  }
-}
-
 // ---- any two capacity classes: one position per wave, 64 lanes per group ---------------------------------
-// (e.g. 1000 v 50 reads.)  Same algorithm as rank_all_kernel; the group with FEWER samples is ranked into the
+// (e.g. 1000 v 50 reads.)  The group with FEWER samples is ranked into the
 // one with more, whichever of the two it is:
 //   E = group 2, T = group 1:  rank sum += b (2m - U - L);  KS candidates (c0, c1) = (U, j_e), (L, j_s)
 //   E = group 1, T = group 2:  rank sum += a (L + U)       (2 #{b < x} + #{b == x} per sample of the run);

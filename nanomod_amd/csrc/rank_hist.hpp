@@ -23,8 +23,8 @@
 // into the LDS words of S's keys, which are dead by then — read back R consecutive keys per lane, and finished
 // by as many odd-even transposition phases as the fullest bin holds samples (~1 sample per bin: 8-10 phases of
 // 2 instructions per key against the 44 of a full network).
-// Against rank_all_kernel (both groups sorted by one network, 2 positions per wave, a 72-instruction ranking
-// step per sample of group 2 with four exact fp64 quotients): 4 positions per wave and ~700 instead of ~1000
+// Against round 1's rank_all_kernel (both groups sorted by one network, 2 positions per wave, a 72-instruction
+// ranking step per sample of group 2 with four exact fp64 quotients): 4 positions per wave and 740 instead of 1003
 // VALU instructions per 200 v 200 position.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -460,6 +460,7 @@ void rank_hist_kernel(RankStatsArgs args) {
         const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
         hi = max(hi, max(ca, cb));
         lo = min(lo, min(ca, cb));
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);                // (bounds the number of comparison masks alive at once)
       }
       if (gl2 == 0) hist[0] = 0u;                                            // bin 0: nothing before it
       best = (unsigned)max(hi, -lo);

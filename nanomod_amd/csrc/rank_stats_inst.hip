@@ -20,7 +20,7 @@ constexpr bool ALL = NMOD_INST_ALL != 0;
 using KernelFn = void (*)(RankStatsArgs);
 
 #if NMOD_INST_ALL
-// all-tests builds: rank_all_kernel for same-class positions, rank_pair_kernel (one position per wave) for the rest
+// all-tests builds: rank_hist_kernel for same-class positions, rank_pair_kernel (one position per wave) for the rest
 template <int C0, int C1>
 constexpr KernelFn kernel_of() { return rank_pair_kernel<(1 << C0), (1 << C1), DT>; }
 

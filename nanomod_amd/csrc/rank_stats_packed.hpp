@@ -33,16 +33,6 @@ __device__ __forceinline__ int seg_scan_max_i32(int v) {
   return v;   // LG == 8: lanes 8..15 of a row also see lanes 0..7; callers bias the second group
 }
 
-// all lanes of a 16-lane row get the row's reduction
-template <typename T, typename F>
-__device__ __forceinline__ T row_allreduce_u32(T v, F f) {
-  v = f(v, (T)dpp_i<NMOD_QP(1, 0, 3, 2)>((int)v, (int)v));
-  v = f(v, (T)dpp_i<NMOD_QP(2, 3, 0, 1)>((int)v, (int)v));
-  v = f(v, (T)dpp_i<kDppRowHalfMirror>((int)v, (int)v));
-  v = f(v, (T)dpp_i<kDppRowMirror>((int)v, (int)v));
-  return v;
-}
-
 __device__ __forceinline__ double dpp_f64_row(double x, int which) {
   long long b = __double_as_longlong(x);
   int lo = (int)(unsigned)b, hi = (int)(unsigned)((unsigned long long)b >> 32);
@@ -67,41 +57,6 @@ __device__ __forceinline__ double seg_allsum_f64(double v) {
   v += dpp_f64_row(v, 0); v += dpp_f64_row(v, 1); v += dpp_f64_row(v, 2);
   if constexpr (LG >= 16) v += dpp_f64_row(v, 3);
   if constexpr (LG == 32) v += xor16_f64(v);
-  return v;
-}
-
-// reductions over the 2*LG lanes of one position; every lane gets its own position's result
-template <int LG>
-__device__ __forceinline__ unsigned pos_max_u32(unsigned v, int lane) {
-  v = row_allreduce_u32<unsigned>(v, [](unsigned a, unsigned b) { return max(a, b); });
-  if constexpr (LG == 8) return v;                 // a position is one 16-lane row
-  unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
-  unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
-  if constexpr (LG == 16) return (lane < 32) ? max(r0, r1) : max(r2, r3);
-  else return max(max(r0, r1), max(r2, r3));
-}
-template <int LG>
-__device__ __forceinline__ unsigned long long pos_sum_u32(unsigned v, int lane) {   // per-lane u32, exact u64 total
-  // row totals fit in u32 only if each lane's value < 2^28; callers guarantee that
-  v = row_allreduce_u32<unsigned>(v, [](unsigned a, unsigned b) { return a + b; });
-  if constexpr (LG == 8) return (unsigned long long)v;
-  unsigned long long r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
-  unsigned long long r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
-  if constexpr (LG == 16) return (lane < 32) ? (r0 + r1) : (r2 + r3);
-  else return r0 + r1 + r2 + r3;
-}
-template <int LG>
-__device__ __forceinline__ double pos_max_f64(double v, int lane) {
-  v = fmax(v, dpp_f64_row(v, 0)); v = fmax(v, dpp_f64_row(v, 1));
-  v = fmax(v, dpp_f64_row(v, 2)); v = fmax(v, dpp_f64_row(v, 3));
-  if constexpr (LG >= 16) v = fmax(v, xor16_f64(v));
-  if constexpr (LG == 32) {
-    long long b = __double_as_longlong(v);
-    unsigned lo0 = __builtin_amdgcn_readlane((unsigned)b, 0), hi0 = __builtin_amdgcn_readlane((unsigned)((unsigned long long)b >> 32), 0);
-    unsigned lo1 = __builtin_amdgcn_readlane((unsigned)b, 32), hi1 = __builtin_amdgcn_readlane((unsigned)((unsigned long long)b >> 32), 32);
-    v = fmax(__longlong_as_double((long long)(((unsigned long long)hi0 << 32) | lo0)),
-             __longlong_as_double((long long)(((unsigned long long)hi1 << 32) | lo1)));
-  }
   return v;
 }
 

@@ -94,8 +94,17 @@ def validate(a):
     return errs
 
 
-def _keys(g, chrom_ids):
-    cid = np.array([chrom_ids[c] for c in g['chrom']], dtype=np.int64) if len(g['chrom']) else np.zeros(0, np.int64)
+def _chrom_codes(*chrom_arrays):
+    """sorted chromosome names over all inputs and, per input, the index of every entry's name (vectorised)"""
+    cat = np.concatenate([np.asarray(c) for c in chrom_arrays]) if chrom_arrays else np.zeros(0, dtype=str)
+    names, inv = np.unique(cat, return_inverse=True)
+    out, o = [], 0
+    for c in chrom_arrays:
+        out.append(inv[o:o + len(c)].astype(np.int64)); o += len(c)
+    return [str(n) for n in names.tolist()], out
+
+
+def _keys(g, cid):
     sid = (g['strand'] == '-').astype(np.int64)                                       # '+' sorts before '-'
     return (cid << 41) | (sid << 40) | g['pos'].astype(np.int64)
 
@@ -105,9 +114,8 @@ def select_positions(g0, g1, min_coverage, out_level=detect.OUTPUT_ERROR, log=pr
     # mfilter_coverage (myDetect.py:301-314): per group
     keep0 = np.nonzero(np.diff(g0['off']) >= min_coverage)[0]
     keep1 = np.nonzero(np.diff(g1['off']) >= min_coverage)[0]
-    names = sorted(set(g0['chrom'].tolist()) | set(g1['chrom'].tolist()))
-    chrom_ids = {c: i for i, c in enumerate(names)}
-    k0, k1 = _keys(g0, chrom_ids)[keep0], _keys(g1, chrom_ids)[keep1]
+    names, (cid0, cid1) = _chrom_codes(g0['chrom'], g1['chrom'])
+    k0, k1 = _keys(g0, cid0)[keep0], _keys(g1, cid1)[keep1]
     # positions present in both groups, in sorted (chrom, strand, pos) order (myDetect.py:421,427-431)
     common, i0, i1 = np.intersect1d(k0, k1, assume_unique=True, return_indices=True)
     rows0, rows1 = keep0[i0], keep1[i1]
@@ -124,7 +132,7 @@ def select_positions(g0, g1, min_coverage, out_level=detect.OUTPUT_ERROR, log=pr
     rid = detect.run_ids(chrom, strand, pos)
     n0 = np.diff(off0).astype(np.int32); n1 = np.diff(off1).astype(np.int32)
     meta = dict(chrom=chrom, strand=strand, pos=pos, base=base, n0=n0, n1=n1, names=names,
-                chrom_id=np.array([chrom_ids[c] for c in chrom], dtype=np.int32) if npos else np.zeros(0, np.int32))
+                chrom_id=cid1[rows1].astype(np.int32))
     return meta, sig0, off0, sig1, off1, rid
 
 
@@ -206,21 +214,7 @@ def rank_order(res, method, rank_use, device=0):
 
 
 def write_sign_test(path, meta, res, with_comb):
-    lib = L.load()
-    npos = len(meta['pos'])
-    p = lambda a: a.ctypes.data_as(C.c_void_p)
-    cid = np.ascontiguousarray(meta['chrom_id'], dtype=np.int32)
-    names = b''.join(n.encode() + b'\0' for n in meta['names'])
-    strand = ''.join(meta['strand'].tolist()).encode()
-    base = ''.join(b[:1] if b else ' ' for b in meta['base'].tolist()).encode()
-    pos = np.ascontiguousarray(meta['pos'], dtype=np.int64)
-    n0 = np.ascontiguousarray(meta['n0'], dtype=np.int32); n1 = np.ascontiguousarray(meta['n1'], dtype=np.int32)
-    cols = [np.ascontiguousarray(res[k], dtype=np.float64) for k in ('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p')]
-    comb = [np.ascontiguousarray(res[k], dtype=np.float64) for k in ('comb_st', 'comb_p')] if with_comb else [None, None]
-    rc = lib.nmod_write_sign_test(path.encode(), npos, p(cid), names, len(meta['names']), strand, p(pos), base,
-                                  p(n0), p(n1), *[p(c) for c in cols],
-                                  *(p(c) if c is not None else None for c in comb), 1 if with_comb else 0)
-    L.check(rc, 'nmod_write_sign_test')
+    engine.write_sign_test_host(path, meta, res, with_comb)
 
 
 def main(argv=None):

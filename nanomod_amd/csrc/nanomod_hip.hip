@@ -11,6 +11,8 @@
 #include <stdio.h>
 #include <atomic>
 #include <mutex>
+#include <thread>
+#include <functional>
 
 #include "../../include/nanomod_hip.h"
 #include "rank_stats.hpp"
@@ -904,28 +906,48 @@ int nmod_write_sign_test(const char* path, int64_t npos, const int32_t* chrom_id
   if (npos > 0 && (!chrom_id || !chrom_names || !strand || !pos0 || !base || !n0 || !n1 || !mwu_u || !mwu_p || !t_t ||
                    !t_p || !ks_d || !ks_p || (with_comb && (!comb_st || !comb_p)))) return NMOD_ERR_INVALID_ARG;
   std::vector<const char*> names(n_chroms);
+  size_t longest = 0;
   const char* q = chrom_names;
-  for (int i = 0; i < n_chroms; ++i) { names[i] = q; q += strlen(q) + 1; }
+  for (int i = 0; i < n_chroms; ++i) { names[i] = q; longest = std::max(longest, strlen(q)); q += strlen(q) + 1; }
+  for (int64_t i = 0; i < npos; ++i) if (chrom_id[i] < 0 || chrom_id[i] >= n_chroms) return NMOD_ERR_INVALID_ARG;
   FILE* f = fopen(path, "w");
   if (!f) return NMOD_ERR_INVALID_ARG;
-  std::vector<char> buf(1 << 22);
-  size_t used = 0;
-  for (int64_t i = 0; i < npos; ++i) {
-    if (chrom_id[i] < 0 || chrom_id[i] >= n_chroms) { fclose(f); return NMOD_ERR_INVALID_ARG; }
-    const char* cn = names[chrom_id[i]];
-    size_t need = strlen(cn) + 4096;
-    if (used + need > buf.size()) { fwrite(buf.data(), 1, used, f); used = 0; if (need > buf.size()) buf.resize(need); }
-    char* p = buf.data() + used;
-    p += snprintf(p, need - 3072, "%s %c %lld %c %d %d ", cn, strand[i], (long long)(pos0[i] + 1), base[i], n0[i], n1[i]);
-    p = put_f3(p, mwu_u[i]); *p++ = ' '; p = put_e3(p, mwu_p[i]); *p++ = ' ';
-    p = put_f3(p, t_t[i]); *p++ = ' '; p = put_e3(p, t_p[i]); *p++ = ' ';
-    p = put_f3(p, ks_d[i]); *p++ = ' '; p = put_e3(p, ks_p[i]);
-    if (with_comb) { *p++ = ' '; p = put_f3(p, comb_st[i]); *p++ = ' '; p = put_e3(p, comb_p[i]); }
-    *p++ = '\n';
-    used = p - buf.data();
+  // lines are formatted by several host threads, a block of positions each, and written in order
+  const size_t line_cap = longest + 4096;              // '%.3f' of a value near DBL_MAX prints ~310 digits, eight of them never do
+  auto format_block = [&](int64_t lo, int64_t hi, std::vector<char>& buf) {
+    buf.clear();
+    buf.reserve((size_t)(hi - lo) * 160);
+    std::vector<char> line(line_cap);
+    for (int64_t i = lo; i < hi; ++i) {
+      char* p = line.data();
+      p += snprintf(p, longest + 128, "%s %c %lld %c %d %d ", names[chrom_id[i]], strand[i], (long long)(pos0[i] + 1), base[i], n0[i], n1[i]);
+      p = put_f3(p, mwu_u[i]); *p++ = ' '; p = put_e3(p, mwu_p[i]); *p++ = ' ';
+      p = put_f3(p, t_t[i]); *p++ = ' '; p = put_e3(p, t_p[i]); *p++ = ' ';
+      p = put_f3(p, ks_d[i]); *p++ = ' '; p = put_e3(p, ks_p[i]);
+      if (with_comb) { *p++ = ' '; p = put_f3(p, comb_st[i]); *p++ = ' '; p = put_e3(p, comb_p[i]); }
+      *p++ = '\n';
+      buf.insert(buf.end(), line.data(), p);
+    }
+  };
+  const int64_t kBlock = 1 << 16;
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(hw ? hw : 1), 16, (npos + kBlock - 1) / kBlock}));
+  bool ok = true;
+  std::vector<std::vector<char>> bufs(nthreads);
+  for (int64_t base_pos = 0; base_pos < npos && ok; base_pos += kBlock * nthreads) {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) {
+      const int64_t lo = base_pos + (int64_t)t * kBlock, hi = std::min(npos, lo + kBlock);
+      if (lo >= npos) { bufs[t].clear(); continue; }
+      if (nthreads == 1) format_block(lo, hi, bufs[t]);
+      else th.emplace_back(format_block, lo, hi, std::ref(bufs[t]));
+    }
+    for (auto& x : th) x.join();
+    for (int t = 0; t < nthreads && ok; ++t)
+      if (!bufs[t].empty()) ok = fwrite(bufs[t].data(), 1, bufs[t].size(), f) == bufs[t].size();
   }
-  if (used) fwrite(buf.data(), 1, used, f);
-  return fclose(f) == 0 ? NMOD_OK : NMOD_ERR_INVALID_ARG;
+  const bool closed = fclose(f) == 0;
+  return (ok && closed) ? NMOD_OK : NMOD_ERR_INVALID_ARG;
 }
 
 int nmod_selftest(int32_t device) {

@@ -170,37 +170,113 @@ def combin_pvalues(moptions):
 
 
 # ---------------------------------------------------------------------------
+class SignTestRecords:
+    """`moptions['sign_test']` as the reference builds it (myDetect.py:436) — a sequence of
+    ((chrom, strand, pos, base, n0, n1), [(U, pU), (t, pt), (D, pKS)[, (comb stat, comb p)]]) records — backed by
+    the result arrays: a record is built when it is first asked for and kept (so `sorted_sign_test` holds the same
+    objects), 4.6 M tuples are not built up front.  Supports what the reference's consumers do: len, indexing,
+    slicing, iteration, sorted()."""
+
+    def __init__(self, meta, res, with_comb, order=None, parent=None):
+        self._meta, self._res, self._with_comb = meta, res, with_comb
+        self._order = order
+        self._parent = parent
+        self._cache = {} if parent is None else None
+
+    def __len__(self):
+        return len(self._order) if self._order is not None else len(self._meta['pos'])
+
+    def _build(self, i):
+        m, r = self._meta, self._res
+        rec = ((str(m['chrom'][i]), str(m['strand'][i]), int(m['pos'][i]), str(m['base'][i]), int(m['n0'][i]), int(m['n1'][i])),
+               [(float(r['mwu_u'][i]), float(r['mwu_p'][i])), (float(r['t_t'][i]), float(r['t_p'][i])),
+                (float(r['ks_d'][i]), float(r['ks_p'][i]))])
+        if self._with_comb:
+            rec[1].append((float(r['comb_st'][i]), float(r['comb_p'][i])))
+        return rec
+
+    def _get(self, i):
+        if self._parent is not None:
+            return self._parent._get(i)
+        rec = self._cache.get(i)
+        if rec is None:
+            rec = self._cache[i] = self._build(i)
+        return rec
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        n = len(self)
+        if k < 0:
+            k += n
+        if not 0 <= k < n:
+            raise IndexError('list index out of range')
+        return self._get(int(self._order[k]) if self._order is not None else k)
+
+    def __iter__(self):
+        for k in range(len(self)):
+            yield self[k]
+
+    def permuted(self, order):
+        """the same records in another order (the ranking)"""
+        return SignTestRecords(self._meta, self._res, self._with_comb, order=np.asarray(order), parent=self if self._parent is None else self._parent)
+
+
 def build_csr(moptions):
-    """The tested-position set and order of mtest2 (myDetect.py:421,427-431) as CSR arrays."""
+    """The tested-position set and order of mtest2 (myDetect.py:421,427-431) as CSR arrays + array-shaped metadata.
+
+    Three input shapes, fastest first: (i) both datasets carry `'nmod_container'` — the flat arrays of
+    nanomod_amd.container (what a loader that never builds the dicts attaches): filter, intersection and order are
+    numpy operations (cli.select_positions; the caller has NOT run mfilter_coverage, it happens here); (ii) the
+    reference's dicts whose per-position values are numpy arrays: no per-value conversion; (iii) the reference's
+    dicts of Python lists of numpy.float64 (myDetect.py:124)."""
     ds0 = moptions[moptions['ds2'][0]]
     ds1 = moptions[moptions['ds2'][1]]
-    meta = []
+    if 'nmod_container' in ds0 and 'nmod_container' in ds1:
+        from . import cli
+        meta, sig0, off0, sig1, off1, rid = cli.select_positions(ds0['nmod_container'], ds1['nmod_container'],
+                                                                 moptions['MinCoverage'], moptions.get('outLevel', OUTPUT_ERROR))
+        return meta, sig0, off0, sig1, off1, rid
+    chrom, strand, pos, base, n0, n1 = [], [], [], [], [], []
     chunks0, chunks1 = [], []
     for sk in sorted(ds0['norm_mean'].keys()):
         if sk not in ds1['norm_mean']:
             continue
         d0, d1 = ds0['norm_mean'][sk], ds1['norm_mean'][sk]
+        b0s, b1s = ds0['base'][sk], ds1['base'][sk]
+        quiet = moptions.get('outLevel', OUTPUT_ERROR) > OUTPUT_ERROR
         for pk in sorted(d0.keys()):
             if pk not in d1:
                 continue
-            b1, b0 = ds1['base'][sk][pk], ds0['base'][sk][pk]
-            if not b1 == b0 and moptions.get('outLevel', OUTPUT_ERROR) <= OUTPUT_ERROR:
+            b1, b0 = b1s[pk], b0s[pk]
+            if not b1 == b0 and not quiet:
                 print('Error not equal', sk, pk, b1, b0)
             a, b = d0[pk], d1[pk]
-            meta.append((sk[0], sk[1], pk, b1, len(a), len(b)))
-            chunks0.append(np.asarray(a, dtype=np.float64))
-            chunks1.append(np.asarray(b, dtype=np.float64))
-    npos = len(meta)
+            chrom.append(sk[0]); strand.append(sk[1]); pos.append(pk); base.append(b1)
+            n0.append(len(a)); n1.append(len(b))
+            chunks0.append(a); chunks1.append(b)
+    npos = len(pos)
     off0 = np.zeros(npos + 1, dtype=np.int64)
     off1 = np.zeros(npos + 1, dtype=np.int64)
     if npos:
-        off0[1:] = np.cumsum([m[4] for m in meta])
-        off1[1:] = np.cumsum([m[5] for m in meta])
-        both = encode_signals(np.concatenate(chunks0 + chunks1))
+        off0[1:] = np.cumsum(n0)
+        off1[1:] = np.cumsum(n1)
+
+        def flat(chunks, total):
+            if isinstance(chunks[0], np.ndarray):
+                return np.concatenate(chunks).astype(np.float64, copy=False)
+            import itertools
+            return np.fromiter(itertools.chain.from_iterable(chunks), dtype=np.float64, count=total)   # one pass, no per-position arrays
+        both = encode_signals(np.concatenate([flat(chunks0, int(off0[-1])), flat(chunks1, int(off1[-1]))]))
         sig0, sig1 = both[:off0[-1]], both[off0[-1]:]
     else:
         sig0 = sig1 = np.zeros(0, dtype=np.float32)
-    rid = run_ids([m[0] for m in meta], [m[1] for m in meta], [m[2] for m in meta])
+    names = sorted(set(chrom))
+    ids = {c: i for i, c in enumerate(names)}
+    meta = dict(chrom=np.array(chrom, dtype=object), strand=np.array(strand, dtype=object), pos=np.array(pos, dtype=np.int64),
+                base=np.array(base, dtype=object), n0=np.array(n0, dtype=np.int32), n1=np.array(n1, dtype=np.int32), names=names,
+                chrom_id=np.array([ids[c] for c in chrom], dtype=np.int32))
+    rid = run_ids(meta['chrom'], meta['strand'], meta['pos'])
     return meta, sig0, off0, sig1, off1, rid
 
 
@@ -264,43 +340,40 @@ def downsample_update(res, sig0, off0, sig1, off1, rid, strands, coverages, *, i
 def mtest2(moptions):
     print("Start sorting")
     meta, sig0, off0, sig1, off1, rid = build_csr(moptions)
+    npos = len(meta['pos'])
     method = moptions['testMethod']
     nb = moptions['neighborPvalues']
     want_mstd = not moptions.get('mstd', 0) == 0
+    dev = moptions.get('nmod_device', 0)
     start_time = time.time()
     # the combine is skipped for 'ks' (myDetect.py:443); for nb == 0 it returns the KS tuple (:413)
     dev_method = method if (method in ('stouffer', 'fisher') and nb > 0) else 'ks'
-    if method not in ('ks', 'stouffer', 'fisher') and nb > 0 and len(meta) > 0:
+    if method not in ('ks', 'stouffer', 'fisher') and nb > 0 and npos > 0:
         raise UnboundLocalError("local variable 'comb_p_p' referenced before assignment")       # as the reference
     res = engine.detect_host(sig0, off0, sig1, off1, rid, nb=max(nb, 0), weights_dif=moptions.get('WeightsDif', 2.0),
-                             method=dev_method, want_mstd=want_mstd, device=moptions.get('nmod_device', 0))
-    if len(meta) and np.any(res['status'] & L.STATUS_MWU_ALL_IDENTICAL):
+                             method=dev_method, want_mstd=want_mstd, device=dev)
+    if npos and np.any(res['status'] & L.STATUS_MWU_ALL_IDENTICAL):
         raise ValueError('All numbers are identical in mannwhitneyu')                             # scipy 1.2.1, uncaught in the reference
-    if len(meta):
-        downsample_update(res, sig0, off0, sig1, off1, rid, [m[1] for m in meta], moptions.get('coverages', (0, 0)),
+    if npos:
+        downsample_update(res, sig0, off0, sig1, off1, rid, meta['strand'], moptions.get('coverages', (0, 0)),
                           iters=int(moptions.get('downsampling', 100)), quantile=float(moptions.get('downsampling_quantile', 0.25)),
                           seed=int(moptions.get('nmod_seed', 0)), nb=nb, weights_dif=moptions.get('WeightsDif', 2.0),
-                          method=dev_method, device=moptions.get('nmod_device', 0))
-    cols = [res[k].tolist() for k in ('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p')]
-    sign_test = [(m, [(u, pu), (t, pt), (d, pk)]) for m, u, pu, t, pt, d, pk in zip(meta, *cols)]
+                          method=dev_method, device=dev)
+    with_comb = not method == "ks" and nb >= 0
+    if with_comb and nb == 0:                                                                     # myDetect.py:413: the KS tuple itself
+        res['comb_st'], res['comb_p'] = res['ks_d'], res['ks_p']
+    sign_test = SignTestRecords(meta, res, with_comb)
     moptions['sign_test'] = sign_test
+    moptions['sign_test_arrays'] = res
+    moptions['sign_test_meta'] = meta
     if want_mstd:
         moptions['sign_test_mstd'] = {
-            (m[0], m[1], m[2]): [[m0, s0], [m1, s1]]
-            for m, m0, s0, m1, s1 in zip(meta, res['mean0'].tolist(), res['std0'].tolist(),
-                                         res['mean1'].tolist(), res['std1'].tolist())}
+            (str(c), str(s), int(p)): [[m0, s0], [m1, s1]]
+            for c, s, p, m0, s0, m1, s1 in zip(meta['chrom'].tolist(), meta['strand'].tolist(), meta['pos'].tolist(),
+                                               res['mean0'].tolist(), res['std0'].tolist(), res['mean1'].tolist(), res['std1'].tolist())}
     end_time = time.time()
     if moptions.get('outLevel', OUTPUT_ERROR) <= OUTPUT_INFO:
         print("Producing pvalues: consuming time %d" % (end_time - start_time))
-
-    if not method == "ks":
-        if nb > 0:
-            for r, s, p in zip(sign_test, res['comb_st'].tolist(), res['comb_p'].tolist()):
-                r[1].append((s, p))
-        elif nb == 0:
-            for r in sign_test:
-                r[1].append(r[1][2])
-    moptions['sign_test_arrays'] = res
 
     use_pind = 1 if moptions.get('rankUse', 'pv') == 'pv' else 0
     sorted_ind = 2 if method == "ks" else 3
@@ -313,17 +386,17 @@ def mtest2(moptions):
         ks_key = res['ks_p'] if use_pind else res['ks_d']
         mw_key = res['mwu_p'] if use_pind else res['mwu_u']
         first = ks_key if (method == 'ks' or nb == 0) else res['comb_p' if use_pind else 'comb_st']
-        if len(sign_test):
-            order = engine.rank_order_host(first, ks_key, mw_key, descending=(use_pind == 0),
-                                           device=moptions.get('nmod_device', 0))
-            moptions['sorted_sign_test'] = [sign_test[i] for i in order.tolist()]
+        if npos:
+            order = engine.rank_order_host(first, ks_key, mw_key, descending=(use_pind == 0), device=dev)
+            moptions['sorted_sign_test'] = sign_test.permuted(order)
         else:
             moptions['sorted_sign_test'] = []
     else:
         moptions['sorted_sign_test'] = region_rank(moptions, sorted_ind, use_pind)
 
 
-# myDetect.py:522-545
+# myDetect.py:522-545 — the table lines are written by the library (nmod_write_sign_test), from the result arrays of
+# mtest2 or, for a hand-built `sign_test` list, from arrays gathered out of its records
 def save_test(moptions):
     print('SaveTest', moptions['SaveTest'])
     if moptions['SaveTest'] == 0:
@@ -333,20 +406,31 @@ def save_test(moptions):
     if moptions.get('outLevel', OUTPUT_ERROR) <= OUTPUT_ERROR:
         print('Test data is saved in', txtfile)
     with_comb = moptions["neighborPvalues"] > 0 and (not moptions["testMethod"] == "ks")
-    with open(txtfile, 'w') as txtwriter:
-        for mostp in moptions['sign_test']:
-            line = '%s %s %d %s %d %d %.3f %.3E %.3f %.3E %.3f %.3E' % (
-                mostp[0][0], mostp[0][1], mostp[0][2] + 1, mostp[0][3], mostp[0][4], mostp[0][5],
-                mostp[1][0][0], mostp[1][0][1], mostp[1][1][0], mostp[1][1][1], mostp[1][2][0], mostp[1][2][1])
-            if with_comb:
-                line += ' %.3f %.3E\n' % (mostp[1][3][0], mostp[1][3][1])
-            else:
-                line += '\n'
-            txtwriter.write(line)
+    recs = moptions['sign_test']
+    if isinstance(recs, SignTestRecords) and recs._parent is None and recs._order is None:
+        meta, res = recs._meta, recs._res
+    else:
+        meta, res = _arrays_from_records(recs, with_comb)
+    engine.write_sign_test_host(txtfile, meta, res, with_comb)
     if not moptions.get('mstd', 0) == 0:
         with open(moptions['outFolder'] + '/' + moptions["FileID"] + '_meanstd.cvs', 'w') as mw:
-            for mostp in moptions['sign_test']:
-                _t_k = (mostp[0][0], mostp[0][1], mostp[0][2])
-                ms = moptions['sign_test_mstd'][_t_k]
-                mw.write("%s %s %d %s %.3f %.3f %.3f %.3f\n" % (
-                    mostp[0][0], mostp[0][1], mostp[0][2], mostp[0][3], ms[0][0], ms[0][1], ms[1][0], ms[1][1]))
+            for c, st, p, b in zip(meta['chrom'].tolist(), meta['strand'].tolist(), meta['pos'].tolist(), meta['base'].tolist()):
+                ms = moptions['sign_test_mstd'][(str(c), str(st), int(p))]
+                mw.write("%s %s %d %s %.3f %.3f %.3f %.3f\n" % (c, st, p, b, ms[0][0], ms[0][1], ms[1][0], ms[1][1]))
+
+
+def _arrays_from_records(recs, with_comb):
+    n = len(recs)
+    chrom = np.array([r[0][0] for r in recs], dtype=object)
+    names = sorted(set(chrom.tolist()))
+    ids = {c: i for i, c in enumerate(names)}
+    meta = dict(chrom=chrom, strand=np.array([r[0][1] for r in recs], dtype=object),
+                pos=np.fromiter((r[0][2] for r in recs), dtype=np.int64, count=n),
+                base=np.array([r[0][3] for r in recs], dtype=object),
+                n0=np.fromiter((r[0][4] for r in recs), dtype=np.int32, count=n),
+                n1=np.fromiter((r[0][5] for r in recs), dtype=np.int32, count=n), names=names,
+                chrom_id=np.array([ids[c] for c in chrom.tolist()], dtype=np.int32))
+    cols = (('mwu_u', 0, 0), ('mwu_p', 0, 1), ('t_t', 1, 0), ('t_p', 1, 1), ('ks_d', 2, 0), ('ks_p', 2, 1)) + \
+           ((('comb_st', 3, 0), ('comb_p', 3, 1)) if with_comb else ())
+    res = {k: np.fromiter((r[1][a][b] for r in recs), dtype=np.float64, count=n) for k, a, b in cols}
+    return meta, res

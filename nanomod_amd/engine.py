@@ -125,6 +125,26 @@ def region_rank_host(strand_lo, strand_hi, pos, base, value, w, movesize, na, pe
     return out[:cnt.value]
 
 
+def write_sign_test_host(path, meta, res, with_comb):
+    """save_test's table (myDetect.py:522-538) through nmod_write_sign_test.  meta: arrays chrom_id (int32), pos
+    (int64, 0-based), strand / base (one character each), n0 / n1 (int32) + the list `names` that chrom_id indexes."""
+    lib = L.load()
+    npos = len(meta['pos'])
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    cid = np.ascontiguousarray(meta['chrom_id'], dtype=np.int32)
+    names = b''.join(str(n).encode() + b'\0' for n in meta['names'])
+    strand = ''.join(str(x)[:1] or ' ' for x in meta['strand'].tolist()).encode()
+    base = ''.join(str(b)[:1] or ' ' for b in meta['base'].tolist()).encode()
+    pos = np.ascontiguousarray(meta['pos'], dtype=np.int64)
+    n0 = np.ascontiguousarray(meta['n0'], dtype=np.int32); n1 = np.ascontiguousarray(meta['n1'], dtype=np.int32)
+    cols = [np.ascontiguousarray(res[k], dtype=np.float64) for k in ('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p')]
+    comb = [np.ascontiguousarray(res[k], dtype=np.float64) for k in ('comb_st', 'comb_p')] if with_comb else [None, None]
+    rc = lib.nmod_write_sign_test(str(path).encode(), npos, p(cid), names, len(meta['names']), strand, p(pos), base,
+                                  p(n0), p(n1), *[p(c) for c in cols],
+                                  *(p(c) if c is not None else None for c in comb), 1 if with_comb else 0)
+    L.check(rc, 'nmod_write_sign_test')
+
+
 class EventTimer:
     """HIP-event timer handle (nmod_evtimer_*): per-kernel elapsed ms measured on the launch stream."""
 

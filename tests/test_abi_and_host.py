@@ -97,12 +97,12 @@ def test_filter_order_and_table_format_without_gpu():
         mo = H.build_moptions(fx, out, 'x', 2, 2.0, 'stouffer')
         D.mfilter_coverage(mo)
         meta, sig0, off0, sig1, off1, rid = D.build_csr(mo)
-        assert [(m[0], m[1], m[2], m[3], m[4], m[5]) for m in meta] == list(zip(
+        assert list(zip(meta['chrom'], meta['strand'], meta['pos'], meta['base'], meta['n0'], meta['n1'])) == list(zip(
             exp['chrom'], exp['strand'], exp['pos'], exp['base'], exp['n0'], exp['n1']))
         assert sig0.dtype == np.float32 and off0[-1] == sig0.shape[0]
         mo['sign_test'] = [(m, [(exp['mwu_u'][i], exp['mwu_p'][i]), (exp['t_t'][i], exp['t_p'][i]),
                                 (exp['ks_d'][i], exp['ks_p'][i]), (exp['comb_st'][i], exp['comb_p'][i])])
-                           for i, m in enumerate(meta)]
+                           for i, m in enumerate(zip(meta['chrom'], meta['strand'], meta['pos'], meta['base'], meta['n0'], meta['n1']))]
         D.save_test(mo)
         assert open(os.path.join(out, 'x_sign_test.txt')).read() == table
 

@@ -57,8 +57,9 @@ def test_oracle_reproduces_reference_tables(inp, name, nb, wdif, method):
     mo = H.build_moptions(fx, tempfile.gettempdir(), name, nb, wdif, method)
     D.mfilter_coverage(mo)
     meta, sig0, off0, sig1, off1, rid = D.build_csr(mo)
-    assert [m[0] for m in meta] == list(exp['chrom']) and [m[2] for m in meta] == list(exp['pos'])
-    assert [m[3] for m in meta] == list(exp['base'])
+    assert list(meta['chrom']) == list(exp['chrom']) and list(meta['pos']) == list(exp['pos'])
+    assert list(meta['base']) == list(exp['base'])
+    meta = list(zip(meta['chrom'], meta['strand'], meta['pos'], meta['base'], meta['n0'], meta['n1']))
     out = orc.detect_batch(sig0, off0, sig1, off1, rid, nb, wdif, METHOD[method])
     with_comb = method != 'ks'
     H.compare_outputs(out, exp, with_comb, p_rel=1e-12)

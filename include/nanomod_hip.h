@@ -36,13 +36,17 @@ enum {
   NMOD_DTYPE_F32 = 0,       /* canonical: float32 (values up-cast exactly to the fp64 the reference sees) */
   NMOD_DTYPE_I16_MILLI = 1, /* int16 = round(norm_mean*1000): NanoMod's Events are 3-dp rounded
                                (myRefBaseSignalAnnotation.py:1108); value = k/1000.0 in fp64 */
-  NMOD_DTYPE_F64 = 2        /* float64 as the reference holds it (lists of numpy.float64, myDetect.py:124).  The
-                               library re-encodes it on the device without changing a value the reference would
-                               see: float32 if every sample of the batch is float32-exact, else int16 milli-units
-                               if every sample is k/1000.0 with |k| <= 32767 (one extra pass over the samples and
-                               one host round trip); anything else is sorted as it is, with 64-bit keys, every
-                               position through the workgroup-per-position kernel (big_rank.hpp) — correct for any
-                               input the reference accepts, ~3e7 positions/s at 200 v 200. */
+  NMOD_DTYPE_F64 = 2        /* float64 as the reference holds it (lists of numpy.float64, myDetect.py:124).  The rank
+                               statistics depend on the order of a position's samples only, so the library gives every
+                               POSITION order- and tie-preserving float32 keys on the device: the samples themselves if all
+                               of them are float32-exact, k if all are k/1000.0 with |k| <= 2^24 (NanoMod's 3-dp Events),
+                               else their float32 roundings — monotone, so the only possible damage is a false tie between
+                               two different doubles; the kernels report the positions whose keys tie and those (rare for
+                               real-valued signals) are redone on the float64 samples with 64-bit keys (big_rank.hpp).  The
+                               Welch moments always come from the float64 samples.  One extra pass over the samples, one
+                               host round trip (the count of positions to redo).  ~3.5e8 positions/s KS-only, 2e8 with all
+                               tests at 200 v 200; a batch made of doubles with exact ties that are neither float32-exact
+                               nor on the 0.001 grid runs at the 64-bit-key rate, ~4e7 positions/s. */
 };
 
 /* where the caller's buffers live */

@@ -210,7 +210,12 @@ __device__ __forceinline__ const float* ks_search(const float* base, float x, co
 // second launch-bound argument = minimum waves per SIMD: keeps every form whose LDS footprint allows
 // four waves per SIMD (R <= 16; the R = 32 forms are limited to two by their LDS) at <= 128 VGPRs (the compiler otherwise spends 130-175 registers on scheduling
 // freedom and occupancy drops to 2-3); no spills result
-template <int R, int LG, int DTYPE>
+// FLAGS: also report per position whether a sample of Q tied with a key of S (args.tied).  The float64 front end
+// ranks order-preserving float32 images of the samples; where no two images tie the ranks are those of the float64
+// samples themselves, and the flagged positions are redone with 64-bit keys (nanomod_hip.hip: detect_f64).  For the KS
+// statistic only ties BETWEEN the groups matter: two keys of S with equal images and no sample of Q on them bound a
+// pooled point that lies between its neighbours' values of |F0 - F1|.
+template <int R, int LG, int DTYPE, bool FLAGS = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (R <= 16 ? 4 : 2))
 void ks_rank_kernel(RankStatsArgs args) {
   static_assert(LG == 8 || LG == 16 || LG == 32 || LG == 64, "lanes per sorted group");
@@ -372,6 +377,9 @@ void ks_rank_kernel(RankStatsArgs args) {
 
     // ---- rank every Q sample into S
     bool any_tie = false;
+    bool tie_lane = false;                     // FLAGS, "own" schedule: this lane saw a tie of its position
+    unsigned tie_coop = 0u;                    // FLAGS, "coop" schedule: bit sl = position sl of the wave saw one
+    int coop_sl = 0;
     // a sorted group that fills its capacity exactly has no +inf pad: only then can a sample rank above every key
     const bool s_full = __ballot(m == Lay::C) != 0ull;
 
@@ -386,6 +394,13 @@ void ks_rank_kernel(RankStatsArgs args) {
       bool eq[NV];
 #pragma unroll
       for (int e = 0; e < NV; ++e) eq[e] = (*lp[e] == xq[e]);                       // key C is +inf
+      if constexpr (FLAGS) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+          tie_lane = tie_lane || eq[e];
+          if (__ballot(eq[e]) != 0ull) tie_coop |= 1u << coop_sl;
+        }
+      }
       // Per sample slot: a slot in which no lane ties with S (the usual case) adds L and U in one go; a slot with
       // ties — common for 3-dp rounded signals and the synthetic grid — takes U = L + 1 (the next row of the
       // column, or row 0 of the next column when L is in the last row), and only if that next key ties again
@@ -437,6 +452,7 @@ void ks_rank_kernel(RankStatsArgs args) {
       slots = (cfull * 4 + (q - cfull * 256 + 63) / 64) * 64;        // per position: what the 64 lanes will process
 #pragma unroll 1
       for (int sl = 0; sl < PW; ++sl) {
+        coop_sl = sl;
         const int src = sl * LG;
         const int qs = __builtin_amdgcn_readlane(q, src);
         const unsigned long long sp = (unsigned long long)(uintptr_t)sig_q;
@@ -541,6 +557,10 @@ void ks_rank_kernel(RankStatsArgs args) {
     }
     best = seg_allmax_u32<LG>(best);
     if (valid && gl == 0) args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;
+    if constexpr (FLAGS) {
+      const unsigned t = coop ? ((tie_coop >> slot) & 1u) : seg_allmax_u32<LG>(tie_lane ? 1u : 0u);
+      if (valid && gl == 0) args.tied[pos] = (uint8_t)t;
+    }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0x0F70);
     rows_next.finish(x, nxt.m, gl);

@@ -61,13 +61,16 @@ struct ScopedKernelTimer {
 struct Workspace {
   uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments;
   double* tmp_ks_d; double* tmp_ks_p; double* ks_d_ref;
-  int32_t* order; uint8_t* cls; int32_t* meta;     // meta: [c] counts, [48 + c] offsets, [96 + c] cursors, [144..145] max n0/n1
+  int32_t* order; uint8_t* cls; uint8_t* tied; int32_t* meta;   // meta: [c] counts, [48 + c] offsets, [96 + c] cursors, [144..145] max n0/n1
   int64_t bytes;
 };
-constexpr int kMetaInts = 160;
+constexpr int kMetaInts = 224;
 constexpr int kMetaMax = 3 * kClassStride;      // [144..145] max n0 / n1
 constexpr int kMetaBigTotal = kMetaMax + 2;     // [146..147] u64: scratch floats the large positions need
 constexpr int kMetaBigCursor = kMetaMax + 4;    // [148..149] u64: bump allocator of big_rank_kernel
+constexpr int kMetaRedo = 160;                  // float64 front end: [160] count of positions to redo, [160 + kClassStride] = 0 (their offset
+                                                // in the list), [210..211] u64 scratch keys they need, [212..213] u64 bump allocator
+constexpr int kMetaRedoTotal = 210, kMetaRedoCursor = 212;
 constexpr int kBigClass = kNumClasses;          // 47: positions for big_rank_kernel (big_rank.hpp)
 constexpr int kNumPairs = kNumClasses + 1;      // <= kClassStride
 static_assert(kNumPairs <= kClassStride, "class tables");
@@ -88,6 +91,7 @@ static Workspace carve(void* base, int64_t npos) {
   w.ks_d_ref = (double*)take(8 * npos);
   w.order = (int32_t*)take(4 * npos);
   w.cls = (uint8_t*)take(npos);
+  w.tied = (uint8_t*)take(npos);
   w.meta = (int32_t*)take(kMetaInts * 4);
   w.bytes = o;
   return w;
@@ -212,25 +216,99 @@ __global__ __launch_bounds__(256) void scatter_kernel(BinArgs a) {
 }
 
 // ---------------------------------------------------------------- float64 input (NMOD_DTYPE_F64)
-// flags[0] stays 1 while every sample is float32-exact, flags[1] while every sample is k/1000.0, |k| <= 32767
-__global__ __launch_bounds__(256) void f64_probe_kernel(const double* a, int64_t na, const double* b, int64_t nb, int32_t* flags) {
-  bool f32_ok = true, grid_ok = true;
-  const int64_t n = na + nb;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const double v = i < na ? a[i] : b[i - na];
-    f32_ok = f32_ok && ((double)(float)v == v);
-    const double k = rint(v * 1000.0);
-    grid_ok = grid_ok && (fabs(k) <= 32767.0) && (k / 1000.0 == v);
-  }
-  if (__ballot(!f32_ok) != 0ull && (threadIdx.x & 63) == 0) atomicAnd(&flags[0], 0);
-  if (__ballot(!grid_ok) != 0ull && (threadIdx.x & 63) == 0) atomicAnd(&flags[1], 0);
+// The reference holds its samples as float64 (myDetect.py:124).  All the rank statistics depend on the ORDER of a
+// position's samples only, so every position gets float32 keys that preserve its order and its ties:
+//   class 1  every sample of the position is float32-exact                      key = (float)x         (exact)
+//   class 2  every sample is k / 1000.0 with |k| <= 2^24 (NanoMod's 3-dp Events)  key = (float)k         (exact)
+//   class 3  anything else                                                       key = (float)x, rounded to nearest
+// Rounding is monotone (x <= y => key(x) <= key(y)) and keeps ties, so in class 3 the only possible damage is a FALSE
+// tie between two different samples.  K1 reports the positions in which keys tie (RankStatsArgs::tied); those among
+// the class-3 positions — rare for real-valued signals — are redone by big_rank_kernel<2> on the float64 samples
+// themselves.  The Welch moments never come from the keys: f64_moments_kernel takes them from the samples.
+struct F64Args {
+  const double* d0; const double* d1;          // the caller's samples (index space of the offsets)
+  const int64_t* off0; const int64_t* off1; int64_t stride0, stride1;
+  int64_t npos;
+  float* k0; float* k1;                        // keys, same index space
+  uint8_t* cls3;                               // [npos] 1 = class 3
+  const uint8_t* tied; const uint8_t* cls;     // K1's tie flags; the size-class byte of the binning (null: no binning ran)
+  int32_t* order; int32_t* meta;               // redo list (ws.order) and its counters (ws.meta + kMetaRedo ...)
+  double* moments;
+};
+
+__device__ __forceinline__ void f64_rows(const F64Args& a, int64_t p, int64_t& o0, int& n0, int64_t& o1, int& n1) {
+  if (a.stride0 > 0) { o0 = p * a.stride0; n0 = (int)a.stride0; } else { o0 = a.off0[p]; n0 = (int)(a.off0[p + 1] - o0); }
+  if (a.stride1 > 0) { o1 = p * a.stride1; n1 = (int)a.stride1; } else { o1 = a.off1[p]; n1 = (int)(a.off1[p + 1] - o1); }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void f64_encode_kernel(const double* in, int64_t n, T* out) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    if constexpr (sizeof(T) == 4) out[i] = (T)in[i];
-    else out[i] = (T)rint(in[i] * 1000.0);
+// one wave per position: classify (first sweep), write the keys (second sweep: the samples come from L2)
+__global__ __launch_bounds__(256) void f64_encode_kernel(F64Args a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), ws = (int64_t)gridDim.x * 4;
+  for (int64_t p = w0; p < a.npos; p += ws) {
+    int64_t o0, o1; int n0, n1;
+    f64_rows(a, p, o0, n0, o1, n1);
+    bool f32_ok = true, grid_ok = true;
+    for (int g = 0; g < 2; ++g) {
+      const double* src = (g ? a.d1 + o1 : a.d0 + o0);
+      const int n = g ? n1 : n0;
+      for (int i = lane; i < n; i += 64) {
+        const double v = src[i];
+        f32_ok = f32_ok && ((double)(float)v == v);
+        const double k = rint(v * 1000.0);
+        grid_ok = grid_ok && (fabs(k) <= 16777216.0) && (k / 1000.0 == v);
+      }
+    }
+    const bool all_f32 = __ballot(!f32_ok) == 0ull;
+    const bool all_grid = __ballot(!grid_ok) == 0ull;
+    const bool scale = !all_f32 && all_grid;
+    for (int g = 0; g < 2; ++g) {
+      const double* src = (g ? a.d1 + o1 : a.d0 + o0);
+      float* dst = (g ? a.k1 + o1 : a.k0 + o0);
+      const int n = g ? n1 : n0;
+      for (int i = lane; i < n; i += 64) {
+        const double v = src[i];
+        dst[i] = scale ? (float)rint(v * 1000.0) : (float)v;
+      }
+    }
+    if (lane == 0) a.cls3[p] = (!all_f32 && !all_grid) ? 1 : 0;
+  }
+}
+
+// mean and sum of squared deviations of both groups from the float64 samples, two-pass like np.mean / np.var
+__global__ __launch_bounds__(256) void f64_moments_kernel(F64Args a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), ws = (int64_t)gridDim.x * 4;
+  for (int64_t p = w0; p < a.npos; p += ws) {
+    int64_t o0, o1; int n0, n1;
+    f64_rows(a, p, o0, n0, o1, n1);
+    for (int g = 0; g < 2; ++g) {
+      const double* src = (g ? a.d1 + o1 : a.d0 + o0);
+      const int n = g ? n1 : n0;
+      double s = 0.0;
+      for (int i = lane; i < n; i += 64) s += src[i];
+      s = wave_sum_f64(s);
+      const double mu = s / (double)n;
+      double q = 0.0;
+      for (int i = lane; i < n; i += 64) { const double d = src[i] - mu; q += d * d; }
+      q = wave_sum_f64(q);
+      if (lane == 0) { double* mo = a.moments + p * 4 + 2 * g; mo[0] = mu; mo[1] = q; }
+    }
+  }
+}
+
+// the class-3 positions whose keys tied (or that went to the large-position pass, which reports no ties) -> redo list
+__global__ __launch_bounds__(256) void f64_redo_list_kernel(F64Args a) {
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.npos; p += (int64_t)gridDim.x * 256) {
+    if (!a.cls3[p]) continue;
+    const bool big = a.cls && a.cls[p] == (uint8_t)kBigClass;
+    const bool skipped = a.cls && a.cls[p] == 255;
+    if (skipped || !(a.tied[p] || big)) continue;
+    int64_t o0, o1; int n0, n1;
+    f64_rows(a, p, o0, n0, o1, n1);
+    const int idx = atomicAdd(&a.meta[kMetaRedo], 1);
+    a.order[idx] = (int32_t)p;
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.meta + kMetaRedoTotal), (unsigned long long)(big_pow2_ceil(n0) + big_pow2_ceil(n1)));
   }
 }
 
@@ -320,9 +398,12 @@ struct DevScratch {
   ~DevScratch() { if (p) { if (async) hipFreeAsync(p, nullptr); else hipFree(p); } }
 };
 
+// the float64 samples behind float32 keys (detect_f64): device pointers in the index space of the offsets
+struct F64Src { const double* d0; const double* d1; uint8_t* cls3; };
+
 static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0, const int64_t* off0,
                          const void* sig1, const int64_t* off1, const int32_t* run_id, void* workspace,
-                         int64_t workspace_bytes, nmod_out* out) {
+                         int64_t workspace_bytes, nmod_out* out, const F64Src* f64 = nullptr) {
   hipStream_t stream = (hipStream_t)prm->stream;
   if (npos == 0) return NMOD_OK;
   if (!sig0 || !sig1 || !out) return NMOD_ERR_INVALID_ARG;
@@ -366,9 +447,8 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   int cmax0 = size_class_of(std::max<int64_t>(max0, 1)), cmax1 = size_class_of(std::max<int64_t>(max1, 1));
   // positions beyond the wave-resident kernels (both groups sorted in all-tests mode, the smaller one in KS-only
   // mode) go to big_rank_kernel; the maxima tell whether any can exist
-  const bool f64_keys = prm->dtype == NMOD_DTYPE_F64;       // (reached through detect_f64 only: samples no narrower type holds)
-  const bool big_possible = f64_keys || (all ? (cmax0 >= kNumSizeClasses || cmax1 >= kNumSizeClasses)
-                                             : (std::min(cmax0, cmax1) >= kNumSizeClasses));
+  const bool big_possible = all ? (cmax0 >= kNumSizeClasses || cmax1 >= kNumSizeClasses)
+                                : (std::min(cmax0, cmax1) >= kNumSizeClasses);
   cmax0 = std::min(cmax0, kNumSizeClasses - 1); cmax1 = std::min(cmax1, kNumSizeClasses - 1);
 
   RankStatsArgs ra;
@@ -376,6 +456,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   ra.sig0 = sig0; ra.sig1 = sig1; ra.off0 = off0; ra.off1 = off1;
   ra.stride0 = prm->stride0 > 0 ? prm->stride0 : 0; ra.stride1 = prm->stride1 > 0 ? prm->stride1 : 0;
   ra.npos = npos; ra.ks_num = ws.ks_num; ra.mwu_s = ws.mwu_s; ra.tie = ws.tie; ra.moments = ws.moments; ra.ks_d_ref = ws.ks_d_ref;
+  ra.tied = f64 ? ws.tied : nullptr;            // float32 keys of float64 samples: K1 reports the positions whose keys tie
 
   auto launch = [&](int cls, int64_t work) -> hipError_t {
     if (prm->dtype == NMOD_DTYPE_F32)
@@ -392,7 +473,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   } else {
     BinArgs ba;
     ba.npos = npos; ba.off0 = off0; ba.off1 = off1; ba.stride0 = ra.stride0; ba.stride1 = ra.stride1;
-    ba.cmax0 = cmax0; ba.cmax1 = cmax1; ba.ks_only = all ? 0 : 1; ba.allow_big = 1; ba.force_big = f64_keys ? 1 : 0; ba.lim0 = std::max<int64_t>(max0, 1); ba.lim1 = std::max<int64_t>(max1, 1);
+    ba.cmax0 = cmax0; ba.cmax1 = cmax1; ba.ks_only = all ? 0 : 1; ba.allow_big = 1; ba.force_big = 0; ba.lim0 = std::max<int64_t>(max0, 1); ba.lim1 = std::max<int64_t>(max1, 1);
     ba.cls = ws.cls; ba.meta = ws.meta; ba.order = ws.order;
     unsigned blocks = (unsigned)std::min<int64_t>((npos + 255) / 256, 4096);
     hipLaunchKernelGGL(classify_kernel, dim3(blocks), dim3(256), 0, stream, ba);
@@ -403,7 +484,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     bool wanted[kNumClasses] = {false};
     for (int c0 = 0; c0 <= cmax0; ++c0)
       for (int c1 = 0; c1 <= cmax1; ++c1) wanted[all ? launch_class_of(c0, c1) : kKsClassBase + std::min(c0, c1)] = true;
-    for (int cls = 0; cls < kNumClasses && !f64_keys; ++cls) {
+    for (int cls = 0; cls < kNumClasses; ++cls) {
       if (!wanted[cls]) continue;
       ra.pos_list = ws.order; ra.class_meta = ws.meta; ra.class_id = cls;
       NMOD_HIP(launch(cls, npos));
@@ -418,7 +499,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
       unsigned long long total;
       memcpy(&total, &head[2], 8);
       if (nbig > 0) {
-        NMOD_HIP(big_scratch.alloc((size_t)total * (f64_keys ? 8 : 4), stream, prm->device));
+        NMOD_HIP(big_scratch.alloc((size_t)total * 4, stream, prm->device));
         BigArgs bg;
         memset(&bg, 0, sizeof(bg));
         bg.sig0 = sig0; bg.sig1 = sig1; bg.off0 = off0; bg.off1 = off1; bg.stride0 = ra.stride0; bg.stride1 = ra.stride1;
@@ -428,11 +509,47 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
         bg.ks_num = ws.ks_num; bg.mwu_s = ws.mwu_s; bg.tie = ws.tie; bg.moments = ws.moments; bg.ks_d_ref = ws.ks_d_ref;
         const unsigned blocks = (unsigned)std::min<int64_t>(nbig, (int64_t)num_cus * 4);   // 4 x 33 KB of LDS per CU
         if (prm->dtype == NMOD_DTYPE_F32) hipLaunchKernelGGL(big_rank_kernel<0>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
-        else if (prm->dtype == NMOD_DTYPE_I16_MILLI) hipLaunchKernelGGL(big_rank_kernel<1>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
-        else hipLaunchKernelGGL(big_rank_kernel<2>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
+        else hipLaunchKernelGGL(big_rank_kernel<1>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
         NMOD_HIP(hipGetLastError());
         NMOD_HIP(big_scratch.release(stream));
       }
+    }
+  }
+
+  // ---- float64 samples behind the keys: redo the positions whose keys tied with 64-bit keys, moments from the samples
+  DevScratch redo_scratch;
+  if (f64) {
+    F64Args fx;
+    memset(&fx, 0, sizeof(fx));
+    fx.d0 = f64->d0; fx.d1 = f64->d1; fx.off0 = off0; fx.off1 = off1; fx.stride0 = ra.stride0; fx.stride1 = ra.stride1;
+    fx.npos = npos; fx.cls3 = f64->cls3; fx.tied = ws.tied; fx.cls = (uniform && !big_possible) ? nullptr : ws.cls;
+    fx.order = ws.order; fx.meta = ws.meta; fx.moments = ws.moments;
+    const unsigned gb = (unsigned)std::min<int64_t>((npos + 255) / 256, 4096);
+    hipLaunchKernelGGL(f64_redo_list_kernel, dim3(gb), dim3(256), 0, stream, fx);
+    NMOD_HIP(hipGetLastError());
+    int32_t nredo = 0; unsigned long long total = 0;
+    NMOD_HIP(hipMemcpyAsync(&nredo, ws.meta + kMetaRedo, 4, hipMemcpyDeviceToHost, stream));
+    NMOD_HIP(hipMemcpyAsync(&total, ws.meta + kMetaRedoTotal, 8, hipMemcpyDeviceToHost, stream));
+    NMOD_HIP(hipStreamSynchronize(stream));
+    if (nredo > 0) {
+      NMOD_HIP(redo_scratch.alloc((size_t)total * 8, stream, prm->device));
+      BigArgs bg;
+      memset(&bg, 0, sizeof(bg));
+      bg.sig0 = f64->d0; bg.sig1 = f64->d1; bg.off0 = off0; bg.off1 = off1; bg.stride0 = ra.stride0; bg.stride1 = ra.stride1;
+      bg.pos_list = ws.order; bg.class_meta = ws.meta + kMetaRedo; bg.big_class = 0; bg.all = all ? 1 : 0;
+      bg.scratch = redo_scratch.p;
+      bg.cursor = reinterpret_cast<unsigned long long*>(ws.meta + kMetaRedoCursor);
+      bg.ks_num = ws.ks_num; bg.mwu_s = ws.mwu_s; bg.tie = ws.tie; bg.moments = ws.moments; bg.ks_d_ref = ws.ks_d_ref;
+      const unsigned blocks = (unsigned)std::min<int64_t>(nredo, (int64_t)num_cus * 4);
+      ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
+      hipLaunchKernelGGL(big_rank_kernel<2>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
+      NMOD_HIP(hipGetLastError());
+      NMOD_HIP(redo_scratch.release(stream));
+    }
+    if (all) {
+      const unsigned mb = (unsigned)std::min<int64_t>((npos + 3) / 4, (int64_t)num_cus * 16);
+      hipLaunchKernelGGL(f64_moments_kernel, dim3(mb), dim3(256), 0, stream, fx);
+      NMOD_HIP(hipGetLastError());
     }
   }
 
@@ -473,12 +590,12 @@ struct DevBuf {
 // sig_on_device: the samples are already device-resident (the float64 front end), everything else is host memory
 static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, const int64_t* off0,
                        const void* sig1, const int64_t* off1, const int32_t* run_id, nmod_out* out,
-                       bool sig_on_device = false) {
+                       bool sig_on_device = false, const F64Src* f64 = nullptr) {
   if (npos == 0) return NMOD_OK;
   if (!sig0 || !sig1 || !out) return NMOD_ERR_INVALID_ARG;
   if ((prm->stride0 <= 0 && !off0) || (prm->stride1 <= 0 && !off1)) return NMOD_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)prm->stream;
-  const size_t esz = prm->dtype == NMOD_DTYPE_F32 ? 4 : (prm->dtype == NMOD_DTYPE_F64 ? 8 : 2);
+  const size_t esz = prm->dtype == NMOD_DTYPE_F32 ? 4 : 2;
   const int64_t tot0 = prm->stride0 > 0 ? prm->stride0 * npos : off0[npos] - off0[0];
   const int64_t tot1 = prm->stride1 > 0 ? prm->stride1 * npos : off1[npos] - off1[0];
   nmod_params dp = *prm;
@@ -526,8 +643,11 @@ static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, c
   for (int k = 0; k < 12; ++k) dpv[k] = hp[k] ? slab + (int64_t)k * npos : nullptr;
   dout.status = out->status ? (uint8_t*)(slab + 12 * npos) : nullptr;
 
+  // (sig_on_device: the staged offsets are rebased by base0 / base1, and so are the pointers — keys and float64 samples)
+  F64Src fsrc;
+  if (f64) { fsrc = *f64; fsrc.d0 += base0; fsrc.d1 += base1; }
   int rc = detect_device(&dp, npos, ds0, (const int64_t*)d_off0.p, ds1, (const int64_t*)d_off1.p,
-                         (const int32_t*)d_run.p, d_ws.p, wsb, &dout);
+                         (const int32_t*)d_run.p, d_ws.p, wsb, &dout, f64 ? &fsrc : nullptr);
   if (rc != NMOD_OK) { hipStreamSynchronize(stream); return rc; }
   // copy back exactly the tracks detect_device wrote (same predicate: the KS pair exists iff KS was asked for or
   // the combine ran, and the combine runs only when both of its outputs were given)
@@ -547,7 +667,7 @@ static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, c
 }
 
 // ---------------------------------------------------------------- float64 front end
-// Re-encodes float64 samples to the dtype the kernels sort (see NMOD_DTYPE_F64) and runs the batch on the result.
+// Gives every position order-preserving float32 keys (f64_encode_kernel) and runs the batch on them; see F64Args.
 static int detect_f64(const nmod_params* prm, int64_t npos, const void* sig0, const int64_t* off0,
                       const void* sig1, const int64_t* off1, const int32_t* run_id, void* workspace,
                       int64_t workspace_bytes, nmod_out* out) {
@@ -570,59 +690,43 @@ static int detect_f64(const nmod_params* prm, int64_t npos, const void* sig0, co
   }
   const int64_t n0 = e0 - b0, n1 = e1 - b1;
   if (n0 < 0 || n1 < 0) return NMOD_ERR_INVALID_ARG;
-  DevBuf st0, st1, enc0, enc1, flg;
-  const double* d0 = (const double*)sig0 + b0;
+  DevBuf st0, st1, d_o0, d_o1;
+  DevScratch enc0, enc1, d_cls3;                    // stream-ordered, from the library's pool: no device-wide synchronisation per batch
+  const double* d0 = (const double*)sig0 + b0;       // first sample in use
   const double* d1 = (const double*)sig1 + b1;
+  const int64_t* doff0 = off0; const int64_t* doff1 = off1;
   if (host) {
     NMOD_HIP(st0.alloc((size_t)n0 * 8)); NMOD_HIP(st1.alloc((size_t)n1 * 8));
     NMOD_HIP(hipMemcpyAsync(st0.p, d0, (size_t)n0 * 8, hipMemcpyHostToDevice, stream));
     NMOD_HIP(hipMemcpyAsync(st1.p, d1, (size_t)n1 * 8, hipMemcpyHostToDevice, stream));
     d0 = (const double*)st0.p; d1 = (const double*)st1.p;
+    // the encoder walks the rows on the device: it needs the offsets there (detect_host stages its own, rebased copy)
+    if (prm->stride0 <= 0) { NMOD_HIP(d_o0.alloc((npos + 1) * 8)); NMOD_HIP(hipMemcpyAsync(d_o0.p, off0, (npos + 1) * 8, hipMemcpyHostToDevice, stream)); doff0 = (const int64_t*)d_o0.p; }
+    if (prm->stride1 <= 0) { NMOD_HIP(d_o1.alloc((npos + 1) * 8)); NMOD_HIP(hipMemcpyAsync(d_o1.p, off1, (npos + 1) * 8, hipMemcpyHostToDevice, stream)); doff1 = (const int64_t*)d_o1.p; }
   }
-  NMOD_HIP(flg.alloc(8));
-  const int32_t ones[2] = {1, 1};
-  NMOD_HIP(hipMemcpyAsync(flg.p, ones, 8, hipMemcpyHostToDevice, stream));
-  const unsigned blocks = (unsigned)std::min<int64_t>((n0 + n1 + 255) / 256 + 1, 8192);
-  hipLaunchKernelGGL(f64_probe_kernel, dim3(blocks), dim3(256), 0, stream, d0, n0, d1, n1, (int32_t*)flg.p);
+  NMOD_HIP(enc0.alloc((size_t)n0 * 4, stream, prm->device)); NMOD_HIP(enc1.alloc((size_t)n1 * 4, stream, prm->device));
+  NMOD_HIP(d_cls3.alloc((size_t)npos, stream, prm->device));
+  // pointers in the index space of the offsets (sample i of the arrays sits at [i], whatever the first offset is)
+  F64Src src;
+  src.d0 = d0 - b0; src.d1 = d1 - b1; src.cls3 = (uint8_t*)d_cls3.p;
+  F64Args fx;
+  memset(&fx, 0, sizeof(fx));
+  fx.d0 = src.d0; fx.d1 = src.d1; fx.off0 = doff0; fx.off1 = doff1;
+  fx.stride0 = prm->stride0 > 0 ? prm->stride0 : 0; fx.stride1 = prm->stride1 > 0 ? prm->stride1 : 0;
+  fx.npos = npos; fx.k0 = (float*)enc0.p - b0; fx.k1 = (float*)enc1.p - b1; fx.cls3 = src.cls3;
+  int num_cus = 0;
+  NMOD_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, prm->device));
+  const unsigned eb = (unsigned)std::min<int64_t>((npos + 3) / 4, (int64_t)num_cus * 16);
+  hipLaunchKernelGGL(f64_encode_kernel, dim3(eb), dim3(256), 0, stream, fx);
   NMOD_HIP(hipGetLastError());
-  int32_t flags[2];
-  NMOD_HIP(hipMemcpyAsync(flags, flg.p, 8, hipMemcpyDeviceToHost, stream));
-  NMOD_HIP(hipStreamSynchronize(stream));
   nmod_params ep = *prm;
-  if (flags[0]) ep.dtype = NMOD_DTYPE_F32;
-  else if (flags[1]) ep.dtype = NMOD_DTYPE_I16_MILLI;
-  else {
-    // neither float32-exact nor on the 0.001 grid: sort the fp64 samples themselves — every position through the
-    // workgroup-per-position kernel with 64-bit keys (correct for any input; ~3e7 positions/s at 200 v 200)
-    const void* s0 = (const char*)d0 - (size_t)b0 * 8;
-    const void* s1 = (const char*)d1 - (size_t)b1 * 8;
-    int rc = host ? detect_host(&ep, npos, s0, off0, s1, off1, run_id, out, true)
-                  : detect_device(&ep, npos, s0, off0, s1, off1, run_id, workspace, workspace_bytes, out);
-    hipStreamSynchronize(stream);
-    return rc;
-  }
-  const size_t esz = ep.dtype == NMOD_DTYPE_F32 ? 4 : 2;
-  NMOD_HIP(enc0.alloc((size_t)n0 * esz)); NMOD_HIP(enc1.alloc((size_t)n1 * esz));
-  const unsigned eb0 = (unsigned)std::min<int64_t>((n0 + 255) / 256 + 1, 8192), eb1 = (unsigned)std::min<int64_t>((n1 + 255) / 256 + 1, 8192);
-  if (ep.dtype == NMOD_DTYPE_F32) {
-    hipLaunchKernelGGL(f64_encode_kernel<float>, dim3(eb0), dim3(256), 0, stream, d0, n0, (float*)enc0.p);
-    hipLaunchKernelGGL(f64_encode_kernel<float>, dim3(eb1), dim3(256), 0, stream, d1, n1, (float*)enc1.p);
-  } else {
-    hipLaunchKernelGGL(f64_encode_kernel<int16_t>, dim3(eb0), dim3(256), 0, stream, d0, n0, (int16_t*)enc0.p);
-    hipLaunchKernelGGL(f64_encode_kernel<int16_t>, dim3(eb1), dim3(256), 0, stream, d1, n1, (int16_t*)enc1.p);
-  }
-  NMOD_HIP(hipGetLastError());
-  // the encoded arrays start at sample b0 / b1: present them through pointers shifted back by the first offset
-  const void* s0 = (const char*)enc0.p - (size_t)b0 * esz;
-  const void* s1 = (const char*)enc1.p - (size_t)b1 * esz;
+  ep.dtype = NMOD_DTYPE_F32;
   int rc;
-  if (host) {
-    // offsets, run ids and outputs are still host buffers: stage them through the host path on device-resident samples
-    rc = detect_host(&ep, npos, s0, off0, s1, off1, run_id, out, true);
-  } else {
-    rc = detect_device(&ep, npos, s0, off0, s1, off1, run_id, workspace, workspace_bytes, out);
-  }
-  hipStreamSynchronize(stream);                      // the encoded buffers are freed on return
+  if (host) rc = detect_host(&ep, npos, fx.k0, off0, fx.k1, off1, run_id, out, true, &src);
+  else rc = detect_device(&ep, npos, fx.k0, off0, fx.k1, off1, run_id, workspace, workspace_bytes, out, &src);
+  // the key buffers go back to the pool in stream order (the host path has synchronised already)
+  const hipError_t r0 = enc0.release(stream), r1 = enc1.release(stream), r2 = d_cls3.release(stream);
+  if (rc == NMOD_OK && (r0 != hipSuccess || r1 != hipSuccess || r2 != hipSuccess)) { g_last_hip = r0 != hipSuccess ? r0 : (r1 != hipSuccess ? r1 : r2); rc = NMOD_ERR_HIP; }
   return rc;
 }
 
@@ -796,11 +900,12 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
   const bool want_comb = prm->method != NMOD_METHOD_KS;
   int tests = prm->tests | (want_comb ? NMOD_TEST_KS : 0);
   const bool all = (tests & (NMOD_TEST_MWU | NMOD_TEST_WELCH)) != 0 || prm->want_mstd;
-  const char* dt = prm->dtype == NMOD_DTYPE_F32 ? "f32" : (prm->dtype == NMOD_DTYPE_I16_MILLI ? "i16" : "f64");
+  // (NMOD_DTYPE_F64 runs on per-position float32 keys: the float32 instances)
+  const char* dt = prm->dtype == NMOD_DTYPE_I16_MILLI ? "i16" : "f32";
   const int c0 = size_class_of(n0), c1 = size_class_of(n1);
   // the same decisions classify_kernel / detect_device take (NMOD_DTYPE_F64: the narrower dtype is a property of the data)
   const bool big = all ? (c0 >= kNumSizeClasses || c1 >= kNumSizeClasses) : (std::min(c0, c1) >= kNumSizeClasses);
-  if (big || prm->dtype == NMOD_DTYPE_F64) { snprintf(buf, buflen, "big_rank_kernel<%s>", dt); return NMOD_OK; }
+  if (big) { snprintf(buf, buflen, "big_rank_kernel<%s>", dt); return NMOD_OK; }
   if (!all) {
     const int cs = std::min(c0, c1);
     const int LG = ks_lanes_per_group(cs), R = (64 << cs) / LG;

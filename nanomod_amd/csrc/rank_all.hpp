@@ -238,6 +238,7 @@ void rank_pair_kernel(RankStatsArgs args) {
       args.mwu_s[pos] = S;
       args.tie[pos] = 3ull * (PP - pads) + 3ull * T3;
       args.ks_d_ref[pos] = (n0 > 0 && n1 > 0) ? dmax : 0.0;
+      if (args.tied) args.tied[pos] = (PP != pads || T3 != 0ull) ? 1 : 0;
     }
     __builtin_amdgcn_wave_barrier();
   }

@@ -258,7 +258,6 @@ void rank_hist_kernel(RankStatsArgs args) {
     int lane = lane_k;
     asm volatile("" : "+v"(lane));
     const int gl = lane & (LG - 1);
-    const int e0 = gl * R;
     const int seg_base = lane & ~(LG - 1);
     const bool valid = cur.valid;
     const int64_t pos = cur.pos;
@@ -610,6 +609,7 @@ void rank_hist_kernel(RankStatsArgs args) {
       args.tie[pos] = 3ull * (unsigned long long)PP + 3ull * (unsigned long long)AB;
       args.ks_d_ref[pos] = (m > 0 && q > 0) ? dmax : 0.0;
       args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;
+      if (args.tied) args.tied[pos] = (PP != 0u || AB != 0u) ? 1 : 0;   // any two samples of the position compare equal
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0x0F70);

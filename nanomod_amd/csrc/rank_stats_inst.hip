@@ -56,7 +56,20 @@ KernelFn pick_packed(int cm) {
 }
 #else
 // KS-only builds carry only the ks_rank kernels
-KernelFn pick_ks(int cs) {
+KernelFn pick_ks(int cs, bool flags) {
+#if NMOD_INST_DTYPE == 0
+  if (flags) {                 // float32 images of float64 samples: report ties (ks_rank.hpp)
+    switch (cs) {
+      case 0: return ks_rank_kernel<8, 8, DT, true>;
+      case 1: return ks_rank_kernel<16, 8, DT, true>;
+      case 2: return ks_rank_kernel<16, 16, DT, true>;
+      case 3: return ks_rank_kernel<32, 16, DT, true>;
+      case 4: return ks_rank_kernel<32, 32, DT, true>;
+      default: return ks_rank_kernel<32, 64, DT, true>;
+    }
+  }
+#endif
+  (void)flags;
   switch (cs) {
     case 0: return ks_rank_kernel<8, 8, DT>;
     case 1: return ks_rank_kernel<16, 8, DT>;
@@ -83,7 +96,7 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
   fn = packed ? pick_packed(cls - kNumGeneralClasses) : pick(cls / kNumSizeClasses, cls % kNumSizeClasses);
 #else
   if (!ks) return hipErrorInvalidValue;
-  fn = pick_ks(cls - kKsClassBase);
+  fn = pick_ks(cls - kKsClassBase, args.tied != nullptr);
 #endif
   const size_t lds = rank_stats_lds_bytes(cls, ALL);
   if (ks || packed) {
@@ -92,10 +105,11 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
   }
   // the dynamic-LDS attribute and the occupancy of a kernel are looked up once per (device, class), not on every launch
   // (atomics: concurrent first launches of a class both run the queries and store the same number)
-  static std::atomic<int> per_cu_cache[64][kClassStride];
+  static std::atomic<int> per_cu_cache[64][2 * kClassStride];     // [class] and [kClassStride + class] for the FLAGS instances
   int dev = 0;
   const bool cacheable = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
-  int per_cu = cacheable ? per_cu_cache[dev][cls].load(std::memory_order_relaxed) : 0;
+  const int slot_id = cls + ((ks && args.tied) ? kClassStride : 0);
+  int per_cu = cacheable ? per_cu_cache[dev][slot_id].load(std::memory_order_relaxed) : 0;
   if (per_cu <= 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -103,7 +117,7 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kWavesPerBlock, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
-    if (cacheable) per_cu_cache[dev][cls].store(per_cu, std::memory_order_relaxed);
+    if (cacheable) per_cu_cache[dev][slot_id].store(per_cu, std::memory_order_relaxed);
   }
   int64_t blocks = (work_items + kWavesPerBlock - 1) / kWavesPerBlock;
   int64_t cap = (int64_t)num_cus * per_cu;

@@ -204,4 +204,198 @@ void big_rank_kernel(BigArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// All-tests mode, positions whose LARGER group is beyond the wave-resident kernels (up to 4 096 samples) and whose
+// SMALLER group has at most 1 024 (config 5: ~2 500 v ~60 reads): the block sorts only the smaller group S in LDS, every sample of the larger group Q
+// finds its ranks L, U in S by binary search and is counted in LDS histograms — the formulas of rank_hist.hpp — and
+// the ties INSIDE Q, the one thing that would need Q sorted, are counted by an open-addressing hash table in LDS:
+// an arrival that finds its key present gets the number of earlier arrivals from the slot's counter and adds
+// p (p - 1).  One pass over Q, no scratch slab, no copy of Q anywhere.
+constexpr int kBigHistMaxS = 1024;              // keys of S in LDS, a power of two (the sort pads to one); two blocks per CU
+constexpr int kBigHistMaxQ = 4096;              // samples of Q: half the slots of the hash table
+constexpr int kBigHistSlots = 8192;
+constexpr unsigned kBigHistEmpty = 0xffffffffu;  // (a NaN pattern no arithmetic produces)
+constexpr int kBigHistAux = 24;                  // words of block-wide accumulators behind the tables
+constexpr size_t kBigHistLds = ((size_t)kBigHistMaxS + (size_t)(kBigHistMaxS + 1) + (size_t)kBigHistSlots * 2 + kBigHistAux + 3) / 4 * 16;
+static_assert(2 * kBigHistLds <= 160 * 1024, "two blocks per CU");
+
+template <int DTYPE>
+__global__ __launch_bounds__(kBigThreads)
+void big_hist_kernel(BigArgs a) {
+  static_assert(DTYPE == 0 || DTYPE == 1, "float32 or int16 samples");
+  extern __shared__ __attribute__((aligned(16))) unsigned big_lds[];
+  float* keys = reinterpret_cast<float*>(big_lds);                   // sorted S, padded with +inf to a power of two
+  unsigned* hist = big_lds + kBigHistMaxS;                             // bin k: (#L == k) << 16 | (#U == k), k = 0 .. m
+  unsigned* hkey = hist + (kBigHistMaxS + 1);                          // hash table: key bits / occurrences - 1
+  unsigned* hcnt = hkey + kBigHistSlots;
+  // block-wide accumulators (in the dynamic allocation: a static __shared__ array would push the block over half a CU)
+  unsigned* aux = hcnt + kBigHistSlots + ((kBigHistMaxS + (kBigHistMaxS + 1)) & 1);     // 8-byte aligned
+  double* red = reinterpret_cast<double*>(aux);                                          // [4]
+  unsigned long long& sh_pp = *reinterpret_cast<unsigned long long*>(aux + 8);
+  unsigned long long& sh_ab = *reinterpret_cast<unsigned long long*>(aux + 10);
+  unsigned long long& sh_slu = *reinterpret_cast<unsigned long long*>(aux + 12);
+  unsigned long long& sh_dmax = *reinterpret_cast<unsigned long long*>(aux + 14);
+  unsigned& sh_best = aux[16];
+  unsigned* sh_scan = aux + 17;                                                          // [4]
+  const int tid = threadIdx.x;
+  const int64_t count = a.class_meta[a.big_class];
+  const int32_t* list = a.pos_list + a.class_meta[kClassStride + a.big_class];
+  const float inf = __builtin_inff();
+
+  for (int64_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
+    const int64_t pos = list[bi];
+    int64_t o0, o1; int n0, n1;
+    if (a.stride0 > 0) { o0 = pos * a.stride0; n0 = (int)a.stride0; } else { o0 = a.off0[pos]; n0 = (int)(a.off0[pos + 1] - o0); }
+    if (a.stride1 > 0) { o1 = pos * a.stride1; n1 = (int)a.stride1; } else { o1 = a.off1[pos]; n1 = (int)(a.off1[pos + 1] - o1); }
+    const bool swap = n1 < n0;                       // S = the smaller group (ties: group 1)
+    const void* sig_s = swap ? a.sig1 : a.sig0; const void* sig_q = swap ? a.sig0 : a.sig1;
+    const int64_t off_s = swap ? o1 : o0, off_q = swap ? o0 : o1;
+    const int m = swap ? n1 : n0, q = swap ? n0 : n1;
+    const int P = (int)big_pow2_ceil(m);
+    if (tid == 0) { sh_pp = 0ull; sh_ab = 0ull; sh_slu = 0ull; sh_best = 0u; sh_dmax = 0ull; }
+
+    // ---- both groups into registers with every load in flight at once (a block works on one position at a time: a
+    // dependent load per loop trip would leave it waiting on HBM latency), then moments (two-pass, fp64) from there
+    constexpr int NS = kBigHistMaxS / kBigThreads, NQ = kBigHistMaxQ / kBigThreads;
+    static_assert(NS * kBigThreads == kBigHistMaxS && NQ * kBigThreads == kBigHistMaxQ && (kBigHistMaxS & (kBigHistMaxS - 1)) == 0, "whole registers per thread");
+    float xs[NS], xq[NQ];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) { const int i = tid + t * kBigThreads; xs[t] = (i < m) ? big_load<DTYPE>(sig_s, off_s + i) : 0.0f; }
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) { const int j = tid + t * kBigThreads; xq[t] = (j < q) ? big_load<DTYPE>(sig_q, off_q + j) : 0.0f; }
+    for (int g = 0; g < 2; ++g) {
+      const int n = g ? q : m;
+      double s = 0.0;
+      if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) if (tid + t * kBigThreads < m) s += (double)xs[t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) if (tid + t * kBigThreads < q) s += (double)xq[t];
+      }
+      s = big_block_sum(s, red);
+      const double mu = s / (double)n;
+      double qq = 0.0;
+      if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) if (tid + t * kBigThreads < m) { const double d = (double)xs[t] - mu; qq += d * d; }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) if (tid + t * kBigThreads < q) { const double d = (double)xq[t] - mu; qq += d * d; }
+      }
+      qq = big_block_sum(qq, red);
+      if (tid == 0) {
+        double* mo = a.moments + pos * 4 + 2 * ((g == 1) != swap ? 1 : 0);     // S is group 1 unless swapped
+        if constexpr (DTYPE == 1) { mo[0] = s / 1000.0 / (double)n; mo[1] = qq * 1e-6; }
+        else { mo[0] = mu; mo[1] = qq; }
+      }
+    }
+
+    // ---- S sorted in LDS; histograms and hash table cleared
+#pragma unroll
+    for (int t = 0; t < NS; ++t) { const int i = tid + t * kBigThreads; if (i < P) keys[i] = (i < m) ? xs[t] + 0.0f : inf; }
+    for (int i = tid; i <= m; i += kBigThreads) hist[i] = 0u;
+    for (int i = tid; i < kBigHistSlots; i += kBigThreads) { hkey[i] = kBigHistEmpty; hcnt[i] = 0u; }
+    __syncthreads();
+    big_bitonic(keys, P);
+
+    // ---- every sample of Q: ranks in S -> histograms; its own ties -> hash table
+    unsigned long long pp = 0ull;
+#pragma unroll 1
+    for (int t = 0; t < NQ; ++t) {
+      const int j = tid + t * kBigThreads;
+      if (j >= q) break;
+      const float x = xq[t] + 0.0f;                                         // (-0.0 -> +0.0: one key per value)
+      const int L = big_lower_bound(keys, m, x);
+      const int U = (L < m && keys[L] == x) ? big_upper_bound(keys, m, x) : L;
+      atomicAdd(&hist[L], 0x10000u);
+      atomicAdd(&hist[U], 1u);
+      const unsigned bits = __float_as_uint(x);
+      unsigned h = (bits * 2654435761u) >> 19;                              // 13 bits: kBigHistSlots = 8192
+      for (;;) {
+        const unsigned old = atomicCAS(&hkey[h], kBigHistEmpty, bits);
+        if (old == kBigHistEmpty) break;                                    // first of its value
+        if (old == bits) {                                                  // the p-th, p = c + 2: adds p (p - 1)
+          const unsigned long long c = atomicAdd(&hcnt[h], 1u);
+          pp += (c + 2ull) * (c + 1ull);
+          break;
+        }
+        h = (h + 1u) & (kBigHistSlots - 1u);
+      }
+    }
+    // ties inside S: every run of a equal keys adds (a^3 - a) / 3 = sum p (p - 1)
+    for (int i = tid; i < m; i += kBigThreads) {
+      const float x = keys[i];
+      if (i + 1 < m && keys[i + 1] == x) continue;
+      if (i == 0 || keys[i - 1] != x) continue;
+      const unsigned long long ta = (unsigned long long)(i + 1 - big_lower_bound(keys, m, x));
+      pp += (ta * ta * ta - ta) / 3ull;
+    }
+    __syncthreads();
+
+    // ---- prefix sums over the bins 0 .. m (each thread a contiguous chunk), candidates at the run ends of S
+    const int per = (m + 1 + kBigThreads - 1) / kBigThreads;
+    const int k0 = min(tid * per, m + 1), k1 = min(k0 + per, m + 1);
+    unsigned loc = 0;
+    for (int k = k0; k < k1; ++k) loc += hist[k];
+    // block exclusive scan of `loc` (packed 16 | 16: both halves stay <= q <= 4096)
+    unsigned inc = loc;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned t = __shfl_up(inc, d); if ((tid & 63) >= d) inc += t; }
+    if ((tid & 63) == 63) sh_scan[tid >> 6] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += sh_scan[w];
+    unsigned c2 = base + inc - loc;                                         // cumL(k0 - 1) << 16 | cumU(k0 - 1)
+    unsigned best = 0; unsigned long long slu = 0ull, ab = 0ull;
+    for (int pass = 0; pass < 2; ++pass) {
+      // pass 0: the integer maximum, the Mann-Whitney sum and the ties with S; pass 1: the float form at the maximum
+      unsigned c = c2;
+      double dmax = 0.0;
+      const unsigned target = sh_best;
+      for (int k = k0; k < k1; ++k) {
+        const int cl_prev = (int)(c >> 16), cu_prev = (int)(c & 0xffffu);  // cumL(k-1), cumU(k-1)
+        c += hist[k];
+        const int cu = (int)(c & 0xffffu);                                  // cumU(k)
+        const bool run_end = (k == 0) || (k == m) || (keys[k - 1] != keys[k]);   // k = 0: the candidate (cumU(0), 0)
+        const long long cand_a = (long long)cu * m - (long long)k * q;
+        const long long cand_b = (k > 0) ? (long long)cl_prev * m - (long long)k * q : 0ll;
+        const unsigned ma = run_end ? (unsigned)(cand_a < 0 ? -cand_a : cand_a) : 0u;
+        const unsigned mb = (run_end && k > 0) ? (unsigned)(cand_b < 0 ? -cand_b : cand_b) : 0u;
+        if (pass == 0) {
+          best = max(best, max(ma, mb));
+          if (k > 0) {
+            slu += (unsigned long long)(2 * q - cl_prev - cu_prev);
+            if (run_end && cl_prev != cu_prev) {                            // Q ties with the run of S that ends at k
+              const unsigned long long b = (unsigned long long)(cl_prev - cu_prev);
+              const unsigned long long ta = (unsigned long long)(k - big_lower_bound(keys, m, keys[k - 1]));
+              ab += ta * b * (ta + b);
+            }
+          }
+        } else {
+          const double dm = (double)m, dq = (double)q;                      // ks_2samp's float form: |fl(c0/n0) - fl(c1/n1)|
+          if (ma == target && run_end) dmax = fmax(dmax, fabs((double)k / dm - (double)cu / dq));
+          if (mb == target && run_end && k > 0) dmax = fmax(dmax, fabs((double)k / dm - (double)cl_prev / dq));
+        }
+      }
+      if (pass == 0) {                                                      // one atomic per wave, not per thread
+        const unsigned wb = wave_max_u32(best);
+        const unsigned long long ws = wave_sum_u64(slu), wa = wave_sum_u64(ab), wp = wave_sum_u64(pp);
+        if ((tid & 63) == 0) { atomicMax(&sh_best, wb); atomicAdd(&sh_slu, ws); atomicAdd(&sh_ab, wa); atomicAdd(&sh_pp, wp); }
+      } else {
+        const double wd = wave_max_f64(dmax);
+        if ((tid & 63) == 0) atomicMax(&sh_dmax, (unsigned long long)__double_as_longlong(wd));   // non-negative doubles order like their bits
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const unsigned long long s_lu = sh_slu;                                // sum over Q of (L + U)
+      a.mwu_s[pos] = swap ? s_lu : 2ull * (unsigned long long)m * (unsigned long long)q - s_lu;
+      a.tie[pos] = 3ull * sh_pp + 3ull * sh_ab;
+      a.ks_d_ref[pos] = (sh_best != 0u) ? __longlong_as_double((long long)sh_dmax) : 0.0;
+      a.ks_num[pos] = sh_best;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace nmod

@@ -61,18 +61,20 @@ struct ScopedKernelTimer {
 struct Workspace {
   uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments;
   double* tmp_ks_d; double* tmp_ks_p; double* ks_d_ref;
-  int32_t* order; uint8_t* cls; uint8_t* tied; int32_t* meta;   // meta: [c] counts, [48 + c] offsets, [96 + c] cursors, [144..145] max n0/n1
+  int32_t* order; uint8_t* cls; uint8_t* tied; int32_t* meta;   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
   int64_t bytes;
 };
-constexpr int kMetaInts = 224;
-constexpr int kMetaMax = 3 * kClassStride;      // [144..145] max n0 / n1
-constexpr int kMetaBigTotal = kMetaMax + 2;     // [146..147] u64: scratch floats the large positions need
-constexpr int kMetaBigCursor = kMetaMax + 4;    // [148..149] u64: bump allocator of big_rank_kernel
-constexpr int kMetaRedo = 160;                  // float64 front end: [160] count of positions to redo, [160 + kClassStride] = 0 (their offset
-                                                // in the list), [210..211] u64 scratch keys they need, [212..213] u64 bump allocator
-constexpr int kMetaRedoTotal = 210, kMetaRedoCursor = 212;
+constexpr int kMetaInts = 256;
+constexpr int kMetaMax = 3 * kClassStride;      // [168..169] max n0 / n1
+constexpr int kMetaBigTotal = kMetaMax + 2;     // [170..171] u64: scratch floats the large positions need
+constexpr int kMetaBigCursor = kMetaMax + 4;    // [172..173] u64: bump allocator of big_rank_kernel
+constexpr int kMetaRedo = 184;                  // float64 front end: [184] count of positions to redo, [184 + kClassStride] = 0 (their
+                                                // offset in the list), [242..243] u64 scratch keys they need, [244..245] u64 bump allocator
+constexpr int kMetaRedoTotal = 242, kMetaRedoCursor = 244;
+static_assert(kMetaRedo + kClassStride < kMetaRedoTotal && kMetaRedoCursor + 2 <= kMetaInts && kMetaBigCursor + 2 <= kMetaRedo, "meta layout");
 constexpr int kBigClass = kNumClasses;          // 47: positions for big_rank_kernel (big_rank.hpp)
-constexpr int kNumPairs = kNumClasses + 1;      // <= kClassStride
+constexpr int kBigHistClass = kNumClasses + 1;  // 48: all-tests positions for big_hist_kernel (smaller group <= 2 048, larger <= 4 096)
+constexpr int kNumPairs = kNumClasses + 2;      // <= kClassStride
 static_assert(kNumPairs <= kClassStride, "class tables");
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256) void classify_kernel(BinArgs a) {
                      (a.ks_only ? (c0 < c1 ? c0 : c1) >= kNumSizeClasses : (c0 >= kNumSizeClasses || c1 >= kNumSizeClasses));
     int cid;
     if (over || n0 <= 0 || n1 <= 0 || (big && !a.allow_big)) cid = 255;
+    else if (big && !a.ks_only && !a.force_big && (n0 < n1 ? n0 : n1) <= kBigHistMaxS && (n0 < n1 ? n1 : n0) <= kBigHistMaxQ) cid = kBigHistClass;
     else if (big) cid = kBigClass;
     else if (a.ks_only) cid = kKsClassBase + (c0 < c1 ? c0 : c1);
     else cid = (c0 > a.cmax0 || c1 > a.cmax1) ? 255 : launch_class_of(c0, c1);
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256) void f64_moments_kernel(F64Args a) {
 __global__ __launch_bounds__(256) void f64_redo_list_kernel(F64Args a) {
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.npos; p += (int64_t)gridDim.x * 256) {
     if (!a.cls3[p]) continue;
-    const bool big = a.cls && a.cls[p] == (uint8_t)kBigClass;
+    const bool big = a.cls && (a.cls[p] == (uint8_t)kBigClass || a.cls[p] == (uint8_t)kBigHistClass);
     const bool skipped = a.cls && a.cls[p] == 255;
     if (skipped || !(a.tied[p] || big)) continue;
     int64_t o0, o1; int n0, n1;
@@ -492,10 +495,10 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     if (big_possible) {
       // the only host round trip of this path: how many large positions, how much scratch
       int32_t head[4];
-      NMOD_HIP(hipMemcpyAsync(&head[0], ws.meta + kBigClass, 4, hipMemcpyDeviceToHost, stream));
+      NMOD_HIP(hipMemcpyAsync(&head[0], ws.meta + kBigClass, 8, hipMemcpyDeviceToHost, stream));     // kBigClass, kBigHistClass
       NMOD_HIP(hipMemcpyAsync(&head[2], ws.meta + kMetaBigTotal, 8, hipMemcpyDeviceToHost, stream));
       NMOD_HIP(hipStreamSynchronize(stream));
-      const int64_t nbig = head[0];
+      const int64_t nbig = head[0], nbig_hist = head[1];
       unsigned long long total;
       memcpy(&total, &head[2], 8);
       if (nbig > 0) {
@@ -512,6 +515,18 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
         else hipLaunchKernelGGL(big_rank_kernel<1>, dim3(blocks), dim3(kBigThreads), 0, stream, bg);
         NMOD_HIP(hipGetLastError());
         NMOD_HIP(big_scratch.release(stream));
+      }
+      if (nbig_hist > 0) {
+        BigArgs bg;
+        memset(&bg, 0, sizeof(bg));
+        bg.sig0 = sig0; bg.sig1 = sig1; bg.off0 = off0; bg.off1 = off1; bg.stride0 = ra.stride0; bg.stride1 = ra.stride1;
+        bg.pos_list = ws.order; bg.class_meta = ws.meta; bg.big_class = kBigHistClass; bg.all = 1;
+        bg.ks_num = ws.ks_num; bg.mwu_s = ws.mwu_s; bg.tie = ws.tie; bg.moments = ws.moments; bg.ks_d_ref = ws.ks_d_ref;
+        const unsigned blocks = (unsigned)std::min<int64_t>(nbig_hist, (int64_t)num_cus * 2);        // 80 KB of LDS per block
+        auto kfn = prm->dtype == NMOD_DTYPE_F32 ? big_hist_kernel<0> : big_hist_kernel<1>;
+        NMOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigHistLds));
+        hipLaunchKernelGGL(kfn, dim3(blocks), dim3(kBigThreads), kBigHistLds, stream, bg);
+        NMOD_HIP(hipGetLastError());
       }
     }
   }
@@ -905,6 +920,7 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
   const int c0 = size_class_of(n0), c1 = size_class_of(n1);
   // the same decisions classify_kernel / detect_device take (NMOD_DTYPE_F64: the narrower dtype is a property of the data)
   const bool big = all ? (c0 >= kNumSizeClasses || c1 >= kNumSizeClasses) : (std::min(c0, c1) >= kNumSizeClasses);
+  if (big && all && std::min(n0, n1) <= kBigHistMaxS && std::max(n0, n1) <= kBigHistMaxQ) { snprintf(buf, buflen, "big_hist_kernel<%s>", dt); return NMOD_OK; }
   if (big) { snprintf(buf, buflen, "big_rank_kernel<%s>", dt); return NMOD_OK; }
   if (!all) {
     const int cs = std::min(c0, c1);

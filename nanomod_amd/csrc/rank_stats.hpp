@@ -25,7 +25,7 @@ namespace nmod {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kLdsPad = 4;   // +inf sentinels after each sorted group
-constexpr int kClassStride = 48;   // class_meta: [c] count, [kClassStride + c] offset, [2*kClassStride + c] cursor
+constexpr int kClassStride = 56;   // class_meta: [c] count, [kClassStride + c] offset, [2*kClassStride + c] cursor
 
 struct RankStatsArgs {
   const void* sig0; const void* sig1;

@@ -19,7 +19,7 @@ constexpr int kNumGeneralClasses = kNumSizeClasses * kNumSizeClasses;
 constexpr int kNumPackedClasses = 5;
 constexpr int kNumKsClasses = 6;                   // KS-only form (ks_rank.hpp): class of the SMALLER group
 constexpr int kKsClassBase = kNumGeneralClasses + kNumPackedClasses;    // 41
-constexpr int kNumClasses = kKsClassBase + kNumKsClasses;               // 47 <= kClassStride (48)
+constexpr int kNumClasses = kKsClassBase + kNumKsClasses;               // 47 (+ 2 large-position classes) <= kClassStride (56)
 
 __host__ __device__ inline int size_class_of(int64_t n) {   // smallest class with 64 << c >= n; 6 if too large
   int c = 0;

@@ -463,6 +463,10 @@ void rank_hist_kernel(RankStatsArgs args) {
       }
       if (gl2 == 0) hist[0] = 0u;                                            // bin 0: nothing before it
       best = (unsigned)max(hi, -lo);
+      // (finished HERE: left to the scheduler, the tie and rank sums sink to the end of the item and keep the 32
+      // per-bin counts they are built from in registers across the scatter, the float-form pass and the clean-up)
+      asm volatile("" : "+v"(ab3), "+v"(acc_l), "+v"(acc_u), "+v"(best));
+      __builtin_amdgcn_sched_barrier(0);
     }
     const unsigned lbest = best;
     best = seg_allmax_u32<LG>(best);

@@ -299,28 +299,49 @@ void big_hist_kernel(BigArgs a) {
     __syncthreads();
     big_bitonic(keys, P);
 
-    // ---- every sample of Q: ranks in S -> histograms; its own ties -> hash table
+    // ---- every sample of Q: ranks in S -> histograms; its own ties -> hash table.  Four samples per trip with
+    // branchless fixed-depth searches over the padded keys (P = 2^k, pads +inf): four independent chains of LDS reads
+    // in flight instead of one (two waves per SIMD hide little of a dependent chain)
     unsigned long long pp = 0ull;
+    const int levels = 31 - __builtin_clz((unsigned)P);                     // log2(P), uniform over the block
 #pragma unroll 1
-    for (int t = 0; t < NQ; ++t) {
-      const int j = tid + t * kBigThreads;
-      if (j >= q) break;
-      const float x = xq[t] + 0.0f;                                         // (-0.0 -> +0.0: one key per value)
-      const int L = big_lower_bound(keys, m, x);
-      const int U = (L < m && keys[L] == x) ? big_upper_bound(keys, m, x) : L;
-      atomicAdd(&hist[L], 0x10000u);
-      atomicAdd(&hist[U], 1u);
-      const unsigned bits = __float_as_uint(x);
-      unsigned h = (bits * 2654435761u) >> 19;                              // 13 bits: kBigHistSlots = 8192
-      for (;;) {
-        const unsigned old = atomicCAS(&hkey[h], kBigHistEmpty, bits);
-        if (old == kBigHistEmpty) break;                                    // first of its value
-        if (old == bits) {                                                  // the p-th, p = c + 2: adds p (p - 1)
-          const unsigned long long c = atomicAdd(&hcnt[h], 1u);
-          pp += (c + 2ull) * (c + 1ull);
-          break;
+    for (int t0 = 0; t0 < NQ; t0 += 4) {
+      if (t0 * kBigThreads >= q) break;                                     // (uniform: no thread has a sample left)
+      float x[4]; bool have[4]; int L[4], U[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        have[e] = tid + (t0 + e) * kBigThreads < q;
+        x[e] = have[e] ? xq[t0 + e] + 0.0f : inf;                          // (-0.0 -> +0.0: one key per value)
+        L[e] = 0; U[e] = 0;
+      }
+      for (int lv = 0, h = P >> 1; lv < levels; ++lv, h >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float kl = keys[L[e] + h - 1], ku = keys[U[e] + h - 1];
+          L[e] += (kl < x[e]) ? h : 0;                                      // #{s < x}
+          U[e] += (ku <= x[e]) ? h : 0;                                     // #{s <= x}
         }
-        h = (h + 1u) & (kBigHistSlots - 1u);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!have[e]) continue;
+        // (one more comparison: the loop ranks among P - 1 keys)
+        const int Lf = L[e] + ((keys[L[e]] < x[e] && L[e] == P - 1) ? 1 : 0);
+        const int Uf = U[e] + ((keys[U[e]] <= x[e] && U[e] == P - 1) ? 1 : 0);
+        atomicAdd(&hist[min(Lf, m)], 0x10000u);
+        atomicAdd(&hist[min(Uf, m)], 1u);
+        const unsigned bits = __float_as_uint(x[e]);
+        unsigned h = (bits * 2654435761u) >> 19;                            // 13 bits: kBigHistSlots = 8192
+        for (;;) {
+          const unsigned old = atomicCAS(&hkey[h], kBigHistEmpty, bits);
+          if (old == kBigHistEmpty) break;                                  // first of its value
+          if (old == bits) {                                                // the p-th, p = c + 2: adds p (p - 1)
+            const unsigned long long c = atomicAdd(&hcnt[h], 1u);
+            pp += (c + 2ull) * (c + 1ull);
+            break;
+          }
+          h = (h + 1u) & (kBigHistSlots - 1u);
+        }
       }
     }
     // ties inside S: every run of a equal keys adds (a^3 - a) / 3 = sum p (p - 1)

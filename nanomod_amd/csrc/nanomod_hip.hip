@@ -72,9 +72,7 @@ constexpr int kMetaRedo = 184;                  // float64 front end: [184] coun
                                                 // offset in the list), [242..243] u64 scratch keys they need, [244..245] u64 bump allocator
 constexpr int kMetaRedoTotal = 242, kMetaRedoCursor = 244;
 static_assert(kMetaRedo + kClassStride < kMetaRedoTotal && kMetaRedoCursor + 2 <= kMetaInts && kMetaBigCursor + 2 <= kMetaRedo, "meta layout");
-constexpr int kBigClass = kNumClasses;          // 47: positions for big_rank_kernel (big_rank.hpp)
-constexpr int kBigHistClass = kNumClasses + 1;  // 48: all-tests positions for big_hist_kernel (smaller group <= 2 048, larger <= 4 096)
-constexpr int kNumPairs = kNumClasses + 2;      // <= kClassStride
+// (kBigClass, kBigHistClass, kWideBigBase .., kNumPairs: rank_stats_launch.hpp)
 static_assert(kNumPairs <= kClassStride, "class tables");
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -135,6 +133,8 @@ __global__ __launch_bounds__(256) void classify_kernel(BinArgs a) {
                      (a.ks_only ? (c0 < c1 ? c0 : c1) >= kNumSizeClasses : (c0 >= kNumSizeClasses || c1 >= kNumSizeClasses));
     int cid;
     if (over || n0 <= 0 || n1 <= 0 || (big && !a.allow_big)) cid = 255;
+    else if (big && !a.ks_only && !a.force_big && (n0 < n1 ? n0 : n1) <= 256 && (n0 < n1 ? n1 : n0) <= kWideBigMaxQ)
+      cid = kWideBigBase + (c0 < c1 ? c0 : c1);
     else if (big && !a.ks_only && !a.force_big && (n0 < n1 ? n0 : n1) <= kBigHistMaxS && (n0 < n1 ? n1 : n0) <= kBigHistMaxQ) cid = kBigHistClass;
     else if (big) cid = kBigClass;
     else if (a.ks_only) cid = kKsClassBase + (c0 < c1 ? c0 : c1);
@@ -462,6 +462,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   ra.tied = f64 ? ws.tied : nullptr;            // float32 keys of float64 samples: K1 reports the positions whose keys tie
 
   auto launch = [&](int cls, int64_t work) -> hipError_t {
+    ra.class_id = cls;
     if (prm->dtype == NMOD_DTYPE_F32)
       return all ? launch_rank_stats_d0_a1(cls, num_cus, work, stream, ra)
                  : launch_rank_stats_d0_a0(cls, num_cus, work, stream, ra);
@@ -491,6 +492,13 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
       if (!wanted[cls]) continue;
       ra.pos_list = ws.order; ra.class_meta = ws.meta; ra.class_id = cls;
       NMOD_HIP(launch(cls, npos));
+    }
+    if (big_possible && all) {
+      // larger group of 2 049 .. 4 096 samples against at most 256: the two-pass form of rank_hist_kernel WIDE
+      for (int cs = 0; cs < kNumWideBig; ++cs) {
+        ra.pos_list = ws.order; ra.class_meta = ws.meta;
+        NMOD_HIP(launch(kWideBigBase + cs, npos));
+      }
     }
     if (big_possible) {
       // the only host round trip of this path: how many large positions, how much scratch
@@ -920,6 +928,9 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
   const int c0 = size_class_of(n0), c1 = size_class_of(n1);
   // the same decisions classify_kernel / detect_device take (NMOD_DTYPE_F64: the narrower dtype is a property of the data)
   const bool big = all ? (c0 >= kNumSizeClasses || c1 >= kNumSizeClasses) : (std::min(c0, c1) >= kNumSizeClasses);
+  if (big && all && std::min(n0, n1) <= 256 && std::max(n0, n1) <= kWideBigMaxQ) {
+    snprintf(buf, buflen, "rank_hist_kernel<%d,64,%s,wide>", 1 << std::min(c0, c1), dt); return NMOD_OK;
+  }
   if (big && all && std::min(n0, n1) <= kBigHistMaxS && std::max(n0, n1) <= kBigHistMaxQ) { snprintf(buf, buflen, "big_hist_kernel<%s>", dt); return NMOD_OK; }
   if (big) { snprintf(buf, buflen, "big_rank_kernel<%s>", dt); return NMOD_OK; }
   if (!all) {
@@ -933,6 +944,8 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
     const int cm = cls - kNumGeneralClasses;
     const int LG = ks_lanes_per_group(cm), R = (64 << cm) / LG;
     snprintf(buf, buflen, "rank_hist_kernel<%d,%d,%s>", R, LG, dt);
+  } else if (wide_class(cls)) {
+    snprintf(buf, buflen, "rank_hist_kernel<%d,64,%s,wide>", 1 << std::min(c0, c1), dt);
   } else {
     snprintf(buf, buflen, "rank_pair_kernel<%d,%d,%s>", 1 << c0, 1 << c1, dt);
   }

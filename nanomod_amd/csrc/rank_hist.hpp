@@ -31,6 +31,7 @@
 #include <stdint.h>
 #include "ks_rank.hpp"
 #include "rank_all.hpp"      // pad_run_pp
+#include "rank_stats_launch.hpp"   // kNumSizeClasses
 
 namespace nmod {
 
@@ -137,6 +138,7 @@ __device__ __forceinline__ unsigned pos_allsum_u32(unsigned v) {     // sum over
   v += (unsigned)dpp_i<kDppRowHalfMirror, 0xf, 0xf, true>(0, (int)v);
   if constexpr (LG >= 16) v += (unsigned)dpp_i<kDppRowMirror, 0xf, 0xf, true>(0, (int)v);
   if constexpr (LG >= 32) v += (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
+  if constexpr (LG == 64) v = (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 32);
   return v;
 }
 
@@ -145,6 +147,7 @@ __device__ __forceinline__ double seg_allmax_f64(double v) {
   v = fmax(v, dpp_f64_row(v, 0)); v = fmax(v, dpp_f64_row(v, 1)); v = fmax(v, dpp_f64_row(v, 2));
   if constexpr (LG >= 16) v = fmax(v, dpp_f64_row(v, 3));
   if constexpr (LG >= 32) v = fmax(v, xor16_f64(v));
+  if constexpr (LG == 64) v = wave_max_f64(v);
   return v;
 }
 
@@ -162,18 +165,42 @@ __device__ __forceinline__ double hist_exact_quot(int c, double n, double r) {
 #ifndef NMOD_HIST_WAVES
 #define NMOD_HIST_WAVES 4
 #endif
-template <int R, int LG, int DTYPE>
-__global__ __launch_bounds__(64 * kWavesPerBlock, (R <= 16 ? NMOD_HIST_WAVES : 2))
+// WIDE (LG = 64, R = 1, 2 or 4; one position per wave): positions whose groups fall in DIFFERENT capacity classes, the
+// smaller one S of at most 256 samples, the other Q of up to 4 096 (config 5: ~1000 v ~50 reads).  S is sorted and
+// ranked into exactly as above; Q streams through the ranking rounds in a loop (nothing of it is kept), and the ties
+// inside Q — the scatter + clean-up needs Q to fit the words of S — are counted by a per-wave hash table in LDS:
+// open addressing that inserts EVERY sample (a multiset): an arrival passes all earlier copies of its key on the way
+// along the key's probe sequence to the first empty slot, so it knows its place p in its run and adds p (p - 1).
+// The table has 128 << cq slots, cq = capacity class of Q (the larger of the launch's two classes, args.class_id):
+// at least twice the samples it can receive.  A Q of 2 049 .. 4 096 samples (classes kWideBigBase + class of S) takes the
+// 4 096-slot table twice: the values are split by one more hash bit and Q is streamed once per half.
+constexpr unsigned kWideEmpty = 0xffffffffu;
+__host__ __device__ constexpr int wide_slots(int cq) { return 128 << cq; }
+
+template <int R, int LG, int DTYPE, bool WIDE = false>
+__global__ __launch_bounds__(64 * kWavesPerBlock, (WIDE ? 2 : (R <= 16 ? NMOD_HIST_WAVES : 2)))
 void rank_hist_kernel(RankStatsArgs args) {
-  static_assert(LG == 8 || LG == 16 || LG == 32, "lanes per sorted group");
-  static_assert(R >= 8 && R <= 32 && (R & (R - 1)) == 0, "registers per lane");
-  static_assert(R * LG <= 1024, "32-bit tie sums and 15-bit counts need groups of at most 1024 samples");
+  static_assert(WIDE ? (LG == 64 && (R == 1 || R == 2 || R == 4)) : (LG == 8 || LG == 16 || LG == 32), "lanes per sorted group");
+  static_assert(WIDE || (R >= 8 && R <= 32 && (R & (R - 1)) == 0), "registers per lane");
+  static_assert(R * LG <= 1024, "32-bit tie sums and 15-bit counts need sorted groups of at most 1024 samples");   // (WIDE: Q <= 4096 < 2^15)
   constexpr int PW = 64 / LG;                  // positions per wave
   constexpr int C = R * LG;
-  constexpr int LOG_R = (R == 8) ? 3 : (R == 16) ? 4 : 5;
+  constexpr int LOG_R = (R == 1) ? 0 : (R == 2) ? 1 : (R == 4) ? 2 : (R == 8) ? 3 : (R == 16) ? 4 : 5;
   using Lay = KsLayout<R, LG>;
   constexpr int ROW = Lay::ROW;
-  constexpr int POS_WORDS = ks_rank_pos_words(R, LG);
+  constexpr int BIN_WORDS = WIDE ? ((ks_rank_pos_words(R, LG) + 3) & ~3) : ks_rank_pos_words(R, LG);   // keys + bins of a position
+  int wide_log = 0;                                                                // WIDE: log2 of the wave's hash slots
+  int wide_passes = 1;                                                             // WIDE: hash passes over Q
+  if constexpr (WIDE) {
+    if (args.class_id >= kWideBigBase) {           // Q of 2 049 .. 4 096 samples: two passes, half of the values each
+      wide_log = 12; wide_passes = 2;
+    } else {
+      const int ca = args.class_id / kNumSizeClasses, cb = args.class_id % kNumSizeClasses;
+      wide_log = 7 + (ca > cb ? ca : cb);
+    }
+  }
+  const int wslots = WIDE ? (1 << wide_log) : 0;
+  const int POS_WORDS = BIN_WORDS + wslots;                                        // WIDE: the table behind them (16-byte aligned)
   constexpr int HIST_OFF = Lay::REGION;        // words from key 0 to bin 0
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
 
@@ -244,7 +271,9 @@ void rank_hist_kernel(RankStatsArgs args) {
 
   Item cur = describe(wave_global);
   float x[R];
-  {
+  if constexpr (WIDE) {
+    load_group<R, DTYPE>(x, cur.swap ? args.sig1 : args.sig0, cur.off_s, cur.m, lane);
+  } else {
     KsRows<R, LG, DTYPE> first;
     first.request(cur.swap ? args.sig1 : args.sig0, cur.off_s, cur.m, gl);
     first.finish(x, cur.m, gl);
@@ -312,12 +341,13 @@ void rank_hist_kernel(RankStatsArgs args) {
     // ---- rank every Q sample into S and count it in the histograms; keep the sample and the LDS byte offset of its
     // L-bin inside the position's words (16 bits, two per register) for the scatter
     bool any_tie = false;
-    float xs[R];                                   // the samples this lane ranked (FLT_MAX where it had none)
-    unsigned la[R / 2];                            // byte offsets of their L-bins from `keys`
+    constexpr int NXS = WIDE ? 1 : R, NLA = WIDE ? 1 : R / 2;
+    float xs[NXS];                                 // the samples this lane ranked (FLT_MAX where it had none)
+    unsigned la[NLA];                              // byte offsets of their L-bins from `keys`
 #pragma unroll
-    for (int r = 0; r < R; ++r) xs[r] = big;
+    for (int r = 0; r < NXS; ++r) xs[r] = big;
 #pragma unroll
-    for (int r = 0; r < R / 2; ++r) la[r] = 0u;
+    for (int r = 0; r < NLA; ++r) la[r] = 0u;
 
     // rank NV samples: all the searches first (independent chains of LDS reads that the scheduler interleaves), then
     // the histogram updates.  Per sample slot: a slot in which no lane ties with S adds L and U in one go; a slot with
@@ -351,6 +381,102 @@ void rank_hist_kernel(RankStatsArgs args) {
       }
     };
 
+    unsigned ppq = 0;                              // WIDE: ties inside Q from the hash table
+    double s1w = 0.0, s2w = 0.0;                   // WIDE: Q's shifted moment sums
+    if constexpr (WIDE) {
+      unsigned* ht = reinterpret_cast<unsigned*>(keys) + BIN_WORDS;
+      const float kqf = (q > 0) ? (float)rk : 0.0f;
+      const double KQ = (double)kqf;
+      // insert NV samples into the multiset table; `dup` = earlier copies of the sample's key passed on the way
+      auto insert_many = [&](auto nv_tag, const float* xq, const bool* have, int pass) {
+        constexpr int NV = decltype(nv_tag)::value;
+        // double hashing: start and (odd) step from the key alone, so every copy of a value walks the same slots.  A
+        // lane without a sample to place issues a no-op (empty -> empty) instead of being masked off.
+        unsigned hh[NV], st[NV], bits[NV], dup[NV]; bool act[NV];
+        bool any = false;
+        const unsigned mask = (unsigned)(wslots - 1);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+          bits[e] = __float_as_uint(xq[e] + 0.0f);                             // (-0.0 -> +0.0: one key per value)
+          hh[e] = (bits[e] * 2654435761u) >> (32 - wide_log);
+          st[e] = ((bits[e] * 0x85ebca6bu) >> (32 - wide_log)) | 1u;
+          // (two passes: the values are split by one more hash bit; each pass holds one half in the table)
+          const bool mine = wide_passes == 1 || ((bits[e] * 0xc2b2ae35u) >> 31) == (unsigned)pass;
+          dup[e] = 0u; act[e] = have[e] && mine; any = any || act[e];
+        }
+#if (NMOD_SKIP & (128 | 256))
+        any = false;
+#endif
+        // every sample once per trip, the NV compare-and-swaps in flight together.  (Taking the stragglers one per lane
+        // and trip instead saves no instructions and adds round trips: measured 6-20 % slower.)
+        while (__ballot(any) != 0ull) {
+          unsigned old[NV];
+#pragma unroll
+          for (int e = 0; e < NV; ++e) old[e] = atomicCAS(&ht[hh[e]], kWideEmpty, act[e] ? bits[e] : kWideEmpty);
+          any = false;
+#pragma unroll
+          for (int e = 0; e < NV; ++e) {
+            dup[e] += (act[e] && old[e] == bits[e]) ? 1u : 0u;
+            act[e] = act[e] && old[e] != kWideEmpty;
+            hh[e] = (hh[e] + st[e]) & mask;
+            any = any || act[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) ppq += dup[e] * (dup[e] + 1u);            // the p-th of its value, p = dup + 1: p (p - 1)
+      };
+#pragma unroll 1
+      for (int pass = 0; pass < wide_passes; ++pass) {
+        const bool first = pass == 0;                // the pass that also ranks the samples and sums their moments
+        __builtin_amdgcn_wave_barrier();
+#if !(NMOD_SKIP & 256)
+        for (int i = lane; i < wslots / 4; i += 64)
+          reinterpret_cast<uint4*>(ht)[i] = make_uint4(kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty);
+#endif
+        if (!first) {
+          ra = load_q4(sig_q, off_q, 4 * gl, 0 < full);
+          rt = load_q1(sig_q, off_q, full * (4 * LG) + gl, full * (4 * LG) + gl < q);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll 1
+        for (int c = 0; c < full_w; ++c) {
+          const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
+          float xa[4];
+          xa[0] = (float)ra.x; xa[1] = (float)ra.y; xa[2] = (float)ra.z; xa[3] = (float)ra.w;
+          const bool hv[4] = {true, true, true, true};
+          if (first) {
+            unsigned ad[4];
+#if !(NMOD_SKIP & 512)
+            rank_many(std::integral_constant<int, 4>{}, xa, true, ad);
+#endif
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double d = (double)xa[e] - KQ; s1w += d; s2w = __fma_rn(d, d, s2w); }
+          }
+          insert_many(std::integral_constant<int, 4>{}, xa, hv, pass);
+          ra = rb;
+        }
+#pragma unroll 1
+        for (int c = 0; c < tail_w; ++c) {
+          const int idx_now = full * (4 * LG) + c * LG + gl;
+          const bool have = idx_now < q;
+          const float xq1[1] = {have ? (float)rt : big};
+          const int idx = full * (4 * LG) + (c + 1) * LG + gl;
+          rt = load_q1(sig_q, off_q, idx, idx < q);
+          const bool hv[1] = {have};
+          if (first) {
+            unsigned a1[1];
+#if !(NMOD_SKIP & 512)
+            rank_many(std::integral_constant<int, 1>{}, xq1, have, a1);
+#endif
+            const double d = (double)(have ? xq1[0] : kqf) - KQ;
+            s1w += d; s2w = __fma_rn(d, d, s2w);
+          }
+          insert_many(std::integral_constant<int, 1>{}, xq1, hv, pass);
+        }
+      }
+    } else {
     __builtin_amdgcn_s_waitcnt(0x0F70);            // everything requested before the sort has arrived
 #if (NMOD_SKIP & 32)
     full_w = 0; tail_w = 0;
@@ -394,6 +520,7 @@ void rank_hist_kernel(RankStatsArgs args) {
           }
       }
     }
+    }   // !WIDE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -410,6 +537,7 @@ void rank_hist_kernel(RankStatsArgs args) {
     int maxc;
     unsigned best;
     unsigned acc_l = 0, acc_u = 0, ab3 = 0;
+    unsigned long long ab3w = 0ull;                // WIDE: a b (a + b) can pass 2^32 (256 keys tied with 4 096 samples)
     {
       unsigned h[R];
 #pragma unroll
@@ -450,7 +578,8 @@ void rank_hist_kernel(RankStatsArgs args) {
         const int cand_b = __mul24(cl, m) + nkq;                             // (cumL(k-1), k)
         const int b = run_end ? cl - cu : 0;                                 // samples of Q equal to the run of S ending at k
         const int a = k - start;
-        ab3 += (unsigned)__mul24(__mul24(a, b), a + b);
+        if constexpr (WIDE) ab3w += (unsigned long long)(unsigned)__mul24(a, b) * (unsigned long long)(unsigned)(a + b);
+        else ab3 += (unsigned)__mul24(__mul24(a, b), a + b);
         start = run_end ? k : start;
         c2 += h[r];
         cu = (int)(c2 & 0xffffu);
@@ -466,6 +595,7 @@ void rank_hist_kernel(RankStatsArgs args) {
       // (finished HERE: left to the scheduler, the tie and rank sums sink to the end of the item and keep the 32
       // per-bin counts they are built from in registers across the scatter, the float-form pass and the clean-up)
       asm volatile("" : "+v"(ab3), "+v"(acc_l), "+v"(acc_u), "+v"(best));
+      if constexpr (WIDE) asm volatile("" : "+v"(ab3w));
       __builtin_amdgcn_sched_barrier(0);
     }
     const unsigned lbest = best;
@@ -474,6 +604,20 @@ void rank_hist_kernel(RankStatsArgs args) {
     __builtin_amdgcn_wave_barrier();
 
 #if !(NMOD_SKIP & 64)
+    if constexpr (WIDE) {
+      // Q's moments from the sums of the ranking rounds (shifted by its first sample)
+      const float kqf = (q > 0) ? (float)rk : 0.0f;
+      const double KQ = (double)kqf;
+      const double s1 = seg_allsum_f64<LG>(s1w), s2 = seg_allsum_f64<LG>(s2w);
+      const double dn = (double)q;
+      double mu = KQ + s1 / dn;
+      double qq = s2 - s1 * s1 / dn;
+      if constexpr (DTYPE != 0) { mu = mu / 1000.0; qq = qq * 1e-6; }
+      if (valid && gl2 == 0) {
+        double* mo = args.moments + pos * 4 + (swap ? 0 : 2);
+        mo[0] = mu; mo[1] = qq;
+      }
+    } else {
     // ---- scatter Q by bin into the key words of S (dead from here on: the table carries its run ends).  The high
     // half of a bin's table word is its bump allocator: afterwards it holds cumL(k).  Q's moments on the way, shifted
     // by its first sample (a slot without a sample adds 0).
@@ -515,9 +659,9 @@ void rank_hist_kernel(RankStatsArgs args) {
         mo[0] = mu; mo[1] = qq;
       }
     }
+    }   // !WIDE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-
 #endif
     // ---- the float form of D, only for the candidates that reach the integer maximum: the lanes of a position
     // take the bins of one such lane at a time from the table
@@ -531,13 +675,14 @@ void rank_hist_kernel(RankStatsArgs args) {
       else { rm = 1.0 / dm; rq = 1.0 / dq; }
       // hit lanes of this lane's position as a bit mask (bit j: lane j of the group reached the maximum)
       const unsigned long long hits = __ballot(lbest == best && best != 0u);
-      unsigned mine = (unsigned)(hits >> seg_base);
-      if constexpr (LG < 32) mine &= (1u << LG) - 1u;
+      using Mine = typename std::conditional<LG == 64, unsigned long long, unsigned>::type;
+      Mine mine = (Mine)(hits >> seg_base);
+      if constexpr (LG < 32) mine &= (Mine)((1u << LG) - 1u);
 #if (NMOD_SKIP & 2)
       mine = 0;
 #endif
       // the candidate (cumU(0), 0) belongs to lane 0 of the position
-      if (gl2 == 0 && (mine & 1u)) {
+      if (gl2 == 0 && (mine & (Mine)1)) {
         const int cu0 = (int)(cum & 0xffffu);
         if ((unsigned)__mul24(cu0, mo) == best) dmax = hist_exact_quot(cu0, dq, rq);
       }
@@ -549,10 +694,10 @@ void rank_hist_kernel(RankStatsArgs args) {
         wofs[j][0] = Lay::word(rr); wofs[j][1] = Lay::word(rr + 1); wofs[j][2] = Lay::word(rr + 2);
       }
 #pragma unroll 1
-      while (__ballot(mine != 0u) != 0ull) {
-        const bool act = mine != 0u;
-        const int hl = act ? (__ffs((int)mine) - 1) : 0;                      // the lane of this position whose bins are examined
-        mine &= mine - 1u;
+      while (__ballot(mine != (Mine)0) != 0ull) {
+        const bool act = mine != (Mine)0;
+        const int hl = act ? (__ffsll((long long)mine) - 1) : 0;              // the lane of this position whose bins are examined
+        mine &= mine - (Mine)1;
 #pragma unroll
         for (int j = 0; j < (R + LG - 1) / LG; ++j) {
           const int rr = gl2 + j * LG;
@@ -562,7 +707,8 @@ void rank_hist_kernel(RankStatsArgs args) {
           const unsigned wp = hist[wofs[j][0] + hl];
           const unsigned w = hist[wofs[j][1] + hl];
           const unsigned wn = (k < C) ? hist[wofs[j][2] + hl] : (unsigned)qo;
-          const int cl = (int)(wp >> 16), cu = (int)(wn & 0x7fffu);
+          // (after the scatter the high half of word k - 1 is cumL(k - 1); WIDE has no scatter: word k still holds it)
+          const int cl = (int)((WIDE ? w : wp) >> 16), cu = (int)(wn & 0x7fffu);
           const bool run_end = (w & 0x8000u) != 0u;
           const int nkq = -__mul24(k, qo);
           const int cand_b = __mul24(cl, mo) + nkq, cand_a = __mul24(cu, mo) + nkq;
@@ -581,9 +727,14 @@ void rank_hist_kernel(RankStatsArgs args) {
     // the next item's S rows: requested as late as the rest of the iteration can still cover the round trip (they
     // occupy 16 registers from here on)
     const Item nxt = describe(it + wave_stride);
-    KsRows<R, LG, DTYPE> rows_next;
-    rows_next.request(nxt.swap ? args.sig1 : args.sig0, nxt.off_s, nxt.m, gl2);
+    KsRows<(WIDE ? 4 : R), LG, DTYPE> rows_next;                             // (WIDE: unused; its rows are R < 4 plain loads)
+    float xn[WIDE ? R : 1];
+    if constexpr (WIDE) load_group<R, DTYPE>(xn, nxt.swap ? args.sig1 : args.sig0, nxt.off_s, nxt.m, lane);
+    else rows_next.request(nxt.swap ? args.sig1 : args.sig0, nxt.off_s, nxt.m, gl2);
 
+    if constexpr (WIDE) {
+      pp += ppq;
+    } else {
     // ---- Q in sorted order: read the scattered keys back, finish inside the bins, count its ties
     __builtin_amdgcn_wave_barrier();
     float y[R];
@@ -599,10 +750,18 @@ void rank_hist_kernel(RankStatsArgs args) {
     if (maxc > 1) seg_oddeven_phases<R, LG>(y, gl2, maxc);
     pp += seg_tie_pp<R, LG>(y, gl2, lane);
 #endif
+    }
 
     // ---- totals of the position
-    const unsigned PP = pos_allsum_u32<LG>(pp);
-    const unsigned AB = pos_allsum_u32<LG>(ab3);
+    // (WIDE: the totals can pass 2^32 — per lane pp < 2^31 and ab3w < 2^35 — so they are summed in two parts)
+    unsigned long long PP, AB;
+    if constexpr (WIDE) {
+      PP = ((unsigned long long)pos_allsum_u32<LG>(pp >> 16) << 16) + (unsigned long long)pos_allsum_u32<LG>(pp & 0xffffu);
+      AB = ((unsigned long long)pos_allsum_u32<LG>((unsigned)(ab3w >> 20)) << 20) + (unsigned long long)pos_allsum_u32<LG>((unsigned)ab3w & 0xfffffu);
+    } else {
+      PP = pos_allsum_u32<LG>(pp);
+      AB = pos_allsum_u32<LG>(ab3);
+    }
     const unsigned AL = pos_allsum_u32<LG>(acc_l);
     const unsigned AU = pos_allsum_u32<LG>(acc_u);
     if (valid && gl2 == 0) {
@@ -610,14 +769,19 @@ void rank_hist_kernel(RankStatsArgs args) {
       const unsigned long long slu = 2ull * (unsigned long long)C * (unsigned long long)q - (unsigned long long)AL - (unsigned long long)AU;
       // mwu_s = sum_{a in group 1} (#{b < a} + #{b <= a}): Q is group 1 when swapped, else count from group 2's side
       args.mwu_s[pos] = swap ? slu : 2ull * (unsigned long long)m * (unsigned long long)q - slu;
-      args.tie[pos] = 3ull * (unsigned long long)PP + 3ull * (unsigned long long)AB;
+      args.tie[pos] = 3ull * PP + 3ull * AB;
       args.ks_d_ref[pos] = (m > 0 && q > 0) ? dmax : 0.0;
       args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;
-      if (args.tied) args.tied[pos] = (PP != 0u || AB != 0u) ? 1 : 0;   // any two samples of the position compare equal
+      if (args.tied) args.tied[pos] = (PP != 0ull || AB != 0ull) ? 1 : 0;   // any two samples of the position compare equal
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    rows_next.finish(x, nxt.m, gl);
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) x[r] = xn[r];
+    } else {
+      rows_next.finish(x, nxt.m, gl);
+    }
     cur = nxt;
   }
 }

@@ -1,5 +1,6 @@
 // Instantiates K1 for every (R0, R1) size class of one (dtype, tests) pair.
 // Built four times by the Makefile: -DNMOD_INST_DTYPE={0,1} -DNMOD_INST_ALL={0,1}.
+#include <algorithm>
 #include <atomic>
 #include "rank_stats.hpp"
 #include "rank_stats_packed.hpp"
@@ -45,6 +46,13 @@ KernelFn pick(int c0, int c1) {
     default: return pick1<5>(c1);
   }
 }
+KernelFn pick_wide(int cmin) {
+  switch (cmin) {
+    case 0: return rank_hist_kernel<1, 64, DT, true>;
+    case 1: return rank_hist_kernel<2, 64, DT, true>;
+    default: return rank_hist_kernel<4, 64, DT, true>;
+  }
+}
 KernelFn pick_packed(int cm) {
   switch (cm) {
     case 0: return rank_hist_kernel<8, 8, DT>;
@@ -88,12 +96,15 @@ KernelFn pick_ks(int cs, bool flags) {
 
 hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_t stream,
                             const RankStatsArgs& args) {
-  const bool ks = cls >= kKsClassBase;
-  const bool packed = !ks && cls >= kNumGeneralClasses;
+  const bool ks = cls >= kKsClassBase && cls < kNumClasses;
+  const bool packed = cls >= kNumGeneralClasses && cls < kKsClassBase;
   KernelFn fn = nullptr;
 #if NMOD_INST_ALL
   if (ks) return hipErrorInvalidValue;
-  fn = packed ? pick_packed(cls - kNumGeneralClasses) : pick(cls / kNumSizeClasses, cls % kNumSizeClasses);
+  const bool wide = wide_class(cls);
+  fn = packed ? pick_packed(cls - kNumGeneralClasses)
+       : wide ? pick_wide(wide_class_of_s(cls))
+              : pick(cls / kNumSizeClasses, cls % kNumSizeClasses);
 #else
   if (!ks) return hipErrorInvalidValue;
   fn = pick_ks(cls - kKsClassBase, args.tied != nullptr);
@@ -111,8 +122,13 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
   const int slot_id = cls + ((ks && args.tied) ? kClassStride : 0);
   int per_cu = cacheable ? per_cu_cache[dev][slot_id].load(std::memory_order_relaxed) : 0;
   if (per_cu <= 0) {
+    // (one WIDE instance serves every class of the larger group: its limit is that of the largest)
+    size_t lds_limit = lds;
+#if NMOD_INST_ALL
+    if (wide) lds_limit = rank_stats_lds_bytes(kWideBigBase + wide_class_of_s(cls), ALL);
+#endif
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);
     if (e != hipSuccess) return e;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kWavesPerBlock, lds);
     if (e != hipSuccess) return e;

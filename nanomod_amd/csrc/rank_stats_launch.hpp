@@ -1,7 +1,9 @@
 // Host-side launch interface of K1 (one translation unit per dtype x tests pair).
 //
 // Size classes.  A group of n samples needs capacity 64 << c (c = 0..5: 64 .. 2048).
-//   general class  c0 * 6 + c1      (0..35): rank_pair_kernel<1<<c0, 1<<c1> (rank_all.hpp), 64 lanes per group;
+//   general class  c0 * 6 + c1      (0..35): min(c0, c1) <= 2 -> rank_hist_kernel<1 << min, 64, dtype, WIDE> (the smaller
+//                  group sorted over the 64 lanes, the larger one streamed; rank_hist.hpp); otherwise
+//                  rank_pair_kernel<1<<c0, 1<<c1> (rank_all.hpp), both groups sorted, 64 lanes per group;
 //   packed class   36 + cm          (36..40): rank_hist_kernel (rank_hist.hpp), both groups in capacity 64 << cm,
 //                  used when max(c0,c1) = cm <= 4 and min(c0,c1) >= cm - 1:
 //                  cm 0..1 -> (R, LG) = (8,8) (16,8): eight positions per wave; cm 2..3 -> (16,16) (32,16): four;
@@ -19,7 +21,14 @@ constexpr int kNumGeneralClasses = kNumSizeClasses * kNumSizeClasses;
 constexpr int kNumPackedClasses = 5;
 constexpr int kNumKsClasses = 6;                   // KS-only form (ks_rank.hpp): class of the SMALLER group
 constexpr int kKsClassBase = kNumGeneralClasses + kNumPackedClasses;    // 41
-constexpr int kNumClasses = kKsClassBase + kNumKsClasses;               // 47 (+ 2 large-position classes) <= kClassStride (56)
+constexpr int kNumClasses = kKsClassBase + kNumKsClasses;               // 47 (+ the large-position classes) <= kClassStride (56)
+// large positions (at least one group beyond 2 048 samples; binned by classify_kernel, nanomod_hip.hip)
+constexpr int kBigClass = kNumClasses;             // 47: big_rank_kernel (big_rank.hpp)
+constexpr int kBigHistClass = kNumClasses + 1;     // 48: all tests, big_hist_kernel (smaller group <= 1 024, larger <= 4 096)
+constexpr int kWideBigBase = kNumClasses + 2;      // 49 + cs: all tests, smaller group in class cs <= 2 (<= 256), larger 2 049 .. 4 096:
+constexpr int kNumWideBig = 3;                     //          rank_hist_kernel WIDE with two hash passes (rank_hist.hpp)
+constexpr int kWideBigMaxQ = 4096;
+constexpr int kNumPairs = kWideBigBase + kNumWideBig;                   // 52 class lists
 
 __host__ __device__ inline int size_class_of(int64_t n) {   // smallest class with 64 << c >= n; 6 if too large
   int c = 0;
@@ -31,6 +40,15 @@ __host__ __device__ inline int launch_class_of(int c0, int c1) {
   if (cm <= 4 && cl >= cm - 1) return kNumGeneralClasses + cm;
   return c0 * kNumSizeClasses + c1;
 }
+// general classes served by the WIDE form of rank_hist_kernel: the smaller group fits 256 sorted samples
+inline bool wide_class(int cls) {
+  if (cls >= kWideBigBase) return cls < kWideBigBase + kNumWideBig;
+  return cls < kNumGeneralClasses && (cls / kNumSizeClasses <= 2 || cls % kNumSizeClasses <= 2);
+}
+inline int wide_class_of_s(int cls) {              // capacity class of the smaller group of a WIDE class
+  if (cls >= kWideBigBase) return cls - kWideBigBase;
+  return cls / kNumSizeClasses < cls % kNumSizeClasses ? cls / kNumSizeClasses : cls % kNumSizeClasses;
+}
 // KS-only classes: capacity 64 << cs sorted in (R, LG) = (8,8) (16,8) (16,16) (32,16) (32,32) (32,64)
 inline int ks_lanes_per_group(int cs) { return cs <= 1 ? 8 : (cs == 2 ? 16 : (8 << (cs - 2))); }
 inline int ks_positions_per_wave(int cs) { return 64 / ks_lanes_per_group(cs); }
@@ -38,7 +56,14 @@ inline int ks_positions_per_wave(int cs) { return 64 / ks_lanes_per_group(cs); }
 inline int packed_positions_per_wave(int cm) { return ks_positions_per_wave(cm); }
 inline size_t rank_stats_lds_bytes(int cls, bool all) {
   size_t words;
-  if (cls >= kKsClassBase) {
+  if (wide_class(cls)) {
+    // rank_hist_kernel WIDE (rank_hist.hpp): keys + bins of S (rounded to 16 bytes) + the wave's hash table, + two doubles
+    const int c0 = cls / kNumSizeClasses, c1 = cls % kNumSizeClasses;
+    const size_t R = (size_t)1 << wide_class_of_s(cls);
+    const int cq = cls >= kWideBigBase ? kNumSizeClasses - 1 : (c0 < c1 ? c1 : c0);
+    const size_t w = ((2 * R * 65 + 3) & ~(size_t)3) + ((size_t)128 << cq);
+    return w * 4 * 4 + 16;
+  } else if (cls >= kKsClassBase) {
     int cs = cls - kKsClassBase;
     size_t LG = (size_t)ks_lanes_per_group(cs), R = (64u << cs) / LG;
     size_t w = 2 * R * (LG + 1);                                             // ks_rank_pos_words (ks_rank.hpp)

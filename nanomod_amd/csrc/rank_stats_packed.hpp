@@ -56,7 +56,16 @@ template <int LG>
 __device__ __forceinline__ double seg_allsum_f64(double v) {
   v += dpp_f64_row(v, 0); v += dpp_f64_row(v, 1); v += dpp_f64_row(v, 2);
   if constexpr (LG >= 16) v += dpp_f64_row(v, 3);
-  if constexpr (LG == 32) v += xor16_f64(v);
+  if constexpr (LG >= 32) v += xor16_f64(v);
+  if constexpr (LG == 64) {                        // both 32-lane halves hold their sum in every lane
+    auto lane_of = [](double x, int l) {
+      const long long b = __double_as_longlong(x);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), l);
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    v = lane_of(v, 0) + lane_of(v, 32);
+  }
   return v;
 }
 

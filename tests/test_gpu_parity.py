@@ -365,6 +365,53 @@ def test_ks_only_large_ranked_group(nm):
         assert abs(got['ks_d'][i] - d) <= 4.5e-16 and abs(got['ks_p'][i] - max(p, orc.DBL_MIN)) <= 1e-9 * max(p, orc.DBL_MIN), i
 
 
+@pytest.mark.parametrize('mode', ['cont', 'grid1', 'const', 'i16'])
+def test_unequal_classes_streamed_larger_group(nm, mode):
+    """positions whose groups fall in different capacity classes with the smaller one <= 256 samples: the WIDE form of
+    rank_hist_kernel (smaller group sorted, larger one streamed and counted in a per-wave hash table), the larger group up
+    to 2 048 in one pass and 2 049 .. 4 096 in two; either group may be the larger one.  `const`: every sample of a
+    position equal — the longest probe chains and the largest tie sums (256 keys tied with 4 096 samples: a b (a + b)
+    and the sum of t^3 - t pass 2^32)"""
+    import nanomod_oracle as orc
+    rng = np.random.default_rng(zlib.crc32(mode.encode()))
+    sizes = [(50, 1000), (1000, 50), (3, 130), (64, 65), (65, 2048), (130, 700), (256, 2048), (256, 4096), (4096, 256),
+             (1, 2049), (2500, 7), (200, 3000), (100, 129), (128, 1025), (256, 4095), (17, 4096)]
+    ca, cb = [], []
+    for i, (a, b) in enumerate(sizes):
+        x = rng.normal(0, 1, a); y = rng.normal(0.3 if i % 2 else 0.0, 1.2, b)
+        if mode == 'grid1':
+            x, y = np.round(x, 1), np.round(y, 1)
+        elif mode == 'const':
+            x[:] = 0.25; y[:] = 0.25
+            if i % 3 == 0:
+                y[: b // 2] = -1.5                    # two runs in the larger group, one of them tied with all of the smaller
+        ca.append(x); cb.append(y)
+    off0 = np.zeros(len(sizes) + 1, np.int64); off0[1:] = np.cumsum([len(c) for c in ca])
+    off1 = np.zeros(len(sizes) + 1, np.int64); off1[1:] = np.cumsum([len(c) for c in cb])
+    rid = np.zeros(len(sizes), np.int32)
+    if mode == 'i16':
+        sig0 = np.round(np.concatenate(ca) * 1000).astype(np.int16); sig1 = np.round(np.concatenate(cb) * 1000).astype(np.int16)
+        r0, r1 = sig0.astype(np.float64) / 1000, sig1.astype(np.float64) / 1000
+    else:
+        sig0 = np.concatenate(ca).astype(np.float32); sig1 = np.concatenate(cb).astype(np.float32); r0, r1 = sig0, sig1
+    got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=1, weights_dif=2.0, method='fisher')
+    exp = orc.detect_batch(r0, off0, r1, off1, rid, 1, 2.0, orc.METHOD_FISHER)
+    ident = (exp['status'] & 1) != 0                  # all samples identical: U / p NaN on both sides
+    assert np.array_equal(np.isnan(got['mwu_u']), np.isnan(exp['mwu_u']))
+    got['mwu_u'][ident] = 0.0; exp['mwu_u'][ident] = 0.0
+    H.compare_outputs(got, exp, True)
+    assert np.array_equal(got['status'], exp['status'])
+    # what runs: the dispatch description names the kernel for the sizes of the extremes
+    L = nm._lib
+    import ctypes as C
+    buf = C.create_string_buffer(96)
+    for (a, b), want in (((50, 1000), b'rank_hist_kernel<1,64,f32,wide>'), ((256, 4096), b'rank_hist_kernel<4,64,f32,wide>'),
+                         ((4096, 130), b'rank_hist_kernel<4,64,f32,wide>'), ((300, 4096), b'big_hist_kernel<f32>')):
+        prm = L.make_params(method=L.METHOD_FISHER, nb=1)
+        assert L.load().nmod_describe_dispatch(C.byref(prm), a, b, buf, 96) == 0
+        assert buf.value == want, (a, b, buf.value)
+
+
 @pytest.mark.parametrize('grid', [False, True])
 def test_large_positions_all_tests_and_ks_only(nm, grid):
     """positions beyond the wave-resident kernels (> 2048 samples in a sorted group) take big_rank_kernel: LDS sort

@@ -127,8 +127,10 @@ def select_positions(g0, g1, min_coverage, out_level=detect.OUTPUT_ERROR, log=pr
     if out_level <= detect.OUTPUT_ERROR:
         for i in mism[:20]:
             log('Error not equal', (chrom[i], strand[i]), int(pos[i]), base[i], g0['base'][rows0][i])
-    both = detect.encode_signals(np.concatenate([sig0, sig1])) if npos else np.zeros(0, np.float32)
-    sig0, sig1 = both[:len(sig0)], both[len(sig0):]
+    if npos:
+        sig0, sig1 = detect.encode_pair(np.asarray(sig0), np.asarray(sig1))
+    else:
+        sig0 = sig1 = np.zeros(0, np.float32)
     rid = detect.run_ids(chrom, strand, pos)
     n0 = np.diff(off0).astype(np.int32); n1 = np.diff(off1).astype(np.int32)
     meta = dict(chrom=chrom, strand=strand, pos=pos, base=base, n0=n0, n1=n1, names=names,

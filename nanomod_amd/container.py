@@ -51,5 +51,7 @@ def gather_rows(sig, off, rows):
     new_off[1:] = np.cumsum(lens)
     if len(rows) == 0:
         return sig[:0], new_off
+    if int(rows[-1]) - int(rows[0]) + 1 == len(rows) and (len(rows) == 1 or bool(np.all(np.diff(rows) == 1))):
+        return sig[off[rows[0]]:off[rows[-1] + 1]], new_off          # consecutive rows: a view, no gather
     idx = np.repeat(off[rows] - new_off[:-1], lens) + np.arange(new_off[-1], dtype=np.int64)
     return sig[idx], new_off

@@ -55,12 +55,18 @@ def mfilter_coverage(moptions):
 
 
 # ---------------------------------------------------------------------------
+# Above this many samples the host does not look for a narrower dtype: the float64 values go to the device as they are
+# and the front end of NMOD_DTYPE_F64 picks order-preserving float32 keys per position there (nanomod_hip.hip:
+# detect_f64).  The host-side search is ~8 passes over the vector (1.2 s of the 3.6 s of a 4.6 M-position mtest2).
+DEVICE_ENCODE_ABOVE = 4_000_000
+
+
 def encode_signals(values):
     """Pick the device dtype for a float64 sample vector without changing a
     single value the reference would see: float32 if every value is
     float32-exact, else int16 milli-units if every value is k/1000.0 (NanoMod's
     Events are 3-dp rounded, myRefBaseSignalAnnotation.py:1108), else the
-    float64 values themselves (NMOD_DTYPE_F64: sorted as 64-bit keys, slower)."""
+    float64 values themselves (NMOD_DTYPE_F64: the device picks keys per position)."""
     v = np.asarray(values, dtype=np.float64)
     f32 = v.astype(np.float32)
     if np.array_equal(f32.astype(np.float64), v):
@@ -69,6 +75,14 @@ def encode_signals(values):
     if np.all(np.abs(k) <= 32767) and np.array_equal(k / 1000.0, v):
         return k.astype(np.int16)
     return v
+
+
+def encode_pair(sig0, sig1):
+    """encode_signals for the two groups of a batch (one dtype for both); large float64 batches pass through"""
+    if sig0.dtype == np.float64 and sig1.dtype == np.float64 and sig0.size + sig1.size > DEVICE_ENCODE_ABOVE:
+        return np.ascontiguousarray(sig0), np.ascontiguousarray(sig1)
+    both = encode_signals(np.concatenate([sig0, sig1]))
+    return both[:len(sig0)], both[len(sig0):]
 
 
 def _coverage_threshold(moptions, m_str):
@@ -267,8 +281,7 @@ def build_csr(moptions):
                 return np.concatenate(chunks).astype(np.float64, copy=False)
             import itertools
             return np.fromiter(itertools.chain.from_iterable(chunks), dtype=np.float64, count=total)   # one pass, no per-position arrays
-        both = encode_signals(np.concatenate([flat(chunks0, int(off0[-1])), flat(chunks1, int(off1[-1]))]))
-        sig0, sig1 = both[:off0[-1]], both[off0[-1]:]
+        sig0, sig1 = encode_pair(flat(chunks0, int(off0[-1])), flat(chunks1, int(off1[-1])))
     else:
         sig0 = sig1 = np.zeros(0, dtype=np.float32)
     names = sorted(set(chrom))

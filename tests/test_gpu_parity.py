@@ -97,6 +97,25 @@ def test_golden_tables_through_mtest2(nm, inp, name, nb, wdif, method):
     assert np.all(np.abs(a - b) <= 1e-9 * np.abs(b))
 
 
+@pytest.mark.parametrize('inp,name,method', [('ragged', 'ragged_stouffer', 'stouffer'), ('ties', 'ties_stouffer', 'stouffer'),
+                                             ('g50', 'g50_fisher', 'fisher')])
+def test_golden_tables_with_device_side_dtype_choice(nm, inp, name, method, monkeypatch):
+    """large float64 batches skip the host's search for a narrower dtype (detect.DEVICE_ENCODE_ABOVE) and let the float64
+    front end of the device pick keys per position: forced here on the golden fixtures — same table, byte for byte"""
+    import nanomod_amd.detect as D
+    monkeypatch.setattr(D, 'DEVICE_ENCODE_ABOVE', 0)
+    fx = H.load_inputs(inp)
+    exp, table = H.load_expected(name)
+    with tempfile.TemporaryDirectory() as out:
+        mo = H.build_moptions(fx, out, name, 2, 2.0, method)
+        nm.mfilter_coverage(mo)
+        meta, sig0, off0, sig1, off1, rid = D.build_csr(mo)
+        assert sig0.dtype == np.float64 and sig1.dtype == np.float64
+        nm.mtest2(mo)
+        with open(os.path.join(out, name + '_sign_test.txt')) as f:
+            assert f.read() == table
+
+
 def _random_batch(rng, npos, lo0, hi0, lo1, hi1, grid=False, shift_every=7):
     ca, cb = [], []
     for i in range(npos):

@@ -79,12 +79,15 @@ def test_cfg3_all_tests_fisher_full_size(nm):
 
 
 def test_cfg4_shape_500v500_fixed_stride(nm):
-    """configs[3]'s per-GPU shape: 500 v 500 reads/position, fixed stride, KS + Stouffer, 2 M positions (8 GB; the
-    8 M positions of a chr20 shard are the same launch four times over): oracle samples, swap symmetry, invariance
-    under a permutation of the reads inside every position, all-tests mode agrees on D and p"""
+    """configs[3]'s per-GPU share at full size: 8 M positions x 500 v 500 reads, fixed stride, KS + Stouffer (32 GB of
+    samples): oracle samples, swap symmetry, invariance under a permutation of the reads inside every position,
+    all-tests mode agrees on D and p"""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 80 * 2 ** 30:
+        pytest.skip('needs ~60 GB of device memory')
     import torch
     L = nm._lib
-    P, n, nb = 2_000_000, 500, 2
+    P, n, nb = 8_000_000, 500, 2          # chr20's per-GPU share of configs[3]: 2 x 16 GB of float32, element offsets beyond 2^32
     dev = 'cuda:0'
     det = nm.DeviceDetector(0, nb=nb, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
     a = torch.empty(P * n, dtype=torch.float32, device=dev); b = torch.empty(P * n, dtype=torch.float32, device=dev)
@@ -93,7 +96,7 @@ def test_cfg4_shape_500v500_fixed_stride(nm):
     r1 = {k: v.clone() for k, v in det.run(a, b, rid, stride0=n, stride1=n, npos=P).items()}
     torch.cuda.synchronize()
     cnt = 8000
-    for lo in (0, 999_990, P - cnt):
+    for lo in (0, 3_999_990, P - cnt):
         exp = _oracle_sample(a, b, n, n, lo, cnt, nb, 'stouffer', tests=1)
         _cmp_sample(r1, exp, lo, cnt, nb, ('ks_d', 'ks_p', 'comb_st', 'comb_p'))
     r2 = det.run(b, a, rid, stride0=n, stride1=n, npos=P)
@@ -181,3 +184,55 @@ def test_cfg5_ragged_lognormal_one_million(nm, tests_all):
     assert max(work) - min(work) <= 2 * 4400
     for k in got:
         assert torch.equal(got[k], full[k]), k
+
+
+@pytest.mark.parametrize('tests_all', [False, True])
+def test_cfg5_full_size_ten_million(nm, tests_all):
+    """configs[4] at BASELINE.json's full size on one GPU: 10 M ragged positions, 1.2e10 samples (47 GB of float32 in
+    HBM, offsets beyond 2^32 bytes).  Oracle on position slices from the start, the middle and the end, on the largest
+    positions, and the swap symmetry of D over the whole batch."""
+    import torch
+    import oracle_c
+    L = nm._lib
+    P, nb = 10_000_000, 2
+    dev = 'cuda:0'
+    if torch.cuda.get_device_properties(0).total_memory < 80 * 2 ** 30:
+        pytest.skip('needs ~60 GB of device memory')
+    rng = np.random.default_rng(55)
+    n0 = np.clip(np.round(rng.lognormal(np.log(1000), 0.5, P)), 5, 4000).astype(np.int64)
+    n1 = np.clip(np.round(rng.lognormal(np.log(50), 0.5, P)), 5, 400).astype(np.int64)
+    off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum(n0)
+    off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum(n1)
+    assert off0[-1] * 4 > 2 ** 32
+    g = torch.Generator(device=dev); g.manual_seed(10)
+    s0 = torch.empty(int(off0[-1]), dtype=torch.float32, device=dev)
+    step = 1 << 30
+    for lo in range(0, s0.numel(), step):                       # (piecewise: the generator's own temporaries stay small)
+        s0[lo:lo + step].normal_(generator=g)
+    s1 = torch.randn(int(off1[-1]), dtype=torch.float32, device=dev, generator=g) + 0.1
+    o0 = torch.from_numpy(off0).to(dev); o1 = torch.from_numpy(off1).to(dev)
+    rid = torch.as_tensor((np.arange(P) // 500_009).astype(np.int32), device=dev)
+    det = nm.DeviceDetector(0, nb=nb, weights_dif=2.0, method='stouffer', tests=L.TEST_ALL if tests_all else L.TEST_KS)
+    full = {k: v.clone() for k, v in det.run(s0, s1, rid, off0=o0, off1=o1, max_n0=4000, max_n1=400).items()}
+    torch.cuda.synchronize()
+    assert int(full['status'].max().item()) == 0
+    names = ('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p') if tests_all else ('ks_d', 'ks_p')
+    for lo, cnt in ((0, 800), (P // 2, 800), (P - 800, 800)):
+        a = s0[int(off0[lo]):int(off0[lo + cnt])].cpu().numpy(); b = s1[int(off1[lo]):int(off1[lo + cnt])].cpu().numpy()
+        exp = oracle_c.detect_batch(a, off0[lo:lo + cnt + 1] - off0[lo], b, off1[lo:lo + cnt + 1] - off1[lo],
+                                    rid[lo:lo + cnt].cpu().numpy(), nb, 2.0, 'stouffer', tests=7 if tests_all else 1, threads=0)
+        _cmp_sample(full, exp, lo, cnt, nb, names)
+    for i in np.argsort(n0)[-8:]:
+        a = s0[int(off0[i]):int(off0[i + 1])].cpu().numpy(); b = s1[int(off1[i]):int(off1[i + 1])].cpu().numpy()
+        e = oracle_c.detect_batch(a, np.array([0, len(a)]), b, np.array([0, len(b)]), np.zeros(1, np.int32), 0, 2.0, 'ks',
+                                  tests=7 if tests_all else 1, threads=1)
+        assert abs(float(full['ks_d'][i].item()) - e['ks_d'][0]) <= 4.5e-16
+        if tests_all:
+            assert float(full['mwu_u'][i].item()) == e['mwu_u'][0]
+    # D, its p-value and U do not depend on which group is called the first
+    swapped = det.run(s1, s0, rid, off0=o1, off1=o0, max_n0=400, max_n1=4000)
+    torch.cuda.synchronize()
+    assert torch.equal(swapped['ks_d'], full['ks_d']) and torch.equal(swapped['ks_p'], full['ks_p'])
+    if tests_all:
+        assert torch.equal(swapped['mwu_u'], full['mwu_u'])
+

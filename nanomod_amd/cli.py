@@ -160,6 +160,7 @@ def load_input(path, a, log=print):
 
 
 def run_detect(a, log=print):
+    engine.warm_up(a.device)                                    # HIP start-up beside the loading of the inputs
     g0, g1 = load_input(a.wrkBase1, a, log), load_input(a.wrkBase2, a, log)
     t0 = time.time()
     meta, sig0, off0, sig1, off1, rid = select_positions(g0, g1, a.MinCoverage, a.outLevel, log)

@@ -364,6 +364,7 @@ def downsample_update(res, sig0, off0, sig1, off1, rid, strands, coverages, *, i
 
 def mtest2(moptions):
     print("Start sorting")
+    engine.warm_up(moptions.get('nmod_device', 0))          # the HIP start-up runs beside the host-side preparation
     meta, sig0, off0, sig1, off1, rid = build_csr(moptions)
     npos = len(meta['pos'])
     method = moptions['testMethod']

@@ -24,6 +24,33 @@ def _check_csr(off, npos, name):
         raise ValueError('%s must be int64[npos+1]' % name)
 
 
+_warm = {}
+
+
+def warm_up(device=0):
+    """Start the HIP runtime, the device context and the code object of the library on a background thread (about a
+    second in a fresh process) while the caller prepares its inputs on the host; detect_host joins it.  Idempotent."""
+    import threading
+    if device in _warm:
+        return _warm[device]
+
+    def run():
+        try:
+            L.load().nmod_selftest(int(device))          # a 64-thread kernel: forces context creation and module load
+        except Exception:                                # (errors surface in the real call, with their message)
+            pass
+    t = threading.Thread(target=run, name='nanomod-warm-up', daemon=True)
+    _warm[device] = t
+    t.start()
+    return t
+
+
+def _join_warm_up(device):
+    t = _warm.get(device)
+    if t is not None and t.is_alive():
+        t.join()
+
+
 def detect_host(sig0, off0, sig1, off1, run_id, *, nb=2, weights_dif=2.0, method='stouffer',
                 tests=L.TEST_ALL, want_mstd=False, device=0, stride0=0, stride1=0):
     """Run the hot path on host-resident CSR inputs; returns a dict of numpy arrays.
@@ -31,6 +58,7 @@ def detect_host(sig0, off0, sig1, off1, run_id, *, nb=2, weights_dif=2.0, method
     sig0/sig1: float32 (canonical), int16 (milli-units) or float64 1-D arrays; off0/off1:
     int64[npos+1] (or None with a fixed stride); run_id: int32[npos]."""
     lib = L.load()
+    _join_warm_up(device)
     sig0 = np.ascontiguousarray(sig0)
     sig1 = np.ascontiguousarray(sig1)
     if sig0.dtype != sig1.dtype or sig0.dtype not in (np.float32, np.int16, np.float64):

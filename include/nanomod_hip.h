@@ -193,6 +193,10 @@ int nmod_write_sign_test(const char* path, int64_t npos, const int32_t* chrom_id
                          const double* t_t, const double* t_p, const double* ks_d, const double* ks_p,
                          const double* comb_st, const double* comb_p, int32_t with_comb);
 
+/* Test hook for the table writer's number formats: v[i] formatted as '%.3f' (sci = 0) or '%.3E' (sci = 1) the way
+ * nmod_write_sign_test does, NUL-separated, into out (capacity cap bytes; at most 420 bytes per value). */
+int nmod_format_probe(const double* v, int64_t n, int32_t sci, char* out, int64_t cap);
+
 /* Replaces the ranking of the result records (myDetect.py:447-462): order_out[i] = index of the i-th record of
  * sorted(records, key = (key_primary, key_second, key_third)) — Python's stable tuple sort, ascending, -0.0 tied
  * with 0.0, NaN last — reversed as a whole when `descending` (rankUse == 'st': the reference reverses the sorted

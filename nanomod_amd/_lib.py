@@ -63,6 +63,7 @@ _SIGNATURES = {
     'nmod_evtimer_read': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     'nmod_evtimer_destroy': (C.c_int, [C.c_void_p]),
     'nmod_selftest': (C.c_int, [C.c_int32]),
+    'nmod_format_probe': (C.c_int, [C.POINTER(C.c_double), C.c_int64, C.c_int32, C.c_char_p, C.c_int64]),
     'nmod_trim_scratch': (C.c_int, [C.c_int32]),
     'nmod_describe_dispatch': (C.c_int, [C.POINTER(NmodParams), C.c_int64, C.c_int64, C.c_char_p, C.c_int32]),
     'nmod_write_sign_test': (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_void_p,

@@ -1018,17 +1018,81 @@ int nmod_evtimer_destroy(void* timer) {
 }
 
 // ---- save_test's table (myDetect.py:532-536), buffered
+// '%.3f' and '%.3E' exactly as printf (and Python) round them — the exact binary value, half to even — without going
+// through printf for every number (350 ns each: the table writer was the largest piece of a 4.6 M-position mtest2).
+// x87 extended precision carries 64 bits: |v| * 1000 is exact in it for every double below 2^63 / 1000, so '%.3f' is
+// decided exactly; '%.3E' scales by a power of ten (relative error ~2^-62) and hands every value whose fourth
+// significant digit is within 1e-7 of a rounding boundary to snprintf.
+#if !defined(__HIP_DEVICE_COMPILE__)                      // (host code; the device pass parses it with a 64-bit long double)
+static_assert(sizeof(long double) >= 10 && __LDBL_MANT_DIG__ >= 64, "the fast formats need a 64-bit significand");
+#endif
+static inline char* put_digits(char* p, unsigned long long v) {
+  char tmp[24]; int n = 0;
+  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+static inline char* put_3(char* p, unsigned v) { p[0] = (char)('0' + v / 100); p[1] = (char)('0' + v / 10 % 10); p[2] = (char)('0' + v % 10); return p + 3; }
 static inline char* put_f3(char* p, double v) {          // '%.3f' as Python formats it
   if (v != v) { memcpy(p, "nan", 3); return p + 3; }
   if (v == INFINITY) { memcpy(p, "inf", 3); return p + 3; }
   if (v == -INFINITY) { memcpy(p, "-inf", 4); return p + 4; }
-  return p + snprintf(p, 400, "%.3f", v);
+  const double a = fabs(v);
+  if (!(a < 9.0e15)) return p + snprintf(p, 400, "%.3f", v);
+  const long double x = (long double)a * 1000.0L;         // exact: 53 + 10 bits
+  unsigned long long d = (unsigned long long)x;           // truncation
+  const long double frac = x - (long double)d;            // exact
+  if (frac > 0.5L || (frac == 0.5L && (d & 1ull))) ++d;   // half to even on the exact value
+  if (signbit(v)) *p++ = '-';
+  p = put_digits(p, d / 1000);
+  *p++ = '.';
+  return put_3(p, (unsigned)(d % 1000));
 }
+struct Pow10Table {                                       // 10^i, i = -360 .. 360, as long double
+  long double v[721];
+  Pow10Table() { for (int i = 0; i <= 720; ++i) v[i] = powl(10.0L, (long double)(i - 360)); }
+  long double operator()(int i) const { return v[i + 360]; }
+};
 static inline char* put_e3(char* p, double v) {          // '%.3E'
+  static const Pow10Table pow10;
   if (v != v) { memcpy(p, "NAN", 3); return p + 3; }      // Python upper-cases non-finite values under %E
   if (v == INFINITY) { memcpy(p, "INF", 3); return p + 3; }
   if (v == -INFINITY) { memcpy(p, "-INF", 4); return p + 4; }
-  return p + snprintf(p, 64, "%.3E", v);
+  const double a = fabs(v);
+  if (a == 0.0) { if (signbit(v)) *p++ = '-'; memcpy(p, "0.000E+00", 9); return p + 9; }
+  int e2;
+  frexp(a, &e2);                                          // a = f * 2^e2, 0.5 <= f < 1
+  int k = (int)floor((e2 - 1) * 0.30102999566398120);     // floor(log10 a) or one less
+  long double x = (long double)a * pow10(3 - k);          // want 1000 <= x < 10000
+  if (x >= 10000.0L) { ++k; x = (long double)a * pow10(3 - k); }
+  else if (x < 1000.0L) { --k; x = (long double)a * pow10(3 - k); }
+  if (!(x >= 1000.0L && x < 10000.0L)) return p + snprintf(p, 64, "%.3E", v);
+  unsigned d = (unsigned)x;
+  const long double frac = x - (long double)d;
+  // (near a boundary of the fourth digit — or of the power of ten itself — the scaled value is not trusted)
+  if (fabsl(frac - 0.5L) < 1e-7L || frac < 1e-7L || frac > 1.0L - 1e-7L) return p + snprintf(p, 64, "%.3E", v);
+  if (frac > 0.5L) ++d;
+  if (d == 10000u) { d = 1000u; ++k; }
+  if (signbit(v)) *p++ = '-';
+  *p++ = (char)('0' + d / 1000); *p++ = '.';
+  p = put_3(p, d % 1000);
+  *p++ = 'E'; *p++ = k < 0 ? '-' : '+';
+  const unsigned ak = (unsigned)(k < 0 ? -k : k);
+  if (ak >= 100) { return put_3(p, ak); }
+  p[0] = (char)('0' + ak / 10); p[1] = (char)('0' + ak % 10);
+  return p + 2;
+}
+
+// test hook: the two formats on an array of values, NUL-separated (tests/test_abi_and_host.py compares with Python)
+extern "C" int nmod_format_probe(const double* v, int64_t n, int32_t sci, char* out, int64_t cap) {
+  if (!v || !out || n < 0) return NMOD_ERR_INVALID_ARG;
+  char* p = out;
+  for (int64_t i = 0; i < n; ++i) {
+    if (p - out + 420 > cap) return NMOD_ERR_INVALID_ARG;
+    p = sci ? put_e3(p, v[i]) : put_f3(p, v[i]);
+    *p++ = '\0';
+  }
+  return NMOD_OK;
 }
 
 int nmod_write_sign_test(const char* path, int64_t npos, const int32_t* chrom_id, const char* chrom_names,
@@ -1042,7 +1106,8 @@ int nmod_write_sign_test(const char* path, int64_t npos, const int32_t* chrom_id
   std::vector<const char*> names(n_chroms);
   size_t longest = 0;
   const char* q = chrom_names;
-  for (int i = 0; i < n_chroms; ++i) { names[i] = q; longest = std::max(longest, strlen(q)); q += strlen(q) + 1; }
+  std::vector<size_t> name_len(n_chroms);
+  for (int i = 0; i < n_chroms; ++i) { names[i] = q; name_len[i] = strlen(q); longest = std::max(longest, name_len[i]); q += name_len[i] + 1; }
   for (int64_t i = 0; i < npos; ++i) if (chrom_id[i] < 0 || chrom_id[i] >= n_chroms) return NMOD_ERR_INVALID_ARG;
   FILE* f = fopen(path, "w");
   if (!f) return NMOD_ERR_INVALID_ARG;
@@ -1054,7 +1119,19 @@ int nmod_write_sign_test(const char* path, int64_t npos, const int32_t* chrom_id
     std::vector<char> line(line_cap);
     for (int64_t i = lo; i < hi; ++i) {
       char* p = line.data();
-      p += snprintf(p, longest + 128, "%s %c %lld %c %d %d ", names[chrom_id[i]], strand[i], (long long)(pos0[i] + 1), base[i], n0[i], n1[i]);
+      {                                                       // "%s %c %lld %c %d %d "
+        const char* nm = names[chrom_id[i]];
+        const size_t ln = name_len[chrom_id[i]];
+        memcpy(p, nm, ln); p += ln;
+        *p++ = ' '; *p++ = strand[i]; *p++ = ' ';
+        const long long ps = (long long)(pos0[i] + 1);
+        if (ps < 0) { *p++ = '-'; p = put_digits(p, 0ull - (unsigned long long)ps); } else p = put_digits(p, (unsigned long long)ps);
+        *p++ = ' '; *p++ = base[i]; *p++ = ' ';
+        if (n0[i] < 0) { *p++ = '-'; p = put_digits(p, (unsigned long long)(-(long long)n0[i])); } else p = put_digits(p, (unsigned long long)n0[i]);
+        *p++ = ' ';
+        if (n1[i] < 0) { *p++ = '-'; p = put_digits(p, (unsigned long long)(-(long long)n1[i])); } else p = put_digits(p, (unsigned long long)n1[i]);
+        *p++ = ' ';
+      }
       p = put_f3(p, mwu_u[i]); *p++ = ' '; p = put_e3(p, mwu_p[i]); *p++ = ' ';
       p = put_f3(p, t_t[i]); *p++ = ' '; p = put_e3(p, t_p[i]); *p++ = ' ';
       p = put_f3(p, ks_d[i]); *p++ = ' '; p = put_e3(p, ks_p[i]);

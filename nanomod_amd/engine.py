@@ -153,6 +153,21 @@ def region_rank_host(strand_lo, strand_hi, pos, base, value, w, movesize, na, pe
     return out[:cnt.value]
 
 
+def _first_chars(a):
+    """the first character of every element (a blank for an empty one) as one bytes object, without a Python loop"""
+    u = np.asarray(a)
+    if u.dtype.kind != 'U':
+        u = u.astype('U1') if u.dtype.kind in 'SO' or u.size == 0 else np.array([str(x) for x in u.tolist()], dtype='U1')
+    elif u.dtype.itemsize != 4:
+        u = u.astype('U1')
+    codes = np.ascontiguousarray(u).view(np.uint32)
+    if codes.size and int(codes.max()) > 127:                      # non-ASCII: the slow, general way
+        return ''.join(str(x)[:1] or ' ' for x in np.asarray(a).tolist()).encode()
+    c = codes.astype(np.uint8)
+    c[c == 0] = 32
+    return c.tobytes()
+
+
 def write_sign_test_host(path, meta, res, with_comb):
     """save_test's table (myDetect.py:522-538) through nmod_write_sign_test.  meta: arrays chrom_id (int32), pos
     (int64, 0-based), strand / base (one character each), n0 / n1 (int32) + the list `names` that chrom_id indexes."""
@@ -161,8 +176,8 @@ def write_sign_test_host(path, meta, res, with_comb):
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     cid = np.ascontiguousarray(meta['chrom_id'], dtype=np.int32)
     names = b''.join(str(n).encode() + b'\0' for n in meta['names'])
-    strand = ''.join(str(x)[:1] or ' ' for x in meta['strand'].tolist()).encode()
-    base = ''.join(str(b)[:1] or ' ' for b in meta['base'].tolist()).encode()
+    strand = _first_chars(meta['strand'])
+    base = _first_chars(meta['base'])
     pos = np.ascontiguousarray(meta['pos'], dtype=np.int64)
     n0 = np.ascontiguousarray(meta['n0'], dtype=np.int32); n1 = np.ascontiguousarray(meta['n1'], dtype=np.int32)
     cols = [np.ascontiguousarray(res[k], dtype=np.float64) for k in ('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p')]

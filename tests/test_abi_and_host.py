@@ -217,3 +217,36 @@ def test_fast5_ingest_matches_reference_reader():
     assert not fast5_ingest.read_passes_filters(100, 'c', 0, '+', {'min_lr': 500}, log=lambda *a: None)
     assert fast5_ingest.read_passes_filters(600, 'c', 0, '+', {'min_lr': 500, 'Chr': 'c'})
     assert not fast5_ingest.read_passes_filters(600, 'c', 0, '+', {'min_lr': 500, 'Chr': 'd'})
+
+
+def test_table_number_formats_equal_printf():
+    """the table writer formats '%.3f' and '%.3E' itself (exact x87 arithmetic, snprintf for values near a rounding
+    boundary): byte-identical to Python's formatting on boundary cases, halves, subnormals, random bit patterns"""
+    import ctypes as C
+    from nanomod_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(20241002)
+    cases = [0.0, -0.0, 1.0, -1.0, 0.0005, 0.0015, 0.0025, 1.0005, 2.5, 12345.0, 1234.5, 0.5, 1e-300, 5e-324,
+             2.2250738585072014e-308, 1.7976931348623157e308, 9.9995, 9.99949999, 99995.0, 999.95, 0.00099995, 1e15, 9e15,
+             8.9999999e15, 1e16, 123456789.0005, 29750.5, 0.125, 0.0625, 1e-5, 9.9999e-5, 1e100, 1e-100, 4.35e-7,
+             1.2345e-200, 9.9995e+99, 9.9995e-100, 1.0e23, 5e22, 9.9994999999999994e-05, 999949999.9999999, 0.9995, 0.99949999999999994]
+    vals = np.array(cases + list(rng.normal(0, 100, 20000)) + list(10.0 ** rng.uniform(-320, 308, 20000))
+                    + list(rng.integers(0, 10 ** 7, 20000) / 1000.0) + list(rng.integers(0, 10 ** 7, 20000) / 2000.0)
+                    + list((rng.integers(10000, 100000, 20000) * 10.0 ** rng.integers(-200, 200, 20000)) / 2.0)
+                    + list(np.frombuffer(rng.bytes(8 * 40000), dtype=np.float64)))
+    vals = np.ascontiguousarray(vals[np.isfinite(vals)])
+    for sci, fmt in ((0, '%.3f'), (1, '%.3E')):
+        for lo in range(0, len(vals), 20000):
+            v = np.ascontiguousarray(vals[lo:lo + 20000])
+            buf = C.create_string_buffer(len(v) * 420 + 16)
+            assert lib.nmod_format_probe(v.ctypes.data_as(C.POINTER(C.c_double)), len(v), sci, buf, len(buf)) == 0
+            got = buf.raw.split(b'\0')[:len(v)]
+            exp = [(fmt % x).encode() for x in v.tolist()]
+            assert got == exp, [(x, g, e) for x, g, e in zip(v.tolist(), got, exp) if g != e][:5]
+    special = np.array([np.nan, np.inf, -np.inf])
+    buf = C.create_string_buffer(2000)
+    assert lib.nmod_format_probe(special.ctypes.data_as(C.POINTER(C.c_double)), 3, 0, buf, 2000) == 0
+    assert buf.raw.split(b'\0')[:3] == [b'nan', b'inf', b'-inf']
+    assert lib.nmod_format_probe(special.ctypes.data_as(C.POINTER(C.c_double)), 3, 1, buf, 2000) == 0
+    assert buf.raw.split(b'\0')[:3] == [b'NAN', b'INF', b'-INF']
+

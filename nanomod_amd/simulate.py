@@ -121,19 +121,21 @@ def get_top_rank(chrom, strand, pos, order, run_id, nb, window, region_rank=Fals
     if best_pos > -1000000:
         best_pos = -1000000
     n = len(pos)
-    accepted = {}                                      # (chrom, strand) -> accepted positions
-    curn = 0
+    blocked = {}                                       # (chrom, strand) -> positions closer than closesize to an accepted one
+    curn = 0                                           # (the reference compares with every accepted record: quadratic)
     for i in order:
         i = int(i)
         cs = (chrom[i], strand[i])
         p = int(pos[i])
-        prev = accepted.get(cs)
-        if prev is not None and any(abs(q - p) < closesize for q in prev):
+        near = blocked.get(cs)
+        if near is not None and p in near:
             continue
         lo, hi = i - window, i + window
         if lo < 0 or hi > n - 1 or run_id[lo] != run_id[i] or run_id[hi] != run_id[i]:
             continue                                   # some neighbour is not a consecutive position: not enough
-        accepted.setdefault(cs, []).append(p)
+        if near is None:
+            near = blocked[cs] = set()
+        near.update(range(p - closesize + 1, p + closesize))
         curn += 1
         if cs == (t_chr, t_strand) and abs(best_pos - t_pos) > abs(p - t_pos) and abs(p - t_pos) < closesize:
             return curn

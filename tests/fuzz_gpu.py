@@ -23,8 +23,8 @@ for it in range(rounds):
     hi1 = int(rng.choice([3, 8, 40, 64, 65, 130, 260, 600, 1100, 2048, 2500, 9000]))
     lo0 = int(rng.integers(1, hi0 + 1)) if rng.random() < 0.5 else 1
     lo1 = int(rng.integers(1, hi1 + 1)) if rng.random() < 0.5 else 1
-    npos = int(rng.integers(1, 400 if max(hi0, hi1) <= 600 else 40))
-    mode = rng.choice(['cont', 'grid2', 'grid0', 'i16'])
+    mode = rng.choice(['cont', 'grid2', 'grid0', 'i16', 'f64', 'f64near'])
+    npos = int(rng.integers(1, (400 if max(hi0, hi1) <= 600 else 40) // (4 if mode.startswith('f64') else 1) + 1))
     n0 = rng.integers(lo0, hi0 + 1, npos); n1 = rng.integers(lo1, hi1 + 1, npos)
     off0 = np.zeros(npos + 1, np.int64); off0[1:] = np.cumsum(n0)
     off1 = np.zeros(npos + 1, np.int64); off1[1:] = np.cumsum(n1)
@@ -36,11 +36,23 @@ for it in range(rounds):
     if mode == 'i16':
         s0 = np.round(a * 1000).astype(np.int16); s1 = np.round(b * 1000).astype(np.int16)
         r0, r1 = s0.astype(np.float64) / 1000, s1.astype(np.float64) / 1000
+    elif mode in ('f64', 'f64near'):
+        # float64 input: arbitrary doubles; 'f64near' plants doubles that differ below float32 resolution and exact copies
+        s0 = a.copy(); s1 = b.copy()
+        if mode == 'f64near':
+            k = min(len(s0), len(s1)) // 2
+            idx = rng.integers(0, len(s0), k)
+            s1[:k] = s0[idx] * (1.0 + rng.choice([0.0, 2.0 ** -30, -2.0 ** -40], k))
+        r0, r1 = s0, s1
     else:
         s0 = a.astype(np.float32); s1 = b.astype(np.float32); r0, r1 = s0, s1
     rid = np.cumsum(rng.random(npos) < 0.1).astype(np.int32)
     nb = int(rng.integers(0, 4)); method = str(rng.choice(['stouffer', 'fisher']))
-    exp = oracle_c.detect_batch(s0, off0, s1, off1, rid, nb, 2.0, method, threads=0)
+    if s0.dtype == np.float64:                # the C oracle takes float32 / int16: the numpy restatement on the doubles
+        import nanomod_oracle as orc
+        exp = orc.detect_batch(r0, off0, r1, off1, rid, nb, 2.0, orc.METHOD_STOUFFER if method == 'stouffer' else orc.METHOD_FISHER)
+    else:
+        exp = oracle_c.detect_batch(s0, off0, s1, off1, rid, nb, 2.0, method, threads=0)
     got = nm.detect_host(s0, off0, s1, off1, rid, nb=nb, weights_dif=2.0, method=method)
     ident = (exp['status'] & 1) != 0          # MWU all identical: U / p NaN on both sides
     assert np.all(np.isnan(got['mwu_u'][ident])) and np.all(np.isnan(exp['mwu_u'][ident]))

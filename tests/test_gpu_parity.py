@@ -384,7 +384,7 @@ def test_ks_only_large_ranked_group(nm):
         assert abs(got['ks_d'][i] - d) <= 4.5e-16 and abs(got['ks_p'][i] - max(p, orc.DBL_MIN)) <= 1e-9 * max(p, orc.DBL_MIN), i
 
 
-@pytest.mark.parametrize('mode', ['cont', 'grid1', 'const', 'i16'])
+@pytest.mark.parametrize('mode', ['cont', 'grid1', 'const', 'i16', 'f64', 'f64ties'])
 def test_unequal_classes_streamed_larger_group(nm, mode):
     """positions whose groups fall in different capacity classes with the smaller one <= 256 samples: the WIDE form of
     rank_hist_kernel (smaller group sorted, larger one streamed and counted in a per-wave hash table), the larger group up
@@ -411,6 +411,16 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
     if mode == 'i16':
         sig0 = np.round(np.concatenate(ca) * 1000).astype(np.int16); sig1 = np.round(np.concatenate(cb) * 1000).astype(np.int16)
         r0, r1 = sig0.astype(np.float64) / 1000, sig1.astype(np.float64) / 1000
+    elif mode.startswith('f64'):
+        # arbitrary doubles (neither float32-exact nor on the 0.001 grid): the float64 front end ranks rounded float32
+        # images and redoes the positions whose images tie; 'f64ties': pairs of doubles one ulp of float32 apart (their
+        # images tie, the doubles do not) and exact duplicates across the groups
+        sig0 = np.concatenate(ca); sig1 = np.concatenate(cb)
+        if mode == 'f64ties':
+            k = min(len(sig0), len(sig1)) // 3
+            sig1[:k] = sig0[:k] * (1.0 + 2.0 ** -30)
+            sig1[k:2 * k:7] = sig0[k:2 * k:7]
+        r0, r1 = sig0, sig1
     else:
         sig0 = np.concatenate(ca).astype(np.float32); sig1 = np.concatenate(cb).astype(np.float32); r0, r1 = sig0, sig1
     got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=1, weights_dif=2.0, method='fisher')

@@ -132,7 +132,7 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
     if (e != hipSuccess) return e;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * kWavesPerBlock, lds);
     if (e != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
+    if (per_cu < 1) return hipErrorLaunchOutOfResources;     // (never launch a block that cannot get its LDS: its table walks would not end)
     if (cacheable) per_cu_cache[dev][slot_id].store(per_cu, std::memory_order_relaxed);
   }
   int64_t blocks = (work_items + kWavesPerBlock - 1) / kWavesPerBlock;

@@ -83,9 +83,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
       double t = nan, pv = nan;
       if (!empty) {
         // ttest_ind(equal_var=False): _unequal_var_ttest_denom + _ttest_finish
-        double v1 = m20 / (dn0 - 1.0), v2 = m21 / (dn1 - 1.0);
-        double vn1 = v1 / dn0, vn2 = v2 / dn1;
-        double df = (vn1 + vn2) * (vn1 + vn2) / (vn1 * vn1 / (dn0 - 1.0) + vn2 * vn2 / (dn1 - 1.0));
+        // (vn = var / n with one division each, df with one: the products of the small integers are exact)
+        const double e0 = dn0 - 1.0, e1 = dn1 - 1.0;
+        double vn1 = m20 / (e0 * dn0), vn2 = m21 / (e1 * dn1);
+        double df = (vn1 + vn2) * (vn1 + vn2) * (e0 * e1) / (vn1 * vn1 * e1 + vn2 * vn2 * e0);
         if (df != df) df = 1.0;
         double denom = sqrt(vn1 + vn2);
         t = (mean0 - mean1) / denom;

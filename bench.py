@@ -1,34 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py --gpus N --steps K --warmup W
+"""bench.py --gpus N --steps K --warmup W [--config ecoli|alltests|chr20|ragged]
 
 One "step" = one pass of the hot path over this job's synthetic genome: K1 rank statistics + K2
 p-values + K3 window combine on every rank's positions and — for N > 1 — the RCCL all-gather that
 reassembles the per-base KS-p and combined-p tracks on every rank (BASELINE.json north_star).
 Inputs are resident in HBM when the timed region starts.
 
-Workload at N=1: BASELINE.json configs[1] — E. coli 4.6 Mb, 200 v 200 reads/position, KS + weighted
-Stouffer (window 5), float32 signals.  N > 1, weak scaling (default): an N x 4.6 M position genome,
-4.6 M positions per rank; --strong: 4.6 M positions in total.  Positions are dealt block-cyclic
-(nanomod_amd/sharding.py: `chunks` rounds of N equal blocks, each block with a +-nb halo of recomputed
-neighbours), so the all-gather of round c lands as one contiguous piece of the full track and runs on
-RCCL's stream beside the kernels of round c+1.  Two figures are timed: `value` = kernels + all-gather
+Workloads (`--config`, BASELINE.json configs[1..4]; per GPU, weak scaling by default):
+  ecoli     configs[1]  4.6 M positions x 200 v 200 reads, KS + weighted Stouffer window 5    (the headline, default)
+  alltests  configs[2]  the same input, KS + Mann-Whitney + Welch-t + Fisher
+  chr20     configs[3]  8 M positions x 500 v 500 reads per GPU (64 M over 8 GPUs), KS + Stouffer
+  ragged    configs[4]  10 M positions, n0 ~ LogNormal(ln 1000, 0.5) in [5, 4000], n1 ~ LogNormal(ln 50, 0.5) in [5, 400], CSR
+`--all-tests` switches any of them to the three tests + Fisher; `--dtype i16` to int16 milli-unit samples;
+`--ties real` to signals on the 3-decimal grid of real NanoMod events (≈11 ties between the groups per position).
+
+N > 1: `python3 bench.py --gpus N` starts its own N ranks (one fresh child process per GPU through
+torch.distributed.run, before this process has touched a GPU); under an external launcher (WORLD_SIZE set) it is a
+rank.  Positions are dealt block-cyclic (nanomod_amd/sharding.py: `chunks` rounds of N equal blocks, each block with
+a +-nb halo of recomputed neighbours), so the all-gather of round c lands as one contiguous piece of the full track
+and runs on RCCL's stream beside the kernels of round c+1.  Two figures are timed: `value` = kernels + all-gather
 (for N=1 there is nothing to gather), and `compute_only` = the kernels alone.
 
-Before the warm-up one untimed pass is checked against the CPU oracle (the C restatement) on a bounded
-sample of the same input; the result goes into `verify`.  The oracle is also the `cpu_baseline`.
-Prints ONE JSON line on rank 0.
+Before the warm-up one untimed pass is checked against the CPU oracle (the C restatement) on a bounded sample of the
+same input; the result goes into `verify`, and a failed verification makes the exit code non-zero.  The oracle is
+also the `cpu_baseline`.  Prints ONE JSON line (the last line of stdout) on rank 0.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-P_ECOLI = 4_600_000
 NB = 2
 WDIF = 2.0
 SEED = 20240601
@@ -36,12 +44,25 @@ PLANT_PERIOD = 10000
 PLANT_SHIFT = 0.8
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GUIDE_GBS = 6290.0    # same guide: measured float4 copy
+KS_D_ABS = 4.5e-16             # gate on D (tests/helpers.py)
+
+PRESETS = {
+    'ecoli': dict(positions=4_600_000, n0=200, n1=200, all_tests=False, layout='stride',
+                  name='BASELINE.json configs[1]: E. coli 4.6 Mb'),
+    'alltests': dict(positions=4_600_000, n0=200, n1=200, all_tests=True, layout='stride',
+                     name='BASELINE.json configs[2]: E. coli 4.6 Mb, all three tests'),
+    'chr20': dict(positions=8_000_000, n0=500, n1=500, all_tests=False, layout='stride',
+                  name='BASELINE.json configs[3]: human chr20 64 Mb over 8 GPUs = 8 M positions per GPU'),
+    'ragged': dict(positions=10_000_000, n0=1000, n1=50, all_tests=False, layout='csr',
+                   name='BASELINE.json configs[4]: skewed ragged coverage, 10 Mb'),
+}
+RAGGED_CLIP0, RAGGED_CLIP1 = (5, 4000), (5, 400)
 
 
-def algorithmic_bytes(n0, n1, sample_bytes, k_out):
-    """s*(n0+n1) [samples] + 16 [CSR offsets; 0 for the fixed-stride layout used here] + 4 [run id]
+def algorithmic_bytes(n0, n1, sample_bytes, k_out, csr):
+    """s*(n0+n1) [samples] + 16 [CSR offsets; 0 for the fixed-stride layout] + 4 [run id]
     + 16*k_out [(stat, p) fp64 pairs written] + 8 [own-p re-read by the combine]."""
-    return sample_bytes * (n0 + n1) + 0 + 4 + 16 * k_out + 8
+    return sample_bytes * (n0 + n1) + (16 if csr else 0) + 4 + 16 * k_out + 8
 
 
 def usable_cpus():
@@ -65,46 +86,70 @@ def cpu_model():
     return 'unknown'
 
 
-def oracle_run(a, b, npos, n0, n1, method, tests, threads):
-    """The checker: oracle/nanomod_oracle.c on the first `npos` rows of a, b.  Returns (outputs, seconds)."""
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def ragged_sizes(seed, pos_begin, npos, group):
+    """Group sizes of configs[4] as a function of the GLOBAL position (every rank derives the same sizes for a halo
+    position): counter-based uniforms -> Box-Muller -> round(LogNormal(ln mu, 0.5)) clipped."""
+    import numpy as np
+    mu, (lo, hi) = ((1000.0, RAGGED_CLIP0), (50.0, RAGGED_CLIP1))[group]
+    with np.errstate(over='ignore'):
+        x = (np.arange(npos, dtype=np.uint64) + np.uint64(pos_begin)) * np.uint64(2) + np.uint64(group)
+        x = x * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    u1 = ((x >> np.uint64(40)).astype(np.float64) + 0.5) / float(1 << 24)
+    u2 = ((x & np.uint64(0xffffff)).astype(np.float64) + 0.5) / float(1 << 24)
+    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return np.clip(np.rint(mu * np.exp(0.5 * z)), lo, hi).astype(np.int64)
+
+
+def oracle_run(a, off0, b, off1, npos, method, tests, threads):
+    """The checker: oracle/nanomod_oracle.c on the first `npos` rows (CSR views of a, b).  Returns (outputs, seconds)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import numpy as np
     import oracle_c
-    off0 = np.arange(0, (npos + 1) * n0, n0, dtype=np.int64)
-    off1 = np.arange(0, (npos + 1) * n1, n1, dtype=np.int64)
     t0 = time.perf_counter()
-    out = oracle_c.detect_batch(a[:npos].reshape(-1), off0, b[:npos].reshape(-1), off1, np.zeros(npos, np.int32),
+    out = oracle_c.detect_batch(a[:off0[npos]], off0[:npos + 1], b[:off1[npos]], off1[:npos + 1], np.zeros(npos, np.int32),
                                 NB, WDIF, method, tests=tests, threads=threads)
     return out, time.perf_counter() - t0
 
 
-def cpu_baseline(a, b, n0, n1, method, tests, threads, target_seconds=12.0):
+def cpu_baseline(rows, what, method, tests, threads, target_seconds=12.0):
     """The oracle timed on this box's host cores on a bounded sample of the same workload (the first rows of rank 0's
     device-resident input, copied back): all usable cores, and one core."""
     import numpy as np
-    cap = a.shape[0]
-    oracle_run(a, b, min(2000, cap), n0, n1, method, tests, threads)                 # thread-pool warm-up
+    a, off0, b, off1 = rows
+    cap = len(off0) - 1
+    oracle_run(a, off0, b, off1, min(2000, cap), method, tests, threads)                 # thread-pool warm-up
     probe = min(20000, cap)
-    rate = probe / oracle_run(a, b, probe, n0, n1, method, tests, threads)[1]
+    rate = probe / oracle_run(a, off0, b, off1, probe, method, tests, threads)[1]
     sample = int(min(cap, max(probe, rate * target_seconds)))
     reps = max(1, int(round(rate * target_seconds / sample)))
-    dt = sum(oracle_run(a, b, sample, n0, n1, method, tests, threads)[1] for _ in range(reps))
+    dt = sum(oracle_run(a, off0, b, off1, sample, method, tests, threads)[1] for _ in range(reps))
     one = int(min(cap, max(2000, rate / max(threads, 1) * 4.0)))                      # ~4 s on one core
-    dt1 = oracle_run(a, b, one, n0, n1, method, tests, 1)[1]
+    dt1 = oracle_run(a, off0, b, off1, one, method, tests, 1)[1]
     # the reference's own shape of the computation — one scipy-style call sequence per position in Python, one core,
     # all three tests as getKStest always computes them (SURVEY.md §8d) — on a small sample, for scale
     import nanomod_oracle as orc
     npy = min(300, cap)
     scale = 1e-3 if a.dtype == np.int16 else 1.0
     t0 = time.perf_counter()
-    ksp = [orc.getKStest(a[i].astype(np.float64) * scale, b[i].astype(np.float64) * scale)[2][1] for i in range(npy)]
+    ksp = [orc.getKStest(a[off0[i]:off0[i + 1]].astype(np.float64) * scale, b[off1[i]:off1[i + 1]].astype(np.float64) * scale)[2][1]
+           for i in range(npy)]
     orc.combine_track(np.zeros(npy), np.array(ksp), np.zeros(npy, np.int32), NB, WDIF,
                       orc.METHOD_STOUFFER if method == 'stouffer' else orc.METHOD_FISHER)
     dpy = time.perf_counter() - t0
-    what = 'all three tests + Fisher' if tests == 7 else 'KS + Stouffer window 5'
     return {'value': sample * reps / dt, 'unit': 'positions/s', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model(),
-            'sample': 'first %d positions of the same workload (%d v %d, %s) x %d passes, oracle/nanomod_oracle.c '
-                      'with OpenMP on %d threads (cgroup CPU quota), %.1f s' % (sample, n0, n1, what, reps, threads, dt),
+            'sample': 'first %d positions of the same workload (%s) x %d passes, oracle/nanomod_oracle.c '
+                      'with OpenMP on %d threads (cgroup CPU quota), %.1f s' % (sample, what, reps, threads, dt),
             'one_core': {'value': one / dt1, 'unit': 'positions/s', 'cores': 1,
                          'sample': 'first %d positions, same library, 1 thread, %.1f s' % (one, dt1)},
             'reference_shaped_python': {'value': npy / dpy, 'unit': 'positions/s', 'cores': 1,
@@ -112,18 +157,45 @@ def cpu_baseline(a, b, n0, n1, method, tests, threads, target_seconds=12.0):
                                                   'positions (the reference computes MWU, Welch and KS for every position)' % npy}}
 
 
-def measured_traffic(lib_path, key):
-    """HBM bytes per K1 launch from a rocprofv3 PMC run (tools/pmc_traffic.py writes profiles/traffic.json), used only
-    if it was taken with the library binary that is running now."""
+def profile_record(lib_path, key):
+    """Counters of this workload's K1 kernel from a rocprofv3 PMC run of THIS library binary (tools/profile_round.py
+    writes profiles/traffic.json keyed by workload + library sha): HBM bytes per launch, VALU instructions per position,
+    VALU issue utilisation.  None for a binary that has not been profiled."""
     try:
         sha = hashlib.sha256(open(lib_path, 'rb').read()).hexdigest()[:16]
         rec = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
         ent = rec.get(key)
         if ent and ent.get('lib_sha16') == sha:
-            return ent['hbm_bytes_per_launch'], ent.get('source')
+            return ent
     except Exception:
         pass
-    return None, None
+    return None
+
+
+def launch_ranks(args, argv):
+    """N > 1 without an external launcher: one fresh child process per GPU.  This process has not imported torch.cuda
+    or loaded the HIP library; it only forwards the children's output (rank 0's JSON line last) and their failure."""
+    port = free_port()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    last_json = None
+    for ln in proc.stdout:
+        ln = ln.rstrip('\n')
+        if ln.startswith('{') and ln.endswith('}'):
+            if last_json is not None:
+                print(last_json, flush=True)
+            last_json = ln
+        else:
+            print(ln, flush=True)
+    rc = proc.wait()
+    if last_json is not None:
+        print(last_json, flush=True)
+    if rc != 0:
+        print('bench.py: a rank failed (torch.distributed.run exit code %d); nothing is retried' % rc, file=sys.stderr)
+    return rc if rc != 0 else (0 if last_json is not None else 1)
 
 
 def main():
@@ -131,17 +203,35 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--positions', type=int, default=P_ECOLI, help='positions per GPU (weak) or in total (--strong)')
-    ap.add_argument('--n0', type=int, default=200)
-    ap.add_argument('--n1', type=int, default=200)
+    ap.add_argument('--config', choices=sorted(PRESETS), default='ecoli', help='BASELINE.json configs[1..4]')
+    ap.add_argument('--positions', type=int, default=0, help='positions per GPU (weak) or in total (--strong); default: the preset\'s')
+    ap.add_argument('--n0', type=int, default=0, help='reads per position, group 1 (default: the preset\'s; ragged: the median)')
+    ap.add_argument('--n1', type=int, default=0)
     ap.add_argument('--dtype', choices=('f32', 'i16'), default='f32', help='sample dtype in HBM (i16 = milli-units)')
-    ap.add_argument('--all-tests', action='store_true', help='BASELINE.json configs[2]: KS + MWU + Welch-t + Fisher (not the headline metric)')
+    ap.add_argument('--all-tests', action='store_true', help='KS + MWU + Welch-t + Fisher instead of the preset\'s tests')
+    ap.add_argument('--ties', choices=('few', 'real'), default='few',
+                    help='real: signals on the 3-decimal grid of NanoMod events (myRefBaseSignalAnnotation.py:1108)')
     ap.add_argument('--strong', action='store_true', help='fixed total size: --positions in total, split over the ranks')
     ap.add_argument('--chunks', type=int, default=0, help='rounds of the block-cyclic pipeline (default 4 for N>1, 1 for N=1)')
     ap.add_argument('--force-collective', action='store_true', help='N=1: initialise RCCL with one rank and issue the all-gather anyway')
     ap.add_argument('--cpu-sample', type=int, default=0, help='cap on positions for the CPU baseline / verification (0 = 1 M)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline (the verification still runs)')
+    ap.add_argument('--no-real-ties', action='store_true', help='skip the second, tie-heavy measurement of the default run')
+    ap.add_argument('--launch-only', action='store_true', help='ranks print RANK / WORLD_SIZE and exit before any GPU call (launcher test)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
+    if args.launch_only:
+        print(json.dumps({'launch_only': True, 'rank': rank, 'local_rank': local_rank, 'world_size': world,
+                          'master': '%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'))}), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -149,11 +239,6 @@ def main():
     from nanomod_amd import sharding
     L = nm._lib
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        raise SystemExit('WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run' % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
     dist = None
@@ -161,40 +246,73 @@ def main():
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('MASTER_PORT', str(free_port()))
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))   # "nccl" = RCCL on ROCm
     gather = dist is not None
 
-    n0, n1 = args.n0, args.n1
+    preset = PRESETS[args.config]
+    csr = preset['layout'] == 'csr'
+    all_tests = bool(args.all_tests or preset['all_tests'])
+    n0, n1 = args.n0 or preset['n0'], args.n1 or preset['n1']
+    positions = args.positions or preset['positions']
     tdtype = torch.float32 if args.dtype == 'f32' else torch.int16
     sample_bytes = 4 if args.dtype == 'f32' else 2
     chunks = args.chunks or (4 if world > 1 else 1)
-    total = args.positions if args.strong else args.positions * world
+    total = positions if args.strong else positions * world
     B = sharding.cyclic_block_len(total, world, chunks)
     total = B * world * chunks                     # the synthetic genome is padded to whole blocks
-    method = 'fisher' if args.all_tests else 'stouffer'
-    tests = L.TEST_ALL if args.all_tests else L.TEST_KS
+    method = 'fisher' if all_tests else 'stouffer'
+    tests = L.TEST_ALL if all_tests else L.TEST_KS
     det = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests)
 
-    # this rank's blocks (+ halo), generated on the device from global position counters
+    def fill(b, ties):
+        """(re)generate a block's samples on the device from global position counters.  ties == 'real': the int16
+        milli-unit grid (float32 input: k / 1000 as float32 — equal k <=> equal value)."""
+        for g, key in ((0, 'sig0'), (1, 'sig1')):
+            dst = b[key]
+            grid = ties == 'real' and dst.dtype == torch.float32
+            tgt = torch.empty(dst.numel(), dtype=torch.int16, device=dev) if grid else dst
+            if csr:
+                det.synth_fill_csr(tgt, SEED, b['lo_h'], b['off%d' % g], g, PLANT_PERIOD, PLANT_SHIFT)
+            else:
+                det.synth_fill(tgt, SEED, b['lo_h'], b['n'], g, (n0, n1)[g], PLANT_PERIOD, PLANT_SHIFT)
+            if grid:
+                step = 1 << 28
+                for lo in range(0, dst.numel(), step):
+                    dst[lo:lo + step] = tgt[lo:lo + step].to(torch.float32) / 1000.0
+                del tgt
+
+    # this rank's blocks (+ halo)
     blocks = []
     for c in range(chunks):
         lo, hi = sharding.cyclic_block(total, world, rank, chunks, c)
         lo_h, hi_h = sharding.halo_bounds(lo, hi, NB, total)
         n = hi_h - lo_h
-        s0 = torch.empty(n * n0, dtype=tdtype, device=dev)
-        s1 = torch.empty(n * n1, dtype=tdtype, device=dev)
-        det.synth_fill(s0, SEED, lo_h, n, 0, n0, PLANT_PERIOD, PLANT_SHIFT)
-        det.synth_fill(s1, SEED, lo_h, n, 1, n1, PLANT_PERIOD, PLANT_SHIFT)
-        blocks.append({'lo_h': lo_h, 'hi_h': hi_h, 'n': n, 'sig0': s0, 'sig1': s1,
-                       'rid': torch.zeros(n, dtype=torch.int32, device=dev),       # one contiguous run
-                       'out': det.alloc_outputs(n)})
-    n_local = sum(b['hi_h'] - b['lo_h'] for b in blocks)
+        b = {'lo_h': lo_h, 'hi_h': hi_h, 'n': n, 'rid': torch.zeros(n, dtype=torch.int32, device=dev),   # one contiguous run
+             'out': det.alloc_outputs(n)}
+        if csr:
+            for g in (0, 1):
+                sz = ragged_sizes(SEED, lo_h, n, g)
+                off = np.zeros(n + 1, np.int64)
+                np.cumsum(sz, out=off[1:])
+                b['hoff%d' % g] = off
+                b['off%d' % g] = torch.from_numpy(off).to(dev)
+                b['sig%d' % g] = torch.empty(int(off[-1]), dtype=tdtype, device=dev)
+        else:
+            b['sig0'] = torch.empty(n * n0, dtype=tdtype, device=dev)
+            b['sig1'] = torch.empty(n * n1, dtype=tdtype, device=dev)
+        fill(b, args.ties)
+        blocks.append(b)
+    n_local = sum(b['n'] for b in blocks)
+    samples_local = sum(b['sig0'].numel() + b['sig1'].numel() for b in blocks)
     state = sharding.PipelinedGather(total, world, chunks, ('ks_p', 'comb_p'), dev)
 
     def compute(c, lo_h, hi_h):
         b = blocks[c]
         assert (lo_h, hi_h) == (b['lo_h'], b['hi_h'])
+        if csr:
+            return det.run(b['sig0'], b['sig1'], b['rid'], off0=b['off0'], off1=b['off1'], max_n0=RAGGED_CLIP0[1],
+                           max_n1=RAGGED_CLIP1[1], out=b['out'])
         return det.run(b['sig0'], b['sig1'], b['rid'], stride0=n0, stride1=n1, npos=b['n'], out=b['out'])
 
     def step(with_gather):
@@ -219,21 +337,21 @@ def main():
             el = float(t.item())
         return el
 
-    # ---- one untimed pass, checked on rank 0 against the CPU oracle on a bounded sample of the same input
-    step(gather)
-    state.wait()
-    torch.cuda.synchronize()
-    verify = None
-    cpu_rows = None
-    if rank == 0:
-        cap = min(args.cpu_sample or 1_000_000, blocks[0]['n'])
-        a = blocks[0]['sig0'][:cap * n0].cpu().numpy().reshape(cap, n0)
-        b = blocks[0]['sig1'][:cap * n1].cpu().numpy().reshape(cap, n1)
-        cpu_rows = (a, b)
-        vn = min(cap, 200_000)
-        exp, _ = oracle_run(a, b, vn, n0, n1, method, 7 if args.all_tests else 1, usable_cpus())
-        verify = {'positions': vn, 'against': 'oracle/nanomod_oracle.c on the first positions of rank 0, same input'}
-        names = ['ks_d', 'ks_p', 'comb_st', 'comb_p'] + (['mwu_u', 'mwu_p', 't_t', 't_p'] if args.all_tests else [])
+    def host_rows(cap):
+        """the first `cap` positions of rank 0's first block as host CSR arrays"""
+        b0 = blocks[0]
+        if csr:
+            o0, o1 = b0['hoff0'][:cap + 1], b0['hoff1'][:cap + 1]
+        else:
+            o0 = np.arange(0, (cap + 1) * n0, n0, dtype=np.int64)
+            o1 = np.arange(0, (cap + 1) * n1, n1, dtype=np.int64)
+        return b0['sig0'][:int(o0[-1])].cpu().numpy(), o0, b0['sig1'][:int(o1[-1])].cpu().numpy(), o1
+
+    def verify_against_oracle(rows, vn):
+        """one finished pass of rank 0's first block against the oracle on its first vn positions (tests/helpers.py gates)"""
+        exp, _ = oracle_run(rows[0], rows[1], rows[2], rows[3], vn, method, 7 if all_tests else 1, usable_cpus())
+        v = {'positions': vn, 'against': 'oracle/nanomod_oracle.c on the first positions of rank 0, same input'}
+        names = ['ks_d', 'ks_p', 'comb_st', 'comb_p'] + (['mwu_u', 'mwu_p', 't_t', 't_p'] if all_tests else [])
         inner = slice(0, vn - NB)                   # the sample's last nb positions see neighbours the oracle run did not
         ok = True
         for k in names:
@@ -241,25 +359,46 @@ def main():
             e = exp[k][inner]
             fin = np.isfinite(e)
             same_special = bool(np.array_equal(g[~fin], e[~fin], equal_nan=True))
-            rel = float(np.max(np.abs(g[fin] - e[fin]) / np.maximum(np.abs(e[fin]), 1e-300))) if fin.any() else 0.0
-            ab = float(np.max(np.abs(g[fin] - e[fin]))) if fin.any() else 0.0
-            verify['max_rel_err_' + k] = rel
-            verify['max_abs_err_' + k] = ab
-            # the gates of tests/helpers.py: p-values 1e-9 relative and 1e-6 absolute (north_star), statistics 1e-9
-            # relative + 1e-12 absolute, D within 4.5e-16 (KS-only mode: the exact rational; bit-exact with all tests)
             err = np.abs(g[fin] - e[fin])
+            rel = float(np.max(err / np.maximum(np.abs(e[fin]), 1e-300))) if fin.any() else 0.0
+            ab = float(np.max(err)) if fin.any() else 0.0
+            v['max_rel_err_' + k] = rel
+            v['max_abs_err_' + k] = ab
+            # the gates of tests/helpers.py: p-values 1e-9 relative and 1e-6 absolute (north_star), statistics 1e-9
+            # relative + 1e-12 absolute (t: 1e-11 relative + 2e-14), U exact, D bit for bit
             if k.endswith('_p'):
                 good = bool(np.all(err <= 1e-9 * np.abs(e[fin]) + 1e-300)) and ab <= 1e-6
             elif k == 'ks_d':
-                good = ab <= 4.5e-16
+                good = ab <= KS_D_ABS
+            elif k == 'mwu_u':
+                good = ab == 0.0
+            elif k == 't_t':
+                good = bool(np.all(err <= 1e-11 * np.abs(e[fin]) + 2e-14))
             else:
                 good = bool(np.all(err <= 1e-9 * np.abs(e[fin]) + 1e-12))
             ok = ok and same_special and good
+        v['ok'] = bool(ok)
+        return v
+
+    # ---- one untimed pass, checked on rank 0 against the CPU oracle on a bounded sample of the same input
+    step(gather)
+    state.wait()
+    torch.cuda.synchronize()
+    verify = None
+    cpu_rows = None
+    mean_n = samples_local / max(n_local, 1)
+    if rank == 0:
+        cap_default = 1_000_000 if not csr else 200_000
+        cap = min(args.cpu_sample or cap_default, blocks[0]['n'])
+        cpu_rows = host_rows(cap)
+        vn = min(cap, 200_000 if not csr else 40_000)
+        verify = verify_against_oracle(cpu_rows, vn)
         if gather:                                   # the gathered track holds rank 0's first block at its natural place
             full = state.result()
-            ok = ok and bool(torch.equal(full['ks_p'][blocks[0]['lo_h']:blocks[0]['lo_h'] + vn], blocks[0]['out']['ks_p'][:vn]))
-        verify['ok'] = bool(ok)
-        if not ok:
+            same = bool(torch.equal(full['ks_p'][blocks[0]['lo_h']:blocks[0]['lo_h'] + vn], blocks[0]['out']['ks_p'][:vn]))
+            verify['gathered_track_equals_local'] = same
+            verify['ok'] = verify['ok'] and same
+        if not verify['ok']:
             print('bench.py: verification against the oracle FAILED: %r' % verify, file=sys.stderr)
 
     # ---- W warm-up steps, then exactly K timed steps (kernels + all-gather when N > 1)
@@ -292,37 +431,73 @@ def main():
         copy_gbs = 2 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
+    # ---- the same step on tie-heavy input (real NanoMod events are 3-decimal values): a second, shorter measurement
+    # beside the headline of the default run; the buffers are refilled in place
+    real_ties = None
+    if world == 1 and args.ties == 'few' and not args.no_real_ties and args.config in ('ecoli', 'alltests') and not args.force_collective:
+        for b in blocks:
+            fill(b, 'real')
+        step(False); state.wait(); torch.cuda.synchronize()
+        rows_t = host_rows(min(20_000, blocks[0]['n']))
+        vt = verify_against_oracle(rows_t, len(rows_t[1]) - 1)
+        for _ in range(3):
+            step(False)
+        t2 = nm.EventTimer(64)
+        det.timer = t2
+        ks = max(1, min(args.steps, 10))
+        el2 = timed(False, ks)
+        det.timer = None
+        r1, rn = t2.read(L.KERNEL_RANK_STATS)
+        real_ties = {'value': total * ks / el2, 'unit': 'positions/s', 'steps': ks, 'ms_per_step': el2 / ks * 1e3,
+                     'kernel_avg_ms': r1 / max(rn, 1),
+                     'data': 'the same generator on the 3-decimal grid (round(1000 x) / 1000 as float32): ties between and '
+                             'inside the groups as in real events' if args.dtype == 'f32' else 'int16 milli-units: identical to the headline input',
+                     'verify': vt}
+        if not vt['ok']:
+            verify['ok'] = False
+            print('bench.py: verification of the tie-heavy pass FAILED: %r' % vt, file=sys.stderr)
+
+    line = None
     if rank == 0:
         value = total * args.steps / elapsed
         launches = max(k1_n, 1)
-        k1_avg_s = k1_ms / launches * 1e-3
-        path_avg_s = (k1_ms + k2_ms + k3_ms) / launches * 1e-3
+        steps_launches = args.steps * chunks                                  # blocks timed (one event pair per block and kernel)
+        k1_per_block_s = k1_ms / steps_launches * 1e-3
+        path_per_block_s = (k1_ms + k2_ms + k3_ms) / steps_launches * 1e-3
         pos_per_launch = n_local / chunks
-        k_out = 4 if args.all_tests else 2
-        algo = algorithmic_bytes(n0, n1, sample_bytes, k_out)
-        k1_bytes = sample_bytes * (n0 + n1) + (4 if not args.all_tests else 8 + 8 + 32 + 8)   # K1's own reads + writes
-        achieved = algo * pos_per_launch / path_avg_s / 1e9 if path_avg_s > 0 else 0.0
-        k1_achieved = k1_bytes * pos_per_launch / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
+        k_out = 4 if all_tests else 2
+        mean0 = (sum(b['sig0'].numel() for b in blocks) / n_local)
+        mean1 = (sum(b['sig1'].numel() for b in blocks) / n_local)
+        algo = algorithmic_bytes(mean0, mean1, sample_bytes, k_out, csr)
+        k1_bytes = sample_bytes * (mean0 + mean1) + (16 if csr else 0) + (4 if not all_tests else 8 + 8 + 32 + 8)   # K1's own reads + writes
+        achieved = algo * pos_per_launch / path_per_block_s / 1e9 if path_per_block_s > 0 else 0.0
+        k1_achieved = k1_bytes * pos_per_launch / k1_per_block_s / 1e9 if k1_per_block_s > 0 else 0.0
         prm = L.make_params(dtype=L.DTYPE_F32 if args.dtype == 'f32' else L.DTYPE_I16_MILLI, tests=tests,
                             method=L.METHOD_BY_NAME[method])
         import ctypes
         kbuf = ctypes.create_string_buffer(96)
         L.check(L.load().nmod_describe_dispatch(ctypes.byref(prm), n0, n1, kbuf, 96), 'nmod_describe_dispatch')
-        traffic, traffic_src = measured_traffic(L.LIB_PATH, '%s_%s_%dv%d_%d' % ('all' if args.all_tests else 'ks', args.dtype, n0, n1, int(pos_per_launch)))
-        what = 'KS + MWU + Welch-t + Fisher window=%d (BASELINE.json configs[2])' % (2 * NB + 1) if args.all_tests \
-            else 'KS + weighted Stouffer window=%d (BASELINE.json configs[1])' % (2 * NB + 1)
+        shape = 'ragged' if csr else '%dv%d' % (n0, n1)
+        key = '%s_%s_%s_%d%s' % ('all' if all_tests else 'ks', args.dtype, shape, int(pos_per_launch), '_realties' if args.ties == 'real' else '')
+        rec = profile_record(L.LIB_PATH, key) or {}
+        tests_txt = 'KS + MWU + Welch-t + Fisher window=%d' % (2 * NB + 1) if all_tests else 'KS + weighted Stouffer window=%d' % (2 * NB + 1)
+        reads_txt = ('n0 ~ LogNormal(ln 1000, 0.5) in [5, 4000], n1 ~ LogNormal(ln 50, 0.5) in [5, 400] (means %.0f v %.0f), CSR'
+                     % (mean0, mean1)) if csr else '%d v %d reads/position' % (n0, n1)
         line = {
-            'metric': 'genomic positions/sec (%s)' % ('KS + MWU + Welch-t + Fisher' if args.all_tests else 'KS + Stouffer'),
+            'metric': 'genomic positions/sec (%s)' % ('KS + MWU + Welch-t + Fisher' if all_tests else 'KS + Stouffer'),
             'value': value, 'unit': 'positions/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
             'vs_baseline': None, 'dtype': '%s keys / f64 p-values' % args.dtype,
             'data': 'synthetic (counter-based Irwin-Hall(4) on a 262 141-value grid, support +-3.46 sigma, unit variance — '
-                    'a stand-in for N(0,1) that keeps ~1 tie per position; +0.8 shift planted in group 2 every 10 000 positions)',
-            'config': {'workload': 'E. coli 4.6 Mb x %d: %d positions in total, %d v %d reads/position, %s'
-                                   % (world if not args.strong else 1, total, n0, n1, what),
-                       'positions_total': total, 'positions_per_gpu': total // world, 'n0': n0, 'n1': n1,
-                       'neighborPvalues': NB, 'WeightsDif': WDIF,
+                    'a stand-in for N(0,1); %s; +0.8 shift planted in group 2 every 10 000 positions)'
+                    % ('~1 tie per position' if args.ties == 'few' and args.dtype == 'f32' else 'on the 3-decimal grid of real events: ~11 ties between the groups per 200 v 200 position'),
+            'config': {'workload': '%s%s: %d positions in total (%d per GPU), %s, %s'
+                                   % (preset['name'], ' x %d' % world if (world > 1 and not args.strong) else '', total, total // world, reads_txt, tests_txt),
+                       'preset': args.config, 'positions_total': total, 'positions_per_gpu': total // world, 'n0': n0, 'n1': n1,
+                       'layout': 'csr' if csr else 'fixed stride', 'neighborPvalues': NB, 'WeightsDif': WDIF, 'ties': args.ties,
+                       'rccl_ranks': dist.get_world_size() if dist is not None else 0,
+                       'backend': dist.get_backend() if dist is not None else None,
                        'parallelism': ('block-cyclic position sharding x%d, %d rounds of %d-position blocks, +-%d halo recomputed; '
                                        'per round one RCCL all_gather_into_tensor per track (ks_p, comb_p), issued async behind '
                                        'the round\'s kernels' % (world, chunks, B, NB)) if gather else
@@ -331,24 +506,34 @@ def main():
                              'ms_per_step': compute_elapsed / args.steps * 1e3,
                              'note': 'the same K steps without the all-gather (tracks stay sharded)' if gather else
                                      'identical to value: one rank has nothing to gather'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'definition': 'SURVEY.md 8(d) bytes/position (fixed stride: no CSR offsets) x positions per launch / '
-                                       'HIP-event time of K1 + K2 + K3 of that launch',
-                         'algorithmic_bytes_per_position': algo, 'positions_per_launch': pos_per_launch,
-                         'path_avg_ms': path_avg_s * 1e3,
-                         'kernel': kbuf.value.decode(), 'kernel_avg_ms': k1_avg_s * 1e3, 'launches_timed': k1_n,
+            'roofline': {'bound': 'hbm', 'limiter': 'valu-issue', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': rec.get('hbm_bytes_per_launch'), 'traffic_source': rec.get('source'),
+                         'note': 'HBM is the mandated yard-stick (sort / search / scan, no MFMA); the kernel is bound by VALU '
+                                 'instruction issue (see `valu`), not by bytes: traffic ~ 1.0 x algorithmic',
+                         'definition': 'SURVEY.md 8(d) bytes/position x positions per launch / HIP-event time of K1 + K2 + K3 of that launch',
+                         'algorithmic_bytes_per_position': algo, 'positions_per_launch': pos_per_launch, 'profile_key': key,
+                         'path_avg_ms': path_per_block_s * 1e3,
+                         'kernel': kbuf.value.decode() if not csr else 'size-class launches of ks_rank_kernel / rank_hist_kernel (ragged)',
+                         'kernel_avg_ms': k1_per_block_s * 1e3, 'launches_timed': k1_n,
                          'dominant_kernel_only': {'bytes_per_position': k1_bytes, 'achieved': k1_achieved,
                                                   'frac': k1_achieved / HBM_PEAK_GBS,
-                                                  'note': 'bytes K1 itself reads and writes / K1 time'},
+                                                  'note': 'bytes K1 itself reads and writes / K1 time (all size-class launches of a block)'},
                          'frac_of_measured_copy': achieved / copy_gbs if copy_gbs else None,
                          'measured_copy_GBps': copy_gbs, 'guide_copy_GBps': HBM_COPY_GUIDE_GBS,
-                         'other_kernels_avg_ms': {'finalize': k2_ms / launches, 'combine': k3_ms / launches}},
+                         'other_kernels_avg_ms': {'finalize': k2_ms / steps_launches, 'combine': k3_ms / steps_launches}},
+            'valu': {'instr_per_position': rec.get('valu_instr_per_position'), 'issue_util': rec.get('valu_issue_util'),
+                     'source': rec.get('source') if rec.get('valu_instr_per_position') is not None else None,
+                     'note': 'rocprofv3 SQ_INSTS_VALU / positions and SQ_ACTIVE_INST_VALU x 4 / SIMD cycles of the K1 kernel, taken '
+                             'with this library binary (null: this binary has not been profiled)'},
             'verify': verify,
         }
+        if real_ties is not None:
+            line['real_ties'] = real_ties
         if not args.no_cpu and world == 1:           # the CPU baseline is an N=1 figure
-            line['cpu_baseline'] = cpu_baseline(cpu_rows[0], cpu_rows[1], n0, n1, method, 7 if args.all_tests else 1, usable_cpus())
+            line['cpu_baseline'] = cpu_baseline(cpu_rows, '%s, %s' % (reads_txt, tests_txt), method, 7 if all_tests else 1, usable_cpus())
+    ok = torch.tensor([1 if (rank != 0 or verify['ok']) else 0], device=dev)
     if dist is not None:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -360,6 +545,8 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+    if int(ok.item()) == 0:
+        sys.exit(3)                                  # a numerically wrong build must not look like a benchmark record
 
 
 if __name__ == '__main__':

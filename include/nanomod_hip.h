@@ -172,6 +172,13 @@ int nmod_synth_fill(const nmod_params* prm, uint64_t seed, int64_t pos_begin, in
                     int32_t group, int32_t n_per_pos, int64_t plant_period, float plant_shift,
                     void* sig_out);
 
+/* The same generator for ragged rows (BASELINE.json configs[4]): sample `read` of position pos_begin + i goes to
+ * sig_out[off[i] + read], read < off[i+1] - off[i]; `off` is a DEVICE array of npos + 1 element offsets into sig_out.
+ * float32 or int16 milli-unit output (prm->dtype). */
+int nmod_synth_fill_csr(const nmod_params* prm, uint64_t seed, int64_t pos_begin, int64_t npos,
+                        int32_t group, const int64_t* off, int64_t plant_period, float plant_shift,
+                        void* sig_out);
+
 /* HIP-event timer: records (start, stop) around every kernel the library
  * launches while prm->timer points to it; read it after synchronising. */
 enum { NMOD_KERNEL_RANK_STATS = 0, NMOD_KERNEL_FINALIZE = 1, NMOD_KERNEL_COMBINE = 2,

@@ -915,6 +915,26 @@ int nmod_synth_fill(const nmod_params* prm, uint64_t seed, int64_t pos_begin, in
   return NMOD_OK;
 }
 
+int nmod_synth_fill_csr(const nmod_params* prm, uint64_t seed, int64_t pos_begin, int64_t npos, int32_t group,
+                        const int64_t* off, int64_t plant_period, float plant_shift, void* sig_out) {
+  int rc = check_params(prm);
+  if (rc != NMOD_OK) return rc;
+  if (npos < 0 || !off || !sig_out || (group != 0 && group != 1)) return NMOD_ERR_INVALID_ARG;
+  if (prm->memspace != NMOD_MEM_DEVICE || (prm->dtype != NMOD_DTYPE_F32 && prm->dtype != NMOD_DTYPE_I16_MILLI)) return NMOD_ERR_INVALID_ARG;
+  if (nmod_device_count() <= prm->device || prm->device < 0) return NMOD_ERR_NO_DEVICE;
+  NMOD_HIP(hipSetDevice(prm->device));
+  if (npos == 0) return NMOD_OK;
+  hipStream_t stream = (hipStream_t)prm->stream;
+  SynthCsrArgs sa;
+  sa.seed = seed; sa.pos_begin = pos_begin; sa.npos = npos; sa.group = group; sa.dtype = prm->dtype;
+  sa.plant_period = plant_period; sa.plant_shift = plant_shift; sa.off = off; sa.out = sig_out;
+  unsigned blocks = (unsigned)std::min<int64_t>((npos + 3) / 4, 256 * 32);
+  ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_SYNTH, stream);
+  hipLaunchKernelGGL(synth_csr_kernel, dim3(blocks), dim3(256), 0, stream, sa);
+  NMOD_HIP(hipGetLastError());
+  return NMOD_OK;
+}
+
 int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char* buf, int32_t buflen) {
   int rc = check_params(prm);
   if (rc != NMOD_OK) return rc;

@@ -199,4 +199,33 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthArgs a) {
   }
 }
 
+// the same values for ragged rows: sample `read` of position pos_begin + i goes to sig[off[i] + read]; one wave per row
+struct SynthCsrArgs {
+  uint64_t seed; int64_t pos_begin; int64_t npos; int32_t group; int32_t dtype;
+  int64_t plant_period; float plant_shift; const int64_t* off; void* out;
+};
+
+__global__ __launch_bounds__(256) void synth_csr_kernel(SynthCsrArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int64_t rel = wave; rel < a.npos; rel += (int64_t)gridDim.x * 4) {
+    const int64_t o = a.off[rel];
+    const int n = (int)(a.off[rel + 1] - o);
+    const int64_t pos = a.pos_begin + rel;
+    bool planted = false;
+    if (a.group == 1 && a.plant_period > 0) {
+      const int64_t m = pos % a.plant_period;
+      planted = (m == 0 || m == 1 || m == a.plant_period - 1);
+    }
+    for (int read = lane; read < n; read += 64) {
+      const uint64_t h = synth_mix(a.seed, pos, a.group, (uint32_t)read);
+      const int s = (int)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + (h >> 48));
+      float x = __fmul_rn((float)(s - 131070), 2.6428997e-05f);
+      if (planted) x = __fadd_rn(x, a.plant_shift);
+      if (a.dtype == NMOD_DTYPE_F32) reinterpret_cast<float*>(a.out)[o + read] = x;
+      else reinterpret_cast<int16_t*>(a.out)[o + read] = (int16_t)rintf(__fmul_rn(x, 1000.0f));
+    }
+  }
+}
+
 }  // namespace nmod

@@ -312,6 +312,15 @@ class DeviceDetector:
         return out
 
 
+    def synth_fill_csr(self, out, seed, pos_begin, off, group, plant_period=0, plant_shift=0.0):
+        """ragged rows: `off` = int64 CUDA tensor of npos + 1 element offsets into `out`"""
+        prm = self._params(self._dtype_of(out), 0, 0, 0, 0)
+        rc = self.lib.nmod_synth_fill_csr(C.byref(prm), seed, pos_begin, off.numel() - 1, group, off.data_ptr(),
+                                          plant_period, plant_shift, out.data_ptr())
+        L.check(rc, 'nmod_synth_fill_csr')
+        return out
+
+
 def downsample_ks(sig0, off0, sig1, off1, positions, cov, *, iters=100, quantile=0.25, seed=0, device=0,
                   max_elements=1 << 27):
     """The down-sampling branch of getKStest (myDetect.py:345-361) for the positions `positions` (indices into

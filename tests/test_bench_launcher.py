@@ -1,0 +1,63 @@
+"""CPU: `python3 bench.py --gpus N` starts its own ranks.  The children of --launch-only print
+their rank and exit before any GPU call, so the launcher path runs in a container without a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _run(args, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e,
+                          timeout=timeout)
+
+
+def test_gpus2_spawns_two_fresh_ranks():
+    r = _run(['--gpus', '2', '--launch-only', '--config', 'chr20'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert sorted(x['rank'] for x in recs) == [0, 1]
+    assert all(x['world_size'] == 2 and x['launch_only'] for x in recs)
+    assert all(x['master'].startswith('127.0.0.1:') for x in recs)
+    assert r.stdout.rstrip().splitlines()[-1].startswith('{')            # a JSON line is the last line of stdout
+
+
+def test_under_an_external_launcher_it_is_a_rank():
+    r = _run(['--gpus', '2', '--launch-only'], env={'RANK': '1', 'WORLD_SIZE': '2', 'LOCAL_RANK': '1'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec['rank'] == 1 and rec['world_size'] == 2                    # no second level of children
+    r = _run(['--gpus', '4', '--launch-only'], env={'RANK': '0', 'WORLD_SIZE': '2', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_a_failed_rank_is_reported_not_retried():
+    """without a GPU every rank fails at its first device call: the parent exits non-zero and prints no record"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip('this box could run the ranks')
+    r = _run(['--gpus', '2', '--steps', '1', '--warmup', '0', '--positions', '64', '--no-cpu'], timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert 'a rank failed' in r.stderr
+
+
+def test_presets_name_the_baseline_configs():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert set(bench.PRESETS) == {'ecoli', 'alltests', 'chr20', 'ragged'}
+    assert bench.PRESETS['chr20']['positions'] == 8_000_000 and bench.PRESETS['chr20']['n0'] == 500
+    assert bench.PRESETS['ragged']['layout'] == 'csr'
+    import numpy as np
+    a = bench.ragged_sizes(1, 0, 100_000, 0); b = bench.ragged_sizes(1, 0, 100_000, 1)
+    assert a.min() >= 5 and a.max() <= 4000 and b.min() >= 5 and b.max() <= 400
+    assert 900 < np.median(a) < 1100 and 45 < np.median(b) < 55
+    # a function of the global position: a halo position gets the same size on every rank
+    assert np.array_equal(bench.ragged_sizes(1, 5000, 100, 0), a[5000:5100])

@@ -827,3 +827,25 @@ def test_mtest2_on_arbitrary_float64(nm):
         assert rec[1][0][0] == e[0][0] and abs(rec[1][0][1] - e[0][1]) <= 1e-9 * e[0][1]
         assert abs(rec[1][1][1] - e[1][1]) <= 1e-9 * e[1][1] and abs(rec[1][2][0] - e[2][0]) <= 4.5e-16
         assert abs(rec[1][2][1] - e[2][1]) <= 1e-9 * e[2][1]
+
+
+def test_synth_fill_csr_matches_the_numpy_restatement(nm):
+    """nmod_synth_fill_csr (bench.py --config ragged): sample `read` of position p is the fixed-stride generator's
+    (p, read) value, written at off[p] + read; float32 and int16 output"""
+    import torch
+    L = nm._lib
+    rng = np.random.default_rng(3)
+    P, begin = 700, 9_990
+    sizes = rng.integers(0, 300, P); sizes[5] = 0; sizes[17] = 1
+    off = np.zeros(P + 1, np.int64); off[1:] = np.cumsum(sizes)
+    det = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    d_off = torch.from_numpy(off).cuda()
+    nmax = int(sizes.max())
+    for tdt, name in ((torch.float32, 'f32'), (torch.int16, 'i16')):
+        for g in (0, 1):
+            out = torch.zeros(int(off[-1]), dtype=tdt, device='cuda:0')
+            det.synth_fill_csr(out, 77, begin, d_off, g, 10000, 0.8)
+            torch.cuda.synchronize()
+            ref = H.synth_ref(77, begin, P, g, nmax, 10000, 0.8, dtype=name).reshape(P, nmax)
+            exp = np.concatenate([ref[i, :sizes[i]] for i in range(P)])
+            assert np.array_equal(out.cpu().numpy(), exp), (name, g)

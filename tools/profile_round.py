@@ -30,7 +30,13 @@ BENCH = os.path.join(ROOT, 'bench.py')
 LIB = os.path.join(ROOT, 'nanomod_amd', 'libnanomod_hip.so')
 SHA = hashlib.sha256(open(LIB, 'rb').read()).hexdigest()[:16]
 
-CONFIGS = [('ks_f32', []), ('all_f32', ['--all-tests']), ('ks_i16', ['--dtype', 'i16'])]
+CONFIGS = [('ks_f32', []), ('all_f32', ['--config', 'alltests']), ('ks_i16', ['--dtype', 'i16']),
+           ('all_i16', ['--config', 'alltests', '--dtype', 'i16']), ('ks_f32_realties', ['--ties', 'real'])]
+if len(sys.argv) > 2:                      # python3 tools/profile_round.py r3 ks_f32,all_f32
+    CONFIGS = [c for c in CONFIGS if c[0] in sys.argv[2].split(',')]
+if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minutes per pass): only on request
+    CONFIGS += [('ragged_all_f32', ['--config', 'ragged', '--all-tests', '--steps', '3', '--warmup', '1']),
+                ('ragged_all_i16', ['--config', 'ragged', '--all-tests', '--dtype', 'i16', '--steps', '3', '--warmup', '1'])]
 K1_NAMES = ('ks_rank_kernel', 'rank_hist_kernel', 'rank_pair_kernel', 'big_rank_kernel', 'big_hist_kernel')
 PMC_GROUPS = [
     ['FETCH_SIZE'], ['WRITE_SIZE'],
@@ -44,7 +50,7 @@ def run(cmd, **kw):
 
 
 def bench_line(extra, steps=20, warmup=5):
-    r = run(['python3', BENCH, '--steps', str(steps), '--warmup', str(warmup)] + extra)
+    r = run(['python3', BENCH, '--steps', str(steps), '--warmup', str(warmup)] + extra)      # (a later --steps in `extra` wins)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     return json.loads(lines[-1]) if lines else {'error': r.stderr[-2000:]}
 
@@ -67,41 +73,54 @@ for cfg, extra in CONFIGS:
     # kernel trace + stats
     d = '/tmp/prof_%s_trace' % cfg
     shutil.rmtree(d, ignore_errors=True)
-    r = run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', 'python3', BENCH, '--steps', '10', '--warmup', '3', '--no-cpu'] + extra)
+    r = run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', 'python3', BENCH, '--steps', '10', '--warmup', '3', '--no-cpu', '--no-real-ties'] + extra)
     under = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     for f in glob.glob(d + '/*/*kernel_stats.csv'):
         shutil.copy(f, os.path.join(OUT, '%s_%s_kernel_stats.csv' % (TAG, cfg)))
     if under:
         open(os.path.join(OUT, '%s_%s_bench_under_rocprof.json' % (TAG, cfg)), 'w').write(under[-1] + '\n')
     # PMC passes
-    summary = ['rocprofv3 PMC summary, %s, bench.py %s (4.6 M positions, 200 v 200), library sha256[:16] %s' % (TAG, ' '.join(extra) or '(default)', SHA),
+    summary = ['rocprofv3 PMC summary, %s, bench.py %s (%s), library sha256[:16] %s' % (TAG, ' '.join(extra) or '(default)', line.get('config', {}).get('workload', '?'), SHA),
                'separate --pmc passes; per-launch means of the K1 kernel(s); FETCH_SIZE / WRITE_SIZE in KiB as reported']
     means = {}
     for gi, group in enumerate(PMC_GROUPS):
         d = '/tmp/prof_%s_pmc%d' % (cfg, gi)
         shutil.rmtree(d, ignore_errors=True)
-        run(['rocprofv3', '--pmc'] + group + ['--output-format', 'csv', '-d', d, '--', 'python3', BENCH, '--steps', '2', '--warmup', '1', '--no-cpu'] + extra)
+        run(['rocprofv3', '--pmc'] + group + ['--output-format', 'csv', '-d', d, '--', 'python3', BENCH] + extra + ['--steps', '2', '--warmup', '1', '--no-cpu', '--no-real-ties'])
         vals, meta = k1_rows(d + '/*/*counter_collection.csv', 'Counter_Name')
+        # per bench step: 4 passes of the hot path run under the profiler (verify, warm-up, 2 timed); a ragged pass is
+        # many size-class launches, so the counters are summed over the K1 kernels and divided by the passes
+        passes = 4
         for (kname, cname), v in sorted(vals.items()):
-            means[cname] = sum(v) / len(v)
-            summary.append('  %-46s %-24s launches=%d mean=%.6g' % (kname, cname, len(v), means[cname]))
+            means[cname] = means.get(cname, 0.0) + sum(v) / passes
+            summary.append('  %-46s %-24s launches=%d sum/pass=%.6g' % (kname, cname, len(v), sum(v) / passes))
         if meta and gi == 2:
             summary.append('  (grid, LDS bytes per block, VGPRs, SGPRs) = %r' % (meta,))
-    npos = 4_600_000
+    npos = int(line.get('roofline', {}).get('positions_per_launch', 4_600_000))
+    key = line.get('roofline', {}).get('profile_key', cfg)
+    ent = {'lib_sha16': SHA, 'source': 'profiles/%s_%s_pmc_summary.txt' % (TAG, cfg)}
     if 'FETCH_SIZE' in means and 'WRITE_SIZE' in means:
         hbm = means['FETCH_SIZE'] * 1024 * 2 + means['WRITE_SIZE'] * 1024
         summary.append('HBM traffic per K1 launch (FETCH_SIZE x2: 64 B counted per 128-B request on gfx950 streaming reads, + WRITE_SIZE): %.4g B' % hbm)
-        n0 = n1 = 200
-        key = '%s_%s_%dv%d_%d' % ('all' if '--all-tests' in extra else 'ks', 'i16' if 'i16' in extra else 'f32', n0, n1, npos)
-        traffic[key] = {'lib_sha16': SHA, 'hbm_bytes_per_launch': hbm, 'source': 'profiles/%s_%s_pmc_summary.txt' % (TAG, cfg)}
+        ent['hbm_bytes_per_launch'] = hbm
     if 'SQ_INSTS_VALU' in means:
+        ent['valu_instr_per_position'] = means['SQ_INSTS_VALU'] / npos
         summary.append('VALU instructions per position: %.1f' % (means['SQ_INSTS_VALU'] / npos))
     if 'SQ_ACTIVE_INST_VALU' in means and 'GRBM_GUI_ACTIVE' in means:
+        ent['valu_issue_util'] = means['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * means['GRBM_GUI_ACTIVE'] / 8)
         summary.append('VALU issue utilisation: SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = %.3f'
-                       % (means['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * means['GRBM_GUI_ACTIVE'] / 8)))
+                       % ent['valu_issue_util'])
+    traffic[key] = ent
     if 'SQ_LDS_BANK_CONFLICT' in means and 'SQ_LDS_IDX_ACTIVE' in means:
         summary.append('LDS bank-conflict share of LDS cycles: %.2f' % (means['SQ_LDS_BANK_CONFLICT'] / means['SQ_LDS_IDX_ACTIVE']))
     open(os.path.join(OUT, '%s_%s_pmc_summary.txt' % (TAG, cfg)), 'w').write('\n'.join(summary) + '\n')
     print('\n'.join(summary[-5:]))
     print(cfg, 'value %.4g  K1 %.3f ms  frac %.3f' % (line.get('value', 0), line.get('roofline', {}).get('kernel_avg_ms', 0), line.get('roofline', {}).get('frac', 0)))
-json.dump(traffic, open(os.path.join(OUT, 'traffic.json'), 'w'), indent=1)
+merged = {}
+for src in (os.path.join(ROOT, 'profiles', 'traffic.json'), os.path.join(OUT, 'traffic.json')):
+    try:
+        merged.update({k: v for k, v in json.load(open(src)).items() if v.get('lib_sha16') == SHA})   # same binary only
+    except Exception:
+        pass
+merged.update(traffic)
+json.dump(merged, open(os.path.join(OUT, 'traffic.json'), 'w'), indent=1)

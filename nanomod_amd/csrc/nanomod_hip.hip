@@ -384,8 +384,9 @@ static hipMemPool_t scratch_pool(int dev) {
 }
 
 struct DevScratch {
-  void* p = nullptr; bool async = false;
+  void* p = nullptr; bool async = false; hipStream_t owner = nullptr;
   hipError_t alloc(size_t bytes, hipStream_t s, int dev) {
+    owner = s;
     hipMemPool_t pool = scratch_pool(dev);
     if (pool && hipMallocFromPoolAsync(&p, bytes ? bytes : 4, pool, s) == hipSuccess) { async = true; return hipSuccess; }
     (void)hipGetLastError();
@@ -398,7 +399,9 @@ struct DevScratch {
     p = nullptr;
     return e;
   }
-  ~DevScratch() { if (p) { if (async) hipFreeAsync(p, nullptr); else hipFree(p); } }
+  // an early return (error path) with kernels of the allocation stream still queued: the slab goes back to the pool
+  // ordered behind them on THAT stream — freeing on the null stream does not order against a non-blocking stream
+  ~DevScratch() { if (p) { if (async) hipFreeAsync(p, owner); else { hipStreamSynchronize(owner); hipFree(p); } } }
 };
 
 // the float64 samples behind float32 keys (detect_f64): device pointers in the index space of the offsets

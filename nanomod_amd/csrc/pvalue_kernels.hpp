@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthArgs a) {
     uint64_t h = synth_mix(a.seed, pos, a.group, read);
     int s = (int)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + (h >> 48));
     float x = __fmul_rn((float)(s - 131070), 2.6428997e-05f);
+    asm volatile("" : "+v"(x));                         // (rounded here: never contracted with the planted shift)
     if (a.group == 1 && a.plant_period > 0) {
       int64_t m = pos % a.plant_period;
       if (m == 0 || m == 1 || m == a.plant_period - 1) x = __fadd_rn(x, a.plant_shift);
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256) void synth_csr_kernel(SynthCsrArgs a) {
       const uint64_t h = synth_mix(a.seed, pos, a.group, (uint32_t)read);
       const int s = (int)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + (h >> 48));
       float x = __fmul_rn((float)(s - 131070), 2.6428997e-05f);
+      asm volatile("" : "+v"(x));                       // (the product is rounded before the shift is added: no fused multiply-add)
       if (planted) x = __fadd_rn(x, a.plant_shift);
       if (a.dtype == NMOD_DTYPE_F32) reinterpret_cast<float*>(a.out)[o + read] = x;
       else reinterpret_cast<int16_t*>(a.out)[o + read] = (int16_t)rintf(__fmul_rn(x, 1000.0f));

@@ -16,6 +16,7 @@ plus 'sign_test_arrays' (the same numbers as numpy arrays, an addition).
 """
 from __future__ import annotations
 
+import collections.abc
 import sys
 import time
 
@@ -184,18 +185,22 @@ def combin_pvalues(moptions):
 
 
 # ---------------------------------------------------------------------------
-class SignTestRecords:
+class SignTestRecords(collections.abc.Sequence):
     """`moptions['sign_test']` as the reference builds it (myDetect.py:436) — a sequence of
     ((chrom, strand, pos, base, n0, n1), [(U, pU), (t, pt), (D, pKS)[, (comb stat, comb p)]]) records — backed by
     the result arrays: a record is built when it is first asked for and kept (so `sorted_sign_test` holds the same
-    objects), 4.6 M tuples are not built up front.  Supports what the reference's consumers do: len, indexing,
-    slicing, iteration, sorted()."""
+    objects), 4.6 M tuples are not built up front.  A read-only `collections.abc.Sequence`: len, indexing, slicing,
+    iteration, sorted(), `in`, reversed(), `.count()`, `.index()` (what mySimulate.getTopRank calls on it,
+    mySimulate.py:312 — constant time for a record obtained from this object or its ranked view), `==` against a
+    list of records, `+` (gives a list); it pickles as a plain list."""
 
     def __init__(self, meta, res, with_comb, order=None, parent=None):
         self._meta, self._res, self._with_comb = meta, res, with_comb
         self._order = order
         self._parent = parent
         self._cache = {} if parent is None else None
+        self._where = {} if parent is None else None     # id(record) -> position index, for index()
+        self._inv = None
 
     def __len__(self):
         return len(self._order) if self._order is not None else len(self._meta['pos'])
@@ -215,6 +220,7 @@ class SignTestRecords:
         rec = self._cache.get(i)
         if rec is None:
             rec = self._cache[i] = self._build(i)
+            self._where[id(rec)] = i
         return rec
 
     def __getitem__(self, k):
@@ -230,6 +236,48 @@ class SignTestRecords:
     def __iter__(self):
         for k in range(len(self)):
             yield self[k]
+
+    def index(self, value, start=0, stop=None):
+        """list.index: first k with self[k] == value.  A record handed out by this object (or by the view that shares its
+        records) is found through its identity; anything else by the equality scan of a list."""
+        root = self._parent if self._parent is not None else self
+        i = root._where.get(id(value))
+        if i is not None and root._cache.get(i) is value:
+            if self._order is None:
+                k = i
+            else:
+                if self._inv is None:
+                    self._inv = {int(p): kk for kk, p in enumerate(np.asarray(self._order).tolist())}
+                k = self._inv.get(i)
+            n = len(self)
+            lo = max(start + n, 0) if start < 0 else start
+            hi = n if stop is None else (max(stop + n, 0) if stop < 0 else min(stop, n))
+            if k is not None and lo <= k < hi:
+                return k
+            raise ValueError('%r is not in list' % (value,))
+        return super().index(value, start, len(self) if stop is None else stop)
+
+    def __eq__(self, other):
+        if isinstance(other, (list, SignTestRecords)):
+            return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+        return NotImplemented
+
+    __hash__ = None
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+    def tolist(self):
+        return list(self)
+
+    def __reduce__(self):
+        return (list, (list(self),))
+
+    def __repr__(self):
+        return 'SignTestRecords(%d records%s)' % (len(self), ', ranked view' if self._order is not None else '')
 
     def permuted(self, order):
         """the same records in another order (the ranking)"""

@@ -40,6 +40,11 @@ def warm_up(device=0):
         except Exception:                                # (errors surface in the real call, with their message)
             pass
     t = threading.Thread(target=run, name='nanomod-warm-up', daemon=True)
+    if not _warm:
+        # a caller that fails before detect_host joins the thread (build_csr raising, say) must not let the interpreter
+        # shut down while the HIP runtime is still initialising on it
+        import atexit
+        atexit.register(lambda: [_join_warm_up(d) for d in list(_warm)])
     _warm[device] = t
     t.start()
     return t

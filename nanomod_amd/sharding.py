@@ -167,6 +167,9 @@ def pipelined_detect(compute, state, nb, group=None, gather=True, force_collecti
             continue
         for name in state.tracks:
             dst = state.full[name][c * world * B:(c + 1) * world * B]
+            if hi > lo and (res[name].dtype != dst.dtype or res[name].device != dst.device):
+                raise TypeError('track %r: compute returned %s on %s, the gather buffer is %s on %s (every rank gathers the '
+                                'same dtype from its own device)' % (name, res[name].dtype, res[name].device, dst.dtype, dst.device))
             if hi - lo == B:
                 src = res[name][lo - lo_h: lo - lo_h + B]
             else:                                        # short or empty block at the end of the genome

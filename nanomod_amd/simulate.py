@@ -79,7 +79,8 @@ def group_events(parts, cs_names):
     ukey, counts = torch.unique_consecutive(key, return_counts=True)
     off = torch.zeros(len(ukey) + 1, dtype=torch.int64, device=dev)
     off[1:] = torch.cumsum(counts, 0)
-    return {'key': ukey, 'off': off, 'sig': val[order], 'base': base[order][off[:-1]]}
+    # (the reference overwrites base[(chrom, strand)][pos] with every event: the LAST one in read / event order stays)
+    return {'key': ukey, 'off': off, 'sig': val[order], 'base': base[order][off[1:] - 1]}
 
 
 def tested_positions(g0, g1, min_coverage):
@@ -145,7 +146,10 @@ def get_top_rank(chrom, strand, pos, order, run_id, nb, window, region_rank=Fals
 def run_repeat(case_parts, control_parts, opts, device=0):
     """One trip of the reference's repeat loops with the draws given: `case_parts` / `control_parts` are lists of
     (ReadPool, selected read indices) feeding dataset 1 ('simulate_case') and dataset 2 ('folder_control').
-    opts: 'MinCoverage', 'neighborPvalues', 'WeightsDif', 'testMethod', 'rankUse', 'window', 'RegionRankbyST'.
+    opts: 'MinCoverage', 'neighborPvalues', 'WeightsDif', 'testMethod', 'rankUse', 'window', 'RegionRankbyST', and —
+    as the reference's loops, which call mtest2 itself — 'coverages' (+ 'downsampling', 'downsampling_quantile',
+    'seed'): the down-sampling branch of getKStest (myDetect.py:345-361) through detect.downsample_update.
+    The device is the pools'; `device` is used only for host-resident pools.
     Returns (rank of the target site, dict of the tested positions and their numbers)."""
     import torch
     cs_names = sorted(set(cs for pool, _ in case_parts + control_parts for cs in pool.cs_names))
@@ -163,7 +167,8 @@ def run_repeat(case_parts, control_parts, opts, device=0):
     if npos == 0:
         return -1, dict(chrom=chrom, strand=strand, pos=pos)
     if sig0.is_cuda:
-        det = engine.DeviceDetector(sig0.device.index or 0, nb=max(nb, 0), weights_dif=opts.get('WeightsDif', 2.0), method=dev_method)
+        device = sig0.device.index or 0
+        det = engine.DeviceDetector(device, nb=max(nb, 0), weights_dif=opts.get('WeightsDif', 2.0), method=dev_method)
         n0 = (off0[1:] - off0[:-1]); n1 = (off1[1:] - off1[:-1])
         r = det.run(sig0, sig1, torch.as_tensor(rid, device=sig0.device), off0=off0, off1=off1,
                     max_n0=int(n0.max().item()), max_n1=int(n1.max().item()))
@@ -173,6 +178,12 @@ def run_repeat(case_parts, control_parts, opts, device=0):
                                  weights_dif=opts.get('WeightsDif', 2.0), method=dev_method, device=device)
     if np.any(res['status'] & L.STATUS_MWU_ALL_IDENTICAL):
         raise ValueError('All numbers are identical in mannwhitneyu')
+    cov = opts.get('coverages')
+    if cov is not None and (int(cov[0]) > 0 or int(cov[1]) > 0):
+        detect.downsample_update(res, sig0.cpu().numpy(), off0.cpu().numpy(), sig1.cpu().numpy(), off1.cpu().numpy(), rid, strand, cov,
+                                 iters=opts.get('downsampling', 100), quantile=opts.get('downsampling_quantile', 0.25),
+                                 seed=opts.get('seed', 0), nb=max(nb, 0), weights_dif=opts.get('WeightsDif', 2.0),
+                                 method=dev_method, device=device)
     use_p = opts.get('rankUse', 'pv') == 'pv'
     ks_key = res['ks_p'] if use_p else res['ks_d']
     mw_key = res['mwu_p'] if use_p else res['mwu_u']

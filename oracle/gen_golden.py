@@ -58,6 +58,10 @@ def crosscheck_restatements(rng):
         d, _p = orc.ks_2samp(a, b)
         r = scipy.stats.ks_2samp(a, b, method='asymp')
         assert abs(d - r.statistic) < 1e-15, (d, r.statistic)
+        # the 1.2.1 p-value expression, verbatim, with the container's kstwobign (unchanged since 1.2.1); the mpmath
+        # series and the p < 1e-100 / D -> 0 cases are in tests/test_oracle_pins.py
+        en = np.sqrt(n0 * n1 / float(n0 + n1))
+        assert _p == float(scipy.stats.kstwobign.sf((en + 0.12 + 0.11 / en) * d)), (_p, d)
         u, p = orc.mannwhitneyu(a, b)
         r = scipy.stats.mannwhitneyu(a, b, use_continuity=True,
                                      alternative='two-sided', method='asymptotic')

@@ -250,3 +250,39 @@ def test_table_number_formats_equal_printf():
     assert lib.nmod_format_probe(special.ctypes.data_as(C.POINTER(C.c_double)), 3, 1, buf, 2000) == 0
     assert buf.raw.split(b'\0')[:3] == [b'NAN', b'INF', b'-INF']
 
+
+
+def test_sign_test_records_behave_like_the_reference_list():
+    """drop-in consumers call list methods on moptions['sign_test'] — mySimulate.getTopRank does
+    `moptions['sign_test'].index(record)` (mySimulate.py:312) with records taken from 'sorted_sign_test'."""
+    import pickle
+    import nanomod_amd.detect as D
+    n = 50
+    rng = np.random.default_rng(1)
+    meta = {'chrom': np.array(['chr1'] * n), 'strand': np.array(['+'] * 30 + ['-'] * 20), 'pos': np.arange(100, 100 + n),
+            'base': np.array(list('ACGT' * 13)[:n]), 'n0': np.full(n, 7), 'n1': np.full(n, 9)}
+    res = {k: rng.random(n) for k in ('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p', 'comb_st', 'comb_p')}
+    st = D.SignTestRecords(meta, res, True)
+    as_list = [st._build(i) for i in range(n)]
+    order = np.argsort(res['comb_p'], kind='stable')
+    ranked = st.permuted(order)
+    assert isinstance(st, __import__('collections').abc.Sequence)
+    assert st == as_list and as_list == st.tolist() and not (st == as_list[:-1])
+    # a reference-style getTopRank walk (mySimulate.py:300-316): records come from the ranked view, their index from sign_test
+    for k, rec in enumerate(ranked):
+        cur = st.index(rec)
+        assert cur == int(order[k]) and st[cur] is rec
+        assert D.pos_check(st, cur, cur) and ranked.index(rec) == k
+        if k > 10:
+            break
+    # an equal record that is not one of ours is found by value; a foreign one raises like a list
+    assert st.index(as_list[17]) == 17 and st.count(as_list[3]) == 1 and as_list[5] in st
+    with pytest.raises(ValueError):
+        st.index((('chrX', '+', 1, 'A', 1, 1), []))
+    with pytest.raises(ValueError):
+        st.index(st[40], 0, 10)
+    assert (st + [1])[-1] == 1 and ([0] + st)[0] == 0 and list(reversed(st))[0] == as_list[-1]
+    back = pickle.loads(pickle.dumps(ranked))
+    assert type(back) is list and back == [as_list[i] for i in order]
+    with pytest.raises(TypeError):
+        hash(st)

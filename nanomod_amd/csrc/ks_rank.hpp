@@ -4,17 +4,22 @@
 // D is symmetric in the two groups, so call the smaller one S (m samples) and the other Q (q samples):
 //   1. S is sorted in registers (R registers x LG lanes, rank_stats_packed.hpp: bitonic network, DPP +
 //      v_med3 across lanes) and written to wave-private LDS;
-//   2. every sample x of Q finds L(x) = #{s < x} by a branchless 1+log2(C)-step binary search in LDS
-//      and, only when x ties with an S value, U(x) = #{s <= x} by a second search;
-//   3. one ds_add_u32 per sample builds the histograms of L and U (two 16-bit halves of a word);
-//   4. with cumL / cumU their prefix sums, the pooled points are
-//        v = an S value with upper rank k :  (#{x <= v}, #{s <= v}) = (cumL(k-1), k)
-//        v = largest Q sample with U = k   :                          (cumU(k),   k)
-//      (k restricted to run ends of S); every other pooled point is dominated by these two, so
+//   2. every sample x of Q finds L(x) = #{s < x} by a branchless 1+log2(C)-step binary search in LDS and
+//      looks at the key it lands on: e(x) = (s_{L+1} == x), "x ties with the run of S that starts there";
+//   3. ONE ds_add_u32 per sample builds two histograms in the halves of a word: bin L gets
+//      (1 << 16) + e(x), i.e. cntL[j] = #{x : L(x) = j} and eq[j] = #{x : x = S[j], the first key of its run};
+//   4. with cumL the prefix sum of cntL, the pooled points that can carry the maximum are, per run end k of S
+//      (s_k != s_{k+1}; k = #{s <= s_k}),
+//        v = s_k                          :  (#{x <= v}, #{s <= v}) = (cumL(k-1), k)
+//        v = the largest sample below s_{k+1} :                        (cumU(k),   k),  cumU(k) = cumL(k) - eq[k]
+//      (x < s_{k+1}  <=>  L(x) <= k and x != s_{k+1}; the samples equal to s_{k+1} are exactly eq[k], counted at
+//      the start of the next run); every other pooled point is dominated by these two, so
 //        ks_num = max_k max(|cumL(k-1)*m - k*q|, |cumU(k)*m - k*q|)
-//      is the exact integer max|c0*n1 - c1*n0| over the pooled points.
+//      is the exact integer max|c0*n1 - c1*n0| over the pooled points.  No second search for
+//      U(x) = #{s <= x} and no branch on ties in the ranking loop: tie-heavy input (3-decimal events) costs
+//      what continuous input costs.
 //      Without ties cumL == cumU and the maximum collapses to max_{k<m} max(a_k, q - a_k),
-//      a_k = cumU(k)*m - k*q: five VALU instructions per histogram bin.
+//      a_k = cumL(k)*m - k*q: five VALU instructions per histogram bin.
 // Against sorting both groups and walking the pooled sample this removes one sort and the whole sequential
 // merge: ~400 instead of ~500 VALU instructions per 200 v 200 position (rocprof SQ_INSTS_VALU).
 #pragma once
@@ -179,11 +184,11 @@ __device__ __forceinline__ void seg_sort_any(float (&x)[R], const LaneSel& sel, 
 }
 
 // branchless binary search: returns the pointer to key L (LE = false: L = #{s < x}) or key U (LE = true:
-// U = #{s <= x}); `base` points at key 0.  *col gets the pointer to row 0 of the column that holds the rank.
+// U = #{s <= x}); `base` points at key 0.
 // FULL = false: the caller knows the array holds at least one +inf pad (fewer than C real keys), so rank C cannot
 // occur and the check of the last key is skipped.
 template <int R, int LG, bool LE, bool FULL = true>
-__device__ __forceinline__ const float* ks_search(const float* base, float x, const float** col = nullptr) {
+__device__ __forceinline__ const float* ks_search(const float* base, float x) {
   using Lay = KsLayout<R, LG>;
   const float* p = base;
   bool all = false;
@@ -197,7 +202,6 @@ __device__ __forceinline__ const float* ks_search(const float* base, float x, co
     const bool right = LE ? (t <= x) : (t < x);
     p = right ? p + hc : p;
   }
-  if (col) *col = all ? base + Lay::END : p;
 #pragma unroll
   for (int h = R / 2; h >= 1; h >>= 1) {                           // down the column
     const float t = p[(h - 1) * Lay::ROW];
@@ -232,7 +236,7 @@ void ks_rank_kernel(RankStatsArgs args) {
   const int gl = lane & (LG - 1);
   const int slot = lane / LG;
   float* keys = lds_all + (wave * PW + slot) * POS_WORDS;        // sorted S of this lane's position (KsLayout)
-  unsigned* hist = reinterpret_cast<unsigned*>(keys + HIST_OFF);    // bin k: (#L == k) << 16 | (#U == k), same layout
+  unsigned* hist = reinterpret_cast<unsigned*>(keys + HIST_OFF);    // bin j: #{x : L(x) = j} << 16 | #{x : x = S[j], L(x) = j}, same layout
   const int e0 = gl * R;                                             // first key / bin this lane owns
 
   const float inf = __builtin_inff();
@@ -376,51 +380,21 @@ void ks_rank_kernel(RankStatsArgs args) {
     __builtin_amdgcn_wave_barrier();
 
     // ---- rank every Q sample into S
-    bool any_tie = false;
-    bool tie_lane = false;                     // FLAGS, "own" schedule: this lane saw a tie of its position
-    unsigned tie_coop = 0u;                    // FLAGS, "coop" schedule: bit sl = position sl of the wave saw one
-    int coop_sl = 0;
     // a sorted group that fills its capacity exactly has no +inf pad: only then can a sample rank above every key
     const bool s_full = __ballot(m == Lay::C) != 0ull;
 
-    // rank NV samples (xq) and add them to the histograms
+    // rank NV samples (xq) and count them: bin L(x) += 1 << 16, + 1 when x equals the key it landed on (key C is +inf)
     auto rank_and_count = [&](auto nv_tag, auto full_tag, const float* kbase, const float* xq) {
       constexpr int NV = decltype(nv_tag)::value;
       constexpr bool FULL = decltype(full_tag)::value;
       const float* lp[NV];
-      const float* lcol[NV];
 #pragma unroll
-      for (int e = 0; e < NV; ++e) lp[e] = ks_search<R, LG, false, FULL>(kbase, xq[e], &lcol[e]);
-      bool eq[NV];
+      for (int e = 0; e < NV; ++e) lp[e] = ks_search<R, LG, false, FULL>(kbase, xq[e]);
+      unsigned inc[NV];
 #pragma unroll
-      for (int e = 0; e < NV; ++e) eq[e] = (*lp[e] == xq[e]);                       // key C is +inf
-      if constexpr (FLAGS) {
+      for (int e = 0; e < NV; ++e) inc[e] = (*lp[e] == xq[e]) ? 0x10001u : 0x10000u;
 #pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          tie_lane = tie_lane || eq[e];
-          if (__ballot(eq[e]) != 0ull) tie_coop |= 1u << coop_sl;
-        }
-      }
-      // Per sample slot: a slot in which no lane ties with S (the usual case) adds L and U in one go; a slot with
-      // ties — common for 3-dp rounded signals and the synthetic grid — takes U = L + 1 (the next row of the
-      // column, or row 0 of the next column when L is in the last row), and only if that next key ties again
-      // (duplicates inside S) the full upper-bound search.
-#pragma unroll
-      for (int e = 0; e < NV; ++e) {
-        unsigned* bin = reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF;
-        if (__ballot(eq[e]) == 0ull) {
-          atomicAdd(bin, 0x10001u);
-        } else {
-          any_tie = true;
-          // (32-bit LDS offsets: a generic-pointer difference would be computed in 64 bits)
-          const unsigned dl = (unsigned)(uintptr_t)lp[e] - (unsigned)(uintptr_t)lcol[e];
-          const int step = (dl == (unsigned)((R - 1) * ROW * 4)) ? 1 - (R - 1) * ROW : ROW;
-          const float* up = eq[e] ? lp[e] + step : lp[e];
-          if (__ballot(*up == xq[e]) != 0ull) up = ks_search<R, LG, true, FULL>(kbase, xq[e]);
-          atomicAdd(bin, 0x10000u);
-          atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up)) + HIST_OFF, 1u);
-        }
-      }
+      for (int e = 0; e < NV; ++e) atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF, inc[e]);
     };
 
     // everything requested before the sort has arrived; from here the number of outstanding loads is known
@@ -452,7 +426,6 @@ void ks_rank_kernel(RankStatsArgs args) {
       slots = (cfull * 4 + (q - cfull * 256 + 63) / 64) * 64;        // per position: what the 64 lanes will process
 #pragma unroll 1
       for (int sl = 0; sl < PW; ++sl) {
-        coop_sl = sl;
         const int src = sl * LG;
         const int qs = __builtin_amdgcn_readlane(q, src);
         const unsigned long long sp = (unsigned long long)(uintptr_t)sig_q;
@@ -483,7 +456,7 @@ void ks_rank_kernel(RankStatsArgs args) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (gl == 0) { const unsigned extra = (unsigned)(slots - q); hist[Lay::word(m)] -= (extra << 16) + extra; }   // the FLT_MAX slots
+    if (gl == 0) { const unsigned extra = (unsigned)(slots - q); hist[Lay::word(m)] -= extra << 16; }   // the FLT_MAX slots: L = m, never equal to a key
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -492,20 +465,22 @@ void ks_rank_kernel(RankStatsArgs args) {
 #pragma unroll
     for (int r = 0; r < R - 1; ++r) h[r] = hist[(r + 1) * ROW + gl];     // bins e0 + 1 .. e0 + R - 1
     h[R - 1] = hist[gl + 1];                                              // bin e0 + R: row 0 of the next column
+    const unsigned h0 = hist[0];
     unsigned tot = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) tot += h[r];
-    const unsigned cum = seg_exscan_add_u32<LG>(tot, gl) + hist[0];      // both cumulative counts up to bin e0
+    const unsigned cum = seg_exscan_add_u32<LG>(tot, gl) + h0;           // cumL(e0) << 16 | (ties counted up to bin e0)
     unsigned best = 0;
-    // Which evaluation: the general one as soon as a sample tied with S; otherwise look for ties INSIDE S — only
-    // then, from the keys in LDS (the general path reloads them anyway): the smallest gap between neighbours is
-    // exactly 0.  Between two +inf pads the gap is NaN, which min() drops.  (A gap that underflows to 0 would only
-    // send the wave down the general path.)
+    // Which evaluation: the general one as soon as a sample tied with S (a low half of the wave's bins is not 0);
+    // otherwise look for ties INSIDE S — only then, from the keys in LDS (the general path reloads them anyway): the
+    // smallest gap between neighbours is exactly 0.  Between two +inf pads the gap is NaN, which min() drops.  (A gap
+    // that underflows to 0 would only send the wave down the general path.)
     float s_own[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) s_own[r] = keys[r * ROW + gl];
     const float s_next = keys[gl + 1];                   // key e0 + R (or the +inf sentinel)
-    bool slow = __ballot(any_tie) != 0ull;
+    const bool tie_lane = ((tot | h0) & 0xffffu) != 0u;  // a sample equal to one of this lane's keys (or to key 0)
+    bool slow = __ballot(tie_lane) != 0ull;
     if (!slow) {
       float gap = inf;
 #pragma unroll
@@ -513,17 +488,17 @@ void ks_rank_kernel(RankStatsArgs args) {
       slow = __ballot(gap == 0.0f) != 0ull;
     }
     if (!slow) {
-      // no ties in this wave: cumL == cumU; D_num = max_{k < m} max(a_k, q - a_k), a_k = cumU(k)*m - k*q.
+      // no ties in this wave: cumL == cumU; D_num = max_{k < m} max(a_k, q - a_k), a_k = cumL(k)*m - k*q.
       // Q samples above every s sit in bin m; clamping k*q at (m-1)*q and the running count at
-      // cumU(m-1) makes every bin >= m repeat a_{m-1}.
+      // cumL(m-1) makes every bin >= m repeat a_{m-1}.
       const int kq_max = __mul24(m - 1, q);                              // (24-bit operands: m <= 2 048, q <= 65 535)
       int kq = min(__mul24(e0, q), kq_max);
-      const int cmax = q - (int)(hist[Lay::word(m)] & 0xffffu);          // cumU(m-1)
-      int c = min((int)(cum & 0xffffu), cmax);
+      const int cmax = q - (int)(hist[Lay::word(m)] >> 16);              // cumL(m-1)
+      int c = min((int)(cum >> 16), cmax);
       int hi = __mul24(c, m) - kq, lo = hi;                              // bin e0 itself: a valid a_k
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        c = min(c + (int)(h[r] & 0xffffu), cmax);
+        c = min(c + (int)(h[r] >> 16), cmax);
         kq = min(kq + q, kq_max);
         const int a = __mul24(c, m) - kq;
         hi = max(hi, a);
@@ -533,11 +508,9 @@ void ks_rank_kernel(RankStatsArgs args) {
     } else {
       // general form with the run ends of S as masks
       // Pads are +inf, so "s_{k-1} != s_k" alone marks the run ends: it holds at k = m and fails for k > m.
-      // both counts stay packed (cumL << 16 | cumU: neither half exceeds q <= 65 535, so no carry crosses) and
-      // each candidate is one multiply-add against the running -k*q
-      unsigned c2 = cum;                                            // cumL(k-1) | cumU(k-1) entering bin k = e0 + 1
-      int cl = (int)(c2 >> 16);
-      int hi = (gl == 0) ? __mul24((int)(c2 & 0xffffu), m) : 0, lo = 0;     // k = 0: (cumU(0), 0)
+      int cl = (int)(cum >> 16);                                    // cumL(k-1) entering bin k = e0 + 1
+      // k = 0: (cumU(0), 0), cumU(0) = the samples below key 0 = cntL[0] - eq[0]
+      int hi = (gl == 0) ? __mul24((int)(h0 >> 16) - (int)(h0 & 0xffffu), m) : 0, lo = 0;
       int nkq = -__mul24(e0, q);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -545,10 +518,9 @@ void ks_rank_kernel(RankStatsArgs args) {
         const bool run_end = s_own[r] != up;
         nkq -= q;
         const int cand_b = __mul24(cl, m) + nkq;                   // v = the S value with upper rank k: cumL(k-1)*m - k*q
-        c2 += h[r];
-        const int cu = (int)(c2 & 0xffffu);
-        cl = (int)(c2 >> 16);
-        const int cand_a = __mul24(cu, m) + nkq;                   // v = largest Q sample with U = k: cumU(k)*m - k*q
+        cl += (int)(h[r] >> 16);                                   // cumL(k)
+        const int cu = cl - (int)(h[r] & 0xffffu);                 // cumU(k) = cumL(k) - #{x = s_{k+1}}
+        const int cand_a = __mul24(cu, m) + nkq;                   // v = the largest sample below s_{k+1}: cumU(k)*m - k*q
         const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
         hi = max(hi, max(ca, cb));
         lo = min(lo, min(ca, cb));
@@ -558,7 +530,7 @@ void ks_rank_kernel(RankStatsArgs args) {
     best = seg_allmax_u32<LG>(best);
     if (valid && gl == 0) args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;
     if constexpr (FLAGS) {
-      const unsigned t = coop ? ((tie_coop >> slot) & 1u) : seg_allmax_u32<LG>(tie_lane ? 1u : 0u);
+      const unsigned t = seg_allmax_u32<LG>(tie_lane ? 1u : 0u);   // a sample of Q tied with a key of S anywhere in the position
       if (valid && gl == 0) args.tied[pos] = (uint8_t)t;
     }
     __builtin_amdgcn_wave_barrier();

@@ -2,19 +2,21 @@
 // (tests mask = MWU | Welch | KS: what getKStest computes for every position, myDetect.py:327-343).
 //
 // Same skeleton as the KS-only kernel (ks_rank.hpp): the smaller group S (m samples) is sorted in registers and
-// written to wave-private LDS, every sample x of the other group Q (q samples) finds L = #{s < x} and
-// U = #{s <= x} by binary search, and one LDS atomic per sample builds the histograms of L and U.  With
-// cumL / cumU their prefix sums everything the three tests need follows without sorting Q against S:
+// written to wave-private LDS, every sample x of the other group Q (q samples) finds L = #{s < x} by binary search
+// and looks whether the key it lands on equals it, and one LDS atomic per sample builds the histograms
+// cntL[j] = #{x : L(x) = j} and eq[j] = #{x : x = S[j], the first key of its run}.  With cumL the prefix sum of cntL
+// everything the three tests need follows without sorting Q against S:
 //   * KS          exact integer max |c0 n1 - c1 n0| over the pooled points from the two candidates per run end
-//                 k of S, (cumL(k-1), k) and (cumU(k), k)  (derivation: ks_rank.hpp).  ks_2samp forms D as
-//                 max |fl(c0/n0) - fl(c1/n1)|; a larger integer numerator always gives a larger float value
-//                 (they differ by >= 1/(n0 n1) >> ulp), so the float form is evaluated ONLY for the candidates
-//                 that reach the integer maximum — the maximum of those is the reference's D bit for bit.
-//   * Mann-Whitney sum_{x in Q} (L(x) + U(x)) = sum_{k=1..C} (2q - cumL(k-1) - cumU(k-1))   [Abel summation]
-//                 = sum_{a in group 1} (#{b < a} + #{b <= a}) when Q is group 1, and 2mq minus it when Q is group 2.
+//                 k of S, (cumL(k-1), k) and (cumU(k), k), cumU(k) = cumL(k) - eq[k]  (derivation: ks_rank.hpp).
+//                 ks_2samp forms D as max |fl(c0/n0) - fl(c1/n1)|; a larger integer numerator always gives a larger
+//                 float value (they differ by >= 1/(n0 n1) >> ulp), so the float form is evaluated ONLY for the
+//                 candidates that reach the integer maximum — the maximum of those is the reference's D bit for bit.
+//   * Mann-Whitney sum_{x in Q} (L(x) + U(x)), U = #{s <= x}:  sum L = sum_{j<C} (q - cumL(j))  [Abel summation] and
+//                 U(x) - L(x) = the length a of the run of S that x ties with, so sum (L + U) = 2 sum L + sum_runs a b,
+//                 b = eq[start of the run] = the samples of Q equal to it.  This is
+//                 sum_{a in group 1} (#{b < a} + #{b <= a}) when Q is group 1, and 2mq minus it when Q is group 2.
 //   * tie term    sum over pooled tie groups of t^3 - t = 3 pp(S) + 3 pp(Q) + 3 sum_{runs of S tied with Q} a b (a + b),
-//                 pp(X) = sum over the elements of X of p (p - 1), p = place of the element in its run of equal keys;
-//                 a = length of the run of S, b = cumL(k-1) - cumU(k-1) at its end k = the samples of Q equal to it.
+//                 pp(X) = sum over the elements of X of p (p - 1), p = place of the element in its run of equal keys.
 //   * Welch       fp64 shifted one-pass moments of both groups on the way (S from the registers before the sort,
 //                 Q as its samples stream through the ranking rounds).
 // pp(S) comes from the sorted registers.  pp(Q) needs equal samples of Q next to each other, but not a second
@@ -209,7 +211,7 @@ void rank_hist_kernel(RankStatsArgs args) {
   const int gl = lane & (LG - 1);
   const int slot = lane / LG;
   float* keys = lds_all + (wave * PW + slot) * POS_WORDS;        // sorted S of this lane's position (KsLayout)
-  unsigned* hist = reinterpret_cast<unsigned*>(keys + HIST_OFF);    // bin k: (#L == k) << 16 | (#U == k); later the prefix table
+  unsigned* hist = reinterpret_cast<unsigned*>(keys + HIST_OFF);    // bin j: cntL[j] << 16 | eq[j]; later the prefix table
 
   const float inf = __builtin_inff();
   const float big = 3.4028234663852886e38f;
@@ -340,7 +342,6 @@ void rank_hist_kernel(RankStatsArgs args) {
 
     // ---- rank every Q sample into S and count it in the histograms; keep the sample and the LDS byte offset of its
     // L-bin inside the position's words (16 bits, two per register) for the scatter
-    bool any_tie = false;
     constexpr int NXS = WIDE ? 1 : R, NLA = WIDE ? 1 : R / 2;
     float xs[NXS];                                 // the samples this lane ranked (FLT_MAX where it had none)
     unsigned la[NLA];                              // byte offsets of their L-bins from `keys`
@@ -350,33 +351,20 @@ void rank_hist_kernel(RankStatsArgs args) {
     for (int r = 0; r < NLA; ++r) la[r] = 0u;
 
     // rank NV samples: all the searches first (independent chains of LDS reads that the scheduler interleaves), then
-    // the histogram updates.  Per sample slot: a slot in which no lane ties with S adds L and U in one go; a slot with
-    // ties takes U = L + 1 key and only if that key ties again (duplicates inside S) the full upper-bound search.
+    // the histogram updates: bin L(x) += 1 << 16, + 1 when x equals the key it landed on (ks_rank.hpp) — no second
+    // search and no branch on ties
     auto rank_many = [&](auto nv_tag, const float* xq, bool have, unsigned* ad) {
       constexpr int NV = decltype(nv_tag)::value;
       const float* lp[NV];
-      const float* lcol[NV];
 #pragma unroll
-      for (int e = 0; e < NV; ++e) lp[e] = ks_search<R, LG, false, true>(keys, xq[e], &lcol[e]);
-      bool eq[NV];
+      for (int e = 0; e < NV; ++e) lp[e] = ks_search<R, LG, false, true>(keys, xq[e]);
+      unsigned inc[NV];
 #pragma unroll
-      for (int e = 0; e < NV; ++e) eq[e] = (*lp[e] == xq[e]);
+      for (int e = 0; e < NV; ++e) inc[e] = (*lp[e] == xq[e]) ? 0x10001u : 0x10000u;
 #pragma unroll
       for (int e = 0; e < NV; ++e) {
         unsigned* bin = reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF;
-        if (__ballot(eq[e]) == 0ull) {
-          if (have) atomicAdd(bin, 0x10001u);
-        } else {
-          any_tie = true;
-          const unsigned dl = (unsigned)(uintptr_t)lp[e] - (unsigned)(uintptr_t)lcol[e];
-          const int step = (dl == (unsigned)((R - 1) * ROW * 4)) ? 1 - (R - 1) * ROW : ROW;
-          const float* up = eq[e] ? lp[e] + step : lp[e];
-          if (__ballot(*up == xq[e]) != 0ull) up = ks_search<R, LG, true, true>(keys, xq[e]);
-          if (have) {
-            atomicAdd(bin, 0x10000u);
-            atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(up)) + HIST_OFF, 1u);
-          }
-        }
+        if (have) atomicAdd(bin, inc[e]);
         ad[e] = (unsigned)(uintptr_t)bin - (unsigned)(uintptr_t)keys;      // byte offset inside the position's LDS (< 64 KB)
       }
     };
@@ -531,12 +519,12 @@ void rank_hist_kernel(RankStatsArgs args) {
     const int e02 = gl2 * R;
 
     // ---- one pass over the lane's bins: histograms -> prefix table in their place (bin k gets
-    // cumL(k-1) << 16 | (a run of S ends at k) << 15 | cumU(k-1): the scatter's bases and the float-form pass read it),
+    // cumL(k-1) << 16 | (a run of S ends at k) << 15 | cumU(k): the scatter's bases and the float-form pass read it),
     // and on the way the KS numerator, the Mann-Whitney sum and the ties between S and Q
     unsigned cum;
     int maxc;
     unsigned best;
-    unsigned acc_l = 0, acc_u = 0, ab3 = 0;
+    unsigned acc_l = 0, ab1 = 0, ab3 = 0;
     unsigned long long ab3w = 0ull;                // WIDE: a b (a + b) can pass 2^32 (256 keys tied with 4 096 samples)
     {
       unsigned h[R];
@@ -551,40 +539,46 @@ void rank_hist_kernel(RankStatsArgs args) {
       unsigned tot = 0, hmax = h0;
 #pragma unroll
       for (int r = 0; r < R; ++r) { tot += h[r]; hmax = max(hmax, h[r]); }
-      cum = seg_exscan_add_u32<LG>(tot, gl2) + h0;                           // cumL(e02) << 16 | cumU(e02)
+      cum = seg_exscan_add_u32<LG>(tot, gl2) + h0;                           // cumL(e02) << 16 | (ties counted up to bin e02)
       maxc = (int)(wave_max_u32(hmax) >> 16);                               // fullest L-bin of the wave's positions
-      // start of the run of S that is open when the lane's first bin begins (only read where Q ties with S)
-      int start = 0;
-      if (__ballot(any_tie) != 0ull) {
+      // the run of S that is open when the lane's first bin begins: its start and the samples of Q equal to it (only
+      // needed where Q ties with S: a low half of the wave's bins is not 0)
+      int start = 0, brun = (int)(h0 & 0xffffu);
+      if (__ballot(((tot | h0) & 0xffffu) != 0u) != 0ull) {
         int ls = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) ls = (sk[r] != sk[r + 1]) ? (e02 + r + 1) : ls;   // a run ends at key e02 + r: the next starts at e02 + r + 1
         const int bias = (LG == 8 && (lane & 8)) ? C + 1 : 0;
         int sc = lane_prev_i(seg_scan_max_i32<LG>(ls + bias), 0) - bias;
         start = (gl2 == 0 || sc < 0) ? 0 : sc;
+        brun = (int)(hist[Lay::word(start)] & 0xffffu);                      // (read before the table overwrites the bins)
       }
-      unsigned c2 = cum;
-      int cl = (int)(c2 >> 16), cu = (int)(c2 & 0xffffu);                   // cumL(k-1), cumU(k-1) entering bin k = e02 + 1
-      int hi = (gl2 == 0) ? __mul24(cu, m) : 0, lo = 0;                     // k = 0: (cumU(0), 0)
+      int cl = (int)(cum >> 16);                                             // cumL(k-1) entering bin k = e02 + 1
+      // k = 0: (cumU(0), 0), cumU(0) = the samples below key 0 = cntL[0] - eq[0]
+      int hi = (gl2 == 0) ? __mul24((int)(h0 >> 16) - (int)(h0 & 0xffffu), m) : 0, lo = 0;
       int nkq = -__mul24(e02, q);
 #pragma unroll
       for (int r = 0; r < R; ++r) {                                          // bin k = e02 + r + 1
         const bool run_end = sk[r] != sk[r + 1];
-        const unsigned w = c2 | (run_end ? 0x8000u : 0u);
-        if (r < R - 1) hist[(r + 1) * ROW + gl2] = w; else hist[gl2 + 1] = w;
         const int k = e02 + r + 1;
         nkq -= q;
-        acc_l += (unsigned)cl; acc_u += (unsigned)cu;
+        acc_l += (unsigned)cl;
         const int cand_b = __mul24(cl, m) + nkq;                             // (cumL(k-1), k)
-        const int b = run_end ? cl - cu : 0;                                 // samples of Q equal to the run of S ending at k
-        const int a = k - start;
-        if constexpr (WIDE) ab3w += (unsigned long long)(unsigned)__mul24(a, b) * (unsigned long long)(unsigned)(a + b);
-        else ab3 += (unsigned)__mul24(__mul24(a, b), a + b);
-        start = run_end ? k : start;
-        c2 += h[r];
-        cu = (int)(c2 & 0xffffu);
-        cl = (int)(c2 >> 16);
+        const unsigned wl = (unsigned)cl << 16;
+        const int eqk = (int)(h[r] & 0xffffu);                               // samples of Q equal to key k (a run start, or 0)
+        cl += (int)(h[r] >> 16);                                             // cumL(k)
+        const int cu = cl - eqk;                                             // cumU(k)
+        const unsigned w = wl | (run_end ? 0x8000u : 0u) | (unsigned)cu;
+        if (r < R - 1) hist[(r + 1) * ROW + gl2] = w; else hist[gl2 + 1] = w;
         const int cand_a = __mul24(cu, m) + nkq;                             // (cumU(k), k)
+        const int b = run_end ? brun : 0;                                    // samples of Q equal to the run of S ending at k
+        const int a = k - start;
+        const unsigned t = (unsigned)__mul24(a, b);
+        ab1 += t;
+        if constexpr (WIDE) ab3w += (unsigned long long)t * (unsigned long long)(unsigned)(a + b);
+        else ab3 += (unsigned)__mul24((int)t, a + b);
+        start = run_end ? k : start;
+        brun = run_end ? eqk : brun;
         const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
         hi = max(hi, max(ca, cb));
         lo = min(lo, min(ca, cb));
@@ -594,7 +588,7 @@ void rank_hist_kernel(RankStatsArgs args) {
       best = (unsigned)max(hi, -lo);
       // (finished HERE: left to the scheduler, the tie and rank sums sink to the end of the item and keep the 32
       // per-bin counts they are built from in registers across the scatter, the float-form pass and the clean-up)
-      asm volatile("" : "+v"(ab3), "+v"(acc_l), "+v"(acc_u), "+v"(best));
+      asm volatile("" : "+v"(ab3), "+v"(acc_l), "+v"(ab1), "+v"(best));
       if constexpr (WIDE) asm volatile("" : "+v"(ab3w));
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -681,17 +675,18 @@ void rank_hist_kernel(RankStatsArgs args) {
 #if (NMOD_SKIP & 2)
       mine = 0;
 #endif
-      // the candidate (cumU(0), 0) belongs to lane 0 of the position
+      // the candidate (cumU(0), 0) belongs to lane 0 of the position: bin 0's table word was cleared, its counts are
+      // what `cum` of lane 0 started from
       if (gl2 == 0 && (mine & (Mine)1)) {
-        const int cu0 = (int)(cum & 0xffffu);
+        const int cu0 = (int)(cum >> 16) - (int)(cum & 0xffffu);
         if ((unsigned)__mul24(cu0, mo) == best) dmax = hist_exact_quot(cu0, dq, rq);
       }
-      // word offsets of the table entries of bins k - 1, k, k + 1 (k = hl * R + rr + 1) for hl = 0
-      int wofs[(R + LG - 1) / LG][3];
+      // word offsets of the table entries of bins k - 1 and k (k = hl * R + rr + 1) for hl = 0
+      int wofs[(R + LG - 1) / LG][2];
 #pragma unroll
       for (int j = 0; j < (R + LG - 1) / LG; ++j) {
         const int rr = gl2 + j * LG;
-        wofs[j][0] = Lay::word(rr); wofs[j][1] = Lay::word(rr + 1); wofs[j][2] = Lay::word(rr + 2);
+        wofs[j][0] = Lay::word(rr); wofs[j][1] = Lay::word(rr + 1);
       }
 #pragma unroll 1
       while (__ballot(mine != (Mine)0) != 0ull) {
@@ -706,9 +701,8 @@ void rank_hist_kernel(RankStatsArgs args) {
           // (lane hl's bins are one column to the right per unit of hl: + hl words)
           const unsigned wp = hist[wofs[j][0] + hl];
           const unsigned w = hist[wofs[j][1] + hl];
-          const unsigned wn = (k < C) ? hist[wofs[j][2] + hl] : (unsigned)qo;
           // (after the scatter the high half of word k - 1 is cumL(k - 1); WIDE has no scatter: word k still holds it)
-          const int cl = (int)((WIDE ? w : wp) >> 16), cu = (int)(wn & 0x7fffu);
+          const int cl = (int)((WIDE ? w : wp) >> 16), cu = (int)(w & 0x7fffu);
           const bool run_end = (w & 0x8000u) != 0u;
           const int nkq = -__mul24(k, qo);
           const int cand_b = __mul24(cl, mo) + nkq, cand_a = __mul24(cu, mo) + nkq;
@@ -763,10 +757,10 @@ void rank_hist_kernel(RankStatsArgs args) {
       AB = pos_allsum_u32<LG>(ab3);
     }
     const unsigned AL = pos_allsum_u32<LG>(acc_l);
-    const unsigned AU = pos_allsum_u32<LG>(acc_u);
+    const unsigned A1 = pos_allsum_u32<LG>(ab1);
     if (valid && gl2 == 0) {
-      // sum_{x in Q} (L + U) = sum_{k=1..C} (2q - cumL(k-1) - cumU(k-1))
-      const unsigned long long slu = 2ull * (unsigned long long)C * (unsigned long long)q - (unsigned long long)AL - (unsigned long long)AU;
+      // sum_{x in Q} (L + U) = 2 sum_{j<C} (q - cumL(j)) + sum_runs a b
+      const unsigned long long slu = 2ull * ((unsigned long long)C * (unsigned long long)q - (unsigned long long)AL) + (unsigned long long)A1;
       // mwu_s = sum_{a in group 1} (#{b < a} + #{b <= a}): Q is group 1 when swapped, else count from group 2's side
       args.mwu_s[pos] = swap ? slu : 2ull * (unsigned long long)m * (unsigned long long)q - slu;
       args.tie[pos] = 3ull * PP + 3ull * AB;

@@ -15,10 +15,10 @@ import oracle_c                     # noqa: E402
 import helpers as H                 # noqa: E402
 
 L = nm._lib
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-master = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
-for it in range(rounds):
-    rng = np.random.default_rng(master.integers(1 << 62))
+
+
+def run_round(rng):
+    """one random batch through the HIP path (both test masks) against the oracle; returns a description"""
     hi0 = int(rng.choice([3, 8, 40, 64, 65, 130, 260, 600, 1100, 2048, 2500, 9000]))
     hi1 = int(rng.choice([3, 8, 40, 64, 65, 130, 260, 600, 1100, 2048, 2500, 9000]))
     lo0 = int(rng.integers(1, hi0 + 1)) if rng.random() < 0.5 else 1
@@ -63,5 +63,16 @@ for it in range(rounds):
     H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
     H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
     H.assert_close_p(ks['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
-    print('round %d ok: npos %d sizes [%d..%d] x [%d..%d] %s nb %d %s identical %d' % (it, npos, lo0, hi0, lo1, hi1, mode, nb, method, ident.sum()), flush=True)
-print('fuzz ok')
+    return 'npos %d sizes [%d..%d] x [%d..%d] %s nb %d %s identical %d' % (npos, lo0, hi0, lo1, hi1, mode, nb, method, ident.sum())
+
+
+def run(rounds, seed=12345, log=print):
+    master = np.random.default_rng(seed)
+    for it in range(rounds):
+        log('round %d ok: %s' % (it, run_round(np.random.default_rng(master.integers(1 << 62)))))
+
+
+if __name__ == '__main__':
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 12345,
+        log=lambda m: print(m, flush=True))
+    print('fuzz ok')

@@ -107,3 +107,26 @@ def synth_ref(seed, pos_begin, npos, group, n_per_pos, plant_period=0, plant_shi
     if dtype == 'i16':
         return np.rint(v * np.float32(1000.0)).astype(np.int16).reshape(-1)
     return v.reshape(-1)
+
+
+# ---- placeholder read files for the FAST5 ingest ((f)2): one .npz per read with what the HDF5 reader would return
+def write_placeholder_reads(root, group):
+    """the reads of tests/golden/fast5_reads.npz (made by oracle/gen_golden.py; the reference's own ReadAllFast5 was run
+    over the same reads through a stub h5py) as files under root/grp<group>/, in the fixture's folder layout"""
+    z = np.load(os.path.join(GOLDEN, 'fast5_reads.npz'))
+    for i in np.flatnonzero(z['group'] == group):
+        path = os.path.join(root, 'grp%d' % group, str(z['rel'][i]))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        a, b = z['off'][i], z['off'][i + 1]
+        with open(path, 'wb') as f:
+            np.savez(f, chrom=z['chrom'][i], strand=z['strand'][i], start=z['start'][i], norm_mean=z['norm_mean'][a:b],
+                     base=z['base'][a:b], has_align=z['has_align'][i])
+    return os.path.join(root, 'grp%d' % group)
+
+
+def placeholder_reader(path):
+    """stands in for fast5_ingest.h5py_reader (h5py is not in this image): same return value, None without alignment"""
+    r = np.load(path)
+    if not bool(r['has_align']):
+        return None
+    return str(r['chrom']), int(r['start']), str(r['strand']), r['norm_mean'], r['base']

@@ -849,3 +849,47 @@ def test_synth_fill_csr_matches_the_numpy_restatement(nm):
             ref = H.synth_ref(77, begin, P, g, nmax, 10000, 0.8, dtype=name).reshape(P, nmax)
             exp = np.concatenate([ref[i, :sizes[i]] for i in range(P)])
             assert np.array_equal(out.cpu().numpy(), exp), (name, g)
+
+
+@pytest.mark.parametrize('method', ['stouffer', 'ks'])
+def test_cli_detect_on_read_folders_through_an_injected_reader(nm, method, capsys):
+    """(f)2 as far as the image allows (h5py absent): `cli detect` on two FOLDERS of placeholder read files — walk,
+    min_lr filter, strand-aware position mapping, CSR build, HIP kernels, table — through `--fast5Reader`, against
+    (a) the table of the same reads handed over as .npz containers and (b) the oracle run on what the reference's
+    own ReadAllFast5 built from these reads (tests/golden/fast5_expected_g*.npz)."""
+    from nanomod_amd import cli, container, fast5_ingest
+    import nanomod_amd.detect as D
+    with tempfile.TemporaryDirectory() as tmp:
+        dirs = [H.write_placeholder_reads(tmp, g) for g in (0, 1)]
+        common = ['--FileID', 'x', '--testMethod', method, '--topN', '5', '--outLevel', '3', '--MinCoverage', '5']
+        rc = cli.main(['detect', '--wrkBase1', dirs[0], '--wrkBase2', dirs[1], '--outFolder', os.path.join(tmp, 'a'),
+                       '--fast5Reader', 'helpers:placeholder_reader'] + common)
+        assert rc == 0
+        got = open(os.path.join(tmp, 'a', 'x_sign_test.txt')).read()
+        # (a) the container path on the same reads
+        paths = []
+        for g in (0, 1):
+            c = fast5_ingest.ingest_folder(dirs[g], {'min_lr': 500, 'min_lr_nb': 0}, H.placeholder_reader, log=lambda *a: None)
+            paths.append(os.path.join(tmp, 'g%d.npz' % g))
+            container.save_group(paths[-1], c['chrom'], c['strand'], c['pos'], c['base'], c['off'], c['sig'])
+        rc = cli.main(['detect', '--wrkBase1', paths[0], '--wrkBase2', paths[1], '--outFolder', os.path.join(tmp, 'b')] + common)
+        assert rc == 0
+        assert got == open(os.path.join(tmp, 'b', 'x_sign_test.txt')).read()
+    assert got.count('\n') > 1000
+    # (b) the oracle on the reference reader's view of the same reads
+    import nanomod_oracle as orc
+    e0, e1 = (dict(np.load(os.path.join(H.GOLDEN, 'fast5_expected_g%d.npz' % g))) for g in (0, 1))
+    meta, sig0, off0, sig1, off1, rid = cli.select_positions(e0, e1, 5, 3, lambda *a: None)
+    s0 = np.asarray(sig0, dtype=np.float64) * (1e-3 if np.asarray(sig0).dtype == np.int16 else 1.0)
+    s1 = np.asarray(sig1, dtype=np.float64) * (1e-3 if np.asarray(sig1).dtype == np.int16 else 1.0)
+    mcode = {'ks': orc.METHOD_KS, 'stouffer': orc.METHOD_STOUFFER}[method]
+    out = orc.detect_batch(s0, off0, s1, off1, rid, 2, 2.0, mcode)
+    lines = []
+    for i in range(len(rid)):
+        rec = [(out['mwu_u'][i], out['mwu_p'][i]), (out['t_t'][i], out['t_p'][i]), (out['ks_d'][i], out['ks_p'][i])]
+        if method != 'ks':
+            rec.append((out['comb_st'][i], out['comb_p'][i]))
+        lines.append(orc.format_sign_test_line(str(meta['chrom'][i]), str(meta['strand'][i]), int(meta['pos'][i]), str(meta['base'][i]),
+                                               int(meta['n0'][i]), int(meta['n1'][i]), rec, method != 'ks'))
+    assert got == ''.join(lines)
+    capsys.readouterr()

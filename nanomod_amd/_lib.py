@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnanomod_hip.so')
+# (NMOD_HIP_LIB: another build of the same library, for A/B measurements of kernel variants on one box)
+LIB_PATH = os.environ.get('NMOD_HIP_LIB') or os.path.join(_HERE, 'libnanomod_hip.so')
 
 NMOD_ABI_VERSION = 1
 DTYPE_F32, DTYPE_I16_MILLI, DTYPE_F64 = 0, 1, 2

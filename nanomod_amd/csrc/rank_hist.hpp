@@ -527,66 +527,94 @@ void rank_hist_kernel(RankStatsArgs args) {
     unsigned acc_l = 0, ab1 = 0, ab3 = 0;
     unsigned long long ab3w = 0ull;                // WIDE: a b (a + b) can pass 2^32 (256 keys tied with 4 096 samples)
     {
-      unsigned h[R];
-#pragma unroll
-      for (int r = 0; r < R - 1; ++r) h[r] = hist[(r + 1) * ROW + gl2];     // bins e02 + 1 .. e02 + R - 1
-      h[R - 1] = hist[gl2 + 1];                                              // bin e02 + R: row 0 of the next column
+      // first the totals of the lane's bins e02 + 1 .. e02 + R (bin e02 + R: row 0 of the next column).  Nothing of this
+      // pass is kept: the sweep below reads bins and keys again, four at a time — both arrays in registers next to
+      // the samples and bin offsets kept for the scatter did not fit 128 VGPRs
       const unsigned h0 = hist[0];
-      float sk[R + 1];
-#pragma unroll
-      for (int r = 0; r < R; ++r) sk[r] = keys[r * ROW + gl2];              // keys e02 .. e02 + R - 1
-      sk[R] = keys[gl2 + 1];                                                // key e02 + R (or the +inf sentinel)
       unsigned tot = 0, hmax = h0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) { tot += h[r]; hmax = max(hmax, h[r]); }
+      for (int r = 0; r < R; ++r) {
+        const unsigned v = (r < R - 1) ? hist[(r + 1) * ROW + gl2] : hist[gl2 + 1];
+        tot += v; hmax = max(hmax, v);
+      }
       cum = seg_exscan_add_u32<LG>(tot, gl2) + h0;                           // cumL(e02) << 16 | (ties counted up to bin e02)
       maxc = (int)(wave_max_u32(hmax) >> 16);                               // fullest L-bin of the wave's positions
       // the run of S that is open when the lane's first bin begins: its start and the samples of Q equal to it (only
       // needed where Q ties with S: a low half of the wave's bins is not 0)
       int start = 0, brun = (int)(h0 & 0xffffu);
-      if (__ballot(((tot | h0) & 0xffffu) != 0u) != 0ull) {
+      const bool wave_ties = __ballot(((tot | h0) & 0xffffu) != 0u) != 0ull;
+      if (wave_ties) {
         int ls = 0;
+        float kp = keys[gl2];
 #pragma unroll
-        for (int r = 0; r < R; ++r) ls = (sk[r] != sk[r + 1]) ? (e02 + r + 1) : ls;   // a run ends at key e02 + r: the next starts at e02 + r + 1
+        for (int r = 0; r < R; ++r) {
+          const float kn = (r < R - 1) ? keys[(r + 1) * ROW + gl2] : keys[gl2 + 1];
+          ls = (kp != kn) ? (e02 + r + 1) : ls;                              // a run ends at key e02 + r: the next starts at e02 + r + 1
+          kp = kn;
+        }
         const int bias = (LG == 8 && (lane & 8)) ? C + 1 : 0;
         int sc = lane_prev_i(seg_scan_max_i32<LG>(ls + bias), 0) - bias;
         start = (gl2 == 0 || sc < 0) ? 0 : sc;
         brun = (int)(hist[Lay::word(start)] & 0xffffu);                      // (read before the table overwrites the bins)
       }
+      __builtin_amdgcn_sched_barrier(0);
       int cl = (int)(cum >> 16);                                             // cumL(k-1) entering bin k = e02 + 1
       // k = 0: (cumU(0), 0), cumU(0) = the samples below key 0 = cntL[0] - eq[0]
       int hi = (gl2 == 0) ? __mul24((int)(h0 >> 16) - (int)(h0 & 0xffffu), m) : 0, lo = 0;
       int nkq = -__mul24(e02, q);
+      float kprev = keys[gl2];                                               // key e02
+      constexpr int CH = (R >= 4) ? 4 : R;                                    // bins per chunk
 #pragma unroll
-      for (int r = 0; r < R; ++r) {                                          // bin k = e02 + r + 1
-        const bool run_end = sk[r] != sk[r + 1];
-        const int k = e02 + r + 1;
-        nkq -= q;
-        acc_l += (unsigned)cl;
-        const int cand_b = __mul24(cl, m) + nkq;                             // (cumL(k-1), k)
-        const unsigned wl = (unsigned)cl << 16;
-        const int eqk = (int)(h[r] & 0xffffu);                               // samples of Q equal to key k (a run start, or 0)
-        cl += (int)(h[r] >> 16);                                             // cumL(k)
-        const int cu = cl - eqk;                                             // cumU(k)
-        const unsigned w = wl | (run_end ? 0x8000u : 0u) | (unsigned)cu;
-        if (r < R - 1) hist[(r + 1) * ROW + gl2] = w; else hist[gl2 + 1] = w;
-        const int cand_a = __mul24(cu, m) + nkq;                             // (cumU(k), k)
-        const int b = run_end ? brun : 0;                                    // samples of Q equal to the run of S ending at k
-        const int a = k - start;
-        const unsigned t = (unsigned)__mul24(a, b);
-        ab1 += t;
-        if constexpr (WIDE) ab3w += (unsigned long long)t * (unsigned long long)(unsigned)(a + b);
-        else ab3 += (unsigned)__mul24((int)t, a + b);
-        start = run_end ? k : start;
-        brun = run_end ? eqk : brun;
-        const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
-        hi = max(hi, max(ca, cb));
-        lo = min(lo, min(ca, cb));
-        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);                // (bounds the number of comparison masks alive at once)
+      for (int r0 = 0; r0 < R; r0 += CH) {
+        // the chunk's bins and keys, requested together and pinned here: one LDS round trip per chunk
+        unsigned hc[CH]; float kc[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const int r = r0 + j;
+          hc[j] = (r < R - 1) ? hist[(r + 1) * ROW + gl2] : hist[gl2 + 1];
+          kc[j] = (r < R - 1) ? keys[(r + 1) * ROW + gl2] : keys[gl2 + 1]; // key k (or the +inf sentinel)
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) asm volatile("" : "+v"(hc[j]), "+v"(kc[j]));
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {                                       // bin k = e02 + r + 1, the boundary between keys k - 1 and k
+          const int r = r0 + j;
+          const unsigned hr = hc[j];
+          const float knext = kc[j];
+          const bool run_end = kprev != knext;
+          kprev = knext;
+          const int k = e02 + r + 1;
+          nkq -= q;
+          acc_l += (unsigned)cl;
+          const int cand_b = __mul24(cl, m) + nkq;                           // (cumL(k-1), k)
+          const unsigned wl = (unsigned)cl << 16;
+          const int eqk = (int)(hr & 0xffffu);                               // samples of Q equal to key k (a run start, or 0)
+          cl += (int)(hr >> 16);                                             // cumL(k)
+          const int cu = cl - eqk;                                           // cumU(k)
+          const unsigned w = wl | (run_end ? 0x8000u : 0u) | (unsigned)cu;
+          if (r < R - 1) hist[(r + 1) * ROW + gl2] = w; else hist[gl2 + 1] = w;
+          const int cand_a = __mul24(cu, m) + nkq;                           // (cumU(k), k)
+          const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
+          hi = max(hi, max(ca, cb));
+          lo = min(lo, min(ca, cb));
+          // the ties of the run of S that ends at k with the `brun` samples of Q equal to it: a wave-uniform branch,
+          // taken for the few boundaries where some lane closes a tied run
+          if (wave_ties && __ballot(run_end && brun != 0) != 0ull) {
+            const int b = run_end ? brun : 0;
+            const int a = k - start;
+            const unsigned t = (unsigned)__mul24(a, b);
+            ab1 += t;
+            if constexpr (WIDE) ab3w += (unsigned long long)t * (unsigned long long)(unsigned)(a + b);
+            else ab3 += (unsigned)__mul24((int)t, a + b);
+          }
+          start = run_end ? k : start;
+          brun = run_end ? eqk : brun;
+        }
+        __builtin_amdgcn_sched_barrier(0);                                  // (bounds what is alive at once: four bins and keys)
       }
       if (gl2 == 0) hist[0] = 0u;                                            // bin 0: nothing before it
       best = (unsigned)max(hi, -lo);
-      // (finished HERE: left to the scheduler, the tie and rank sums sink to the end of the item and keep the 32
+      // (finished HERE: left to the scheduler, the tie and rank sums sink to the end of the item and keep the
       // per-bin counts they are built from in registers across the scatter, the float-form pass and the clean-up)
       asm volatile("" : "+v"(ab3), "+v"(acc_l), "+v"(ab1), "+v"(best));
       if constexpr (WIDE) asm volatile("" : "+v"(ab3w));

@@ -177,6 +177,11 @@ __device__ __forceinline__ double hist_exact_quot(int c, double n, double r) {
 // at least twice the samples it can receive.  A Q of 2 049 .. 4 096 samples (classes kWideBigBase + class of S) takes the
 // 4 096-slot table twice: the values are split by one more hash bit and Q is streamed once per half.
 constexpr unsigned kWideEmpty = 0xffffffffu;
+#ifndef NMOD_WIDE_PROBES
+#define NMOD_WIDE_PROBES 2
+#endif
+constexpr int kWideProbes = NMOD_WIDE_PROBES;      // steps of a walk before the sample is deferred
+constexpr int kWideList = 128;                     // words of the deferred list: < 64 waiting + <= 64 of one sample slot
 __host__ __device__ constexpr int wide_slots(int cq) { return 128 << cq; }
 
 template <int R, int LG, int DTYPE, bool WIDE = false>
@@ -202,7 +207,7 @@ void rank_hist_kernel(RankStatsArgs args) {
     }
   }
   const int wslots = WIDE ? (1 << wide_log) : 0;
-  const int POS_WORDS = BIN_WORDS + wslots;                                        // WIDE: the table behind them (16-byte aligned)
+  const int POS_WORDS = BIN_WORDS + wslots + (WIDE ? kWideList : 0);               // WIDE: the table and the deferred list behind them (16-byte aligned)
   constexpr int HIST_OFF = Lay::REGION;        // words from key 0 to bin 0
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
 
@@ -375,43 +380,77 @@ void rank_hist_kernel(RankStatsArgs args) {
       unsigned* ht = reinterpret_cast<unsigned*>(keys) + BIN_WORDS;
       const float kqf = (q > 0) ? (float)rk : 0.0f;
       const double KQ = (double)kqf;
-      // insert NV samples into the multiset table; `dup` = earlier copies of the sample's key passed on the way
+      // The multiset table: an arrival walks its value's double-hashing sequence (start and odd step from the value
+      // alone, so every copy of a value walks the same slots) past all earlier copies to the first empty slot; `dup` =
+      // the copies it passed, it is the (dup + 1)-th of its value.  A wave pays for the LONGEST walk of its lanes, so the
+      // walks are cut after kWideProbes steps: a sample that has not found its slot by then is put on a list in LDS and
+      // starts again later, 64 deferred samples at a time, one per lane, to the end of their walks.  (Each copy of a
+      // value still gets its own place p in 1..b whatever the order of arrival, so the sum of p (p - 1) is the same.)
+      unsigned* lst = ht + wslots;                   // the deferred samples (kWideList words)
+      int lcnt = 0;                                  // how many (the same in every lane)
+      const unsigned mask = (unsigned)(wslots - 1);
+      auto walk_to_end = [&](unsigned bits, bool act) {
+        const unsigned hsh = bits * 2654435761u;
+        unsigned hh = hsh >> (32 - wide_log);
+        const unsigned st = (hsh >> 6) | 1u;
+        unsigned dup = 0u;
+        while (__ballot(act) != 0ull) {
+          const unsigned old = atomicCAS(&ht[hh], kWideEmpty, act ? bits : kWideEmpty);   // (idle lanes: empty -> empty)
+          dup += (act && old == bits) ? 1u : 0u;
+          act = act && old != kWideEmpty;
+          hh = (hh + st) & mask;
+        }
+        ppq += dup * (dup + 1u);                     // the p-th of its value, p = dup + 1: p (p - 1)
+      };
+      auto drain = [&](int n) {                      // the last n <= 64 entries of the list
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        lcnt -= n;
+        const bool act = lane < n;
+        const unsigned bits = lst[lcnt + (act ? lane : 0)];
+        walk_to_end(bits, act);
+      };
       auto insert_many = [&](auto nv_tag, const float* xq, const bool* have, int pass) {
         constexpr int NV = decltype(nv_tag)::value;
-        // double hashing: start and (odd) step from the key alone, so every copy of a value walks the same slots.  A
-        // lane without a sample to place issues a no-op (empty -> empty) instead of being masked off.
         unsigned hh[NV], st[NV], bits[NV], dup[NV]; bool act[NV];
-        bool any = false;
-        const unsigned mask = (unsigned)(wslots - 1);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
           bits[e] = __float_as_uint(xq[e] + 0.0f);                             // (-0.0 -> +0.0: one key per value)
-          hh[e] = (bits[e] * 2654435761u) >> (32 - wide_log);
-          st[e] = ((bits[e] * 0x85ebca6bu) >> (32 - wide_log)) | 1u;
+          const unsigned hsh = bits[e] * 2654435761u;
+          hh[e] = hsh >> (32 - wide_log);
+          st[e] = (hsh >> 6) | 1u;
           // (two passes: the values are split by one more hash bit; each pass holds one half in the table)
-          const bool mine = wide_passes == 1 || ((bits[e] * 0xc2b2ae35u) >> 31) == (unsigned)pass;
-          dup[e] = 0u; act[e] = have[e] && mine; any = any || act[e];
+          const bool mine = wide_passes == 1 || ((hsh >> 5) & 1u) == (unsigned)pass;
+          dup[e] = 0u; act[e] = have[e] && mine;
         }
 #if (NMOD_SKIP & (128 | 256))
-        any = false;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) act[e] = false;
 #endif
-        // every sample once per trip, the NV compare-and-swaps in flight together.  (Taking the stragglers one per lane
-        // and trip instead saves no instructions and adds round trips: measured 6-20 % slower.)
-        while (__ballot(any) != 0ull) {
+        // kWideProbes steps for every sample, the NV compare-and-swaps of a step in flight together
+#pragma unroll
+        for (int t = 0; t < kWideProbes; ++t) {
           unsigned old[NV];
 #pragma unroll
           for (int e = 0; e < NV; ++e) old[e] = atomicCAS(&ht[hh[e]], kWideEmpty, act[e] ? bits[e] : kWideEmpty);
-          any = false;
 #pragma unroll
           for (int e = 0; e < NV; ++e) {
             dup[e] += (act[e] && old[e] == bits[e]) ? 1u : 0u;
             act[e] = act[e] && old[e] != kWideEmpty;
             hh[e] = (hh[e] + st[e]) & mask;
-            any = any || act[e];
           }
         }
 #pragma unroll
-        for (int e = 0; e < NV; ++e) ppq += dup[e] * (dup[e] + 1u);            // the p-th of its value, p = dup + 1: p (p - 1)
+        for (int e = 0; e < NV; ++e) {
+          ppq += act[e] ? 0u : dup[e] * (dup[e] + 1u);                          // placed: p (p - 1); deferred: counted when it is
+          const unsigned long long m = __ballot(act[e]);
+          if (m != 0ull) {
+            const int at = lcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (act[e]) lst[at] = bits[e];
+            lcnt += __popcll(m);
+            if (lcnt >= 64) drain(64);
+          }
+        }
       };
 #pragma unroll 1
       for (int pass = 0; pass < wide_passes; ++pass) {
@@ -463,6 +502,7 @@ void rank_hist_kernel(RankStatsArgs args) {
           }
           insert_many(std::integral_constant<int, 1>{}, xq1, hv, pass);
         }
+        if (lcnt > 0) drain(lcnt);                   // what is still deferred belongs to this pass's half of the values
       }
     } else {
     __builtin_amdgcn_s_waitcnt(0x0F70);            // everything requested before the sort has arrived

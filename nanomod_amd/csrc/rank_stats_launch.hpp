@@ -61,7 +61,7 @@ inline size_t rank_stats_lds_bytes(int cls, bool all) {
     const int c0 = cls / kNumSizeClasses, c1 = cls % kNumSizeClasses;
     const size_t R = (size_t)1 << wide_class_of_s(cls);
     const int cq = cls >= kWideBigBase ? kNumSizeClasses - 1 : (c0 < c1 ? c1 : c0);
-    const size_t w = ((2 * R * 65 + 3) & ~(size_t)3) + ((size_t)128 << cq);
+    const size_t w = ((2 * R * 65 + 3) & ~(size_t)3) + ((size_t)128 << cq) + 128;   // + kWideList (rank_hist.hpp)
     return w * 4 * 4 + 16;
   } else if (cls >= kKsClassBase) {
     int cs = cls - kKsClassBase;

@@ -44,7 +44,7 @@ PLANT_PERIOD = 10000
 PLANT_SHIFT = 0.8
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GUIDE_GBS = 6290.0    # same guide: measured float4 copy
-KS_D_ABS = 4.5e-16             # gate on D (tests/helpers.py)
+KS_D_RATIONAL_ABS = 4.5e-16    # gate on D under NMOD_FLAG_KS_RATIONAL_D (2 ulp); without the flag D is bit for bit
 
 PRESETS = {
     'ecoli': dict(positions=4_600_000, n0=200, n1=200, all_tests=False, layout='stride',
@@ -217,6 +217,8 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=0, help='cap on positions for the CPU baseline / verification (0 = 1 M)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline (the verification still runs)')
     ap.add_argument('--no-real-ties', action='store_true', help='skip the second, tie-heavy measurement of the default run')
+    ap.add_argument('--exact-d', action='store_true', help='KS-only configurations: D as ks_2samp\'s float form bit for bit (the library default) '
+                    'instead of NMOD_FLAG_KS_RATIONAL_D; the default run reports this rate beside the headline')
     ap.add_argument('--launch-only', action='store_true', help='ranks print RANK / WORLD_SIZE and exit before any GPU call (launcher test)')
     args = ap.parse_args()
 
@@ -263,7 +265,12 @@ def main():
     total = B * world * chunks                     # the synthetic genome is padded to whole blocks
     method = 'fisher' if all_tests else 'stouffer'
     tests = L.TEST_ALL if all_tests else L.TEST_KS
-    det = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests)
+    # KS-only (a mode the reference never runs): the timed configuration reports D as the exact rational, <= 2 ulp from
+    # ks_2samp's float form (include/nanomod_hip.h: NMOD_FLAG_KS_RATIONAL_D); --exact-d times the library default
+    rational_d = (not all_tests) and not args.exact_d
+    det = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests,
+                            flags=L.FLAG_KS_RATIONAL_D if rational_d else 0)
+    d_gate = [KS_D_RATIONAL_ABS if rational_d else 0.0]
 
     def fill(b, ties):
         """(re)generate a block's samples on the device from global position counters.  ties == 'real': the int16
@@ -369,7 +376,7 @@ def main():
             if k.endswith('_p'):
                 good = bool(np.all(err <= 1e-9 * np.abs(e[fin]) + 1e-300)) and ab <= 1e-6
             elif k == 'ks_d':
-                good = ab <= KS_D_ABS
+                good = ab <= d_gate[0]
             elif k == 'mwu_u':
                 good = ab == 0.0
             elif k == 't_t':
@@ -457,6 +464,32 @@ def main():
             verify['ok'] = False
             print('bench.py: verification of the tie-heavy pass FAILED: %r' % vt, file=sys.stderr)
 
+    # ---- the library default in KS-only mode (D bit for bit): a second, shorter measurement beside the headline
+    exact_d = None
+    if world == 1 and rational_d and real_ties is not None:
+        for b in blocks:
+            fill(b, args.ties)
+        det.flags = 0
+        d_gate[0] = 0.0
+        step(False); state.wait(); torch.cuda.synchronize()
+        rows_e = host_rows(min(20_000, blocks[0]['n']))
+        ve = verify_against_oracle(rows_e, len(rows_e[1]) - 1)
+        for _ in range(3):
+            step(False)
+        t3 = nm.EventTimer(64)
+        det.timer = t3
+        ks = max(1, min(args.steps, 10))
+        el3 = timed(False, ks)
+        det.timer = None
+        e1, en = t3.read(L.KERNEL_RANK_STATS)
+        exact_d = {'value': total * ks / el3, 'unit': 'positions/s', 'steps': ks, 'ms_per_step': el3 / ks * 1e3,
+                   'kernel_avg_ms': e1 / max(en, 1), 'verify': ve,
+                   'note': 'flags = 0: ks_d is max|fl(c0/n0) - fl(c1/n1)| exactly as ks_2samp forms it (what mtest2 / the CLI always get: '
+                           'they run all three tests, whose kernels are bit-exact in D without a flag)'}
+        if not ve['ok']:
+            verify['ok'] = False
+            print('bench.py: verification of the exact-D pass FAILED: %r' % ve, file=sys.stderr)
+
     line = None
     if rank == 0:
         value = total * args.steps / elapsed
@@ -478,7 +511,7 @@ def main():
         kbuf = ctypes.create_string_buffer(96)
         L.check(L.load().nmod_describe_dispatch(ctypes.byref(prm), n0, n1, kbuf, 96), 'nmod_describe_dispatch')
         shape = 'ragged' if csr else '%dv%d' % (n0, n1)
-        key = '%s_%s_%s_%d%s' % ('all' if all_tests else 'ks', args.dtype, shape, int(pos_per_launch), '_realties' if args.ties == 'real' else '')
+        key = '%s_%s_%s_%d%s' % ('all' if all_tests else 'ks', args.dtype, shape, int(pos_per_launch), ('_realties' if args.ties == 'real' else '') + ('_exactd' if (args.exact_d and not all_tests) else ''))
         rec = profile_record(L.LIB_PATH, key) or {}
         tests_txt = 'KS + MWU + Welch-t + Fisher window=%d' % (2 * NB + 1) if all_tests else 'KS + weighted Stouffer window=%d' % (2 * NB + 1)
         reads_txt = ('n0 ~ LogNormal(ln 1000, 0.5) in [5, 4000], n1 ~ LogNormal(ln 50, 0.5) in [5, 400] (means %.0f v %.0f), CSR'
@@ -496,6 +529,9 @@ def main():
                                    % (preset['name'], ' x %d' % world if (world > 1 and not args.strong) else '', total, total // world, reads_txt, tests_txt),
                        'preset': args.config, 'positions_total': total, 'positions_per_gpu': total // world, 'n0': n0, 'n1': n1,
                        'layout': 'csr' if csr else 'fixed stride', 'neighborPvalues': NB, 'WeightsDif': WDIF, 'ties': args.ties,
+                       'ks_d': ('exact rational max|c0 n1 - c1 n0| / (n0 n1), correctly rounded (NMOD_FLAG_KS_RATIONAL_D; <= 2 ulp from '
+                                'ks_2samp\'s float form, gate 4.5e-16; the bit-exact default is timed in `exact_d`)') if rational_d else
+                               'ks_2samp\'s float form bit for bit (library default)',
                        'rccl_ranks': dist.get_world_size() if dist is not None else 0,
                        'backend': dist.get_backend() if dist is not None else None,
                        'parallelism': ('block-cyclic position sharding x%d, %d rounds of %d-position blocks, +-%d halo recomputed; '
@@ -529,6 +565,8 @@ def main():
         }
         if real_ties is not None:
             line['real_ties'] = real_ties
+        if exact_d is not None:
+            line['exact_d'] = exact_d
         if not args.no_cpu and world == 1:           # the CPU baseline is an N=1 figure
             line['cpu_baseline'] = cpu_baseline(cpu_rows, '%s, %s' % (reads_txt, tests_txt), method, 7 if all_tests else 1, usable_cpus())
     ok = torch.tensor([1 if (rank != 0 or verify['ok']) else 0], device=dev)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NMOD_ABI_VERSION 1
+#define NMOD_ABI_VERSION 2
 
 /* sample dtype of sig0 / sig1 */
 enum {
@@ -102,7 +102,15 @@ typedef struct nmod_params {
                              reduces off0 on the device and synchronises once to read it) */
   int32_t max_n1;         /* same for group 2 */
   void*   timer;          /* optional nmod_evtimer handle: HIP events are recorded around each kernel */
+  int32_t flags;          /* NMOD_FLAG_* (0 = the reference's numbers bit for bit wherever it defines them) */
+  int32_t reserved;       /* 0 */
 } nmod_params;
+
+/* tests == NMOD_TEST_KS only (a mode the reference never runs: getKStest always computes all three tests): report D as the
+ * correctly rounded exact rational max|c0*n1 - c1*n0| / (n0*n1) instead of ks_2samp's float form max|fl(c0/n0) - fl(c1/n1)|
+ * (they differ by <= 2 ulp, <= 4.5e-16 absolute; p-values agree to ~1e-15 relative).  Skips the pass that evaluates the float
+ * form at the pooled points reaching the integer maximum (~10 % of the KS-only kernel).  Ignored with any other test in the mask. */
+#define NMOD_FLAG_KS_RATIONAL_D 1
 
 /* Caller-allocated SoA outputs, npos elements each; a NULL member is skipped.
  * One (stat, p) pair per test = the tuples getKStest returns
@@ -143,10 +151,9 @@ int nmod_detect_batch(const nmod_params* prm, int64_t npos,
                       void* workspace, int64_t workspace_bytes,
                       nmod_out* out);
 
-/* KS statistic, exact form: with tests == NMOD_TEST_KS only (a mode the reference itself never runs — getKStest always
- * computes all three tests) ks_d is the correctly rounded exact rational max|c0*n1 - c1*n0| / (n0*n1); ks_2samp forms
- * max|fl(c0/n0) - fl(c1/n1)|, which can differ from it by <= 2 ulp (<= 4.5e-16 absolute).  With any other test in the
- * mask (what mtest2 / getKStest / the CLI use) ks_d is the reference's float form bit for bit. */
+/* KS statistic: ks_d is ks_2samp's own float form max|fl(c0/n0) - fl(c1/n1)| bit for bit in every mode (myDetect.py:341 ->
+ * scipy 1.2.1), tests == NMOD_TEST_KS included: the kernels find the exact integer maximum of |c0*n1 - c1*n0| and evaluate the
+ * float form for the pooled points that reach it. */
 
 /* Name of the K1 kernel instance a position with n0 / n1 samples is dispatched to under prm's dtype / tests / method
  * (e.g. "ks_rank_kernel<16,16,f32>"), from the same size-class functions the dispatcher uses: what bench.py prints as

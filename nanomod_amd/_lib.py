@@ -12,11 +12,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (NMOD_HIP_LIB: another build of the same library, for A/B measurements of kernel variants on one box)
 LIB_PATH = os.environ.get('NMOD_HIP_LIB') or os.path.join(_HERE, 'libnanomod_hip.so')
 
-NMOD_ABI_VERSION = 1
+NMOD_ABI_VERSION = 2
 DTYPE_F32, DTYPE_I16_MILLI, DTYPE_F64 = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 METHOD_KS, METHOD_STOUFFER, METHOD_FISHER = 0, 1, 2
 TEST_KS, TEST_MWU, TEST_WELCH, TEST_ALL = 1, 2, 4, 7
+FLAG_KS_RATIONAL_D = 1
 STATUS_MWU_ALL_IDENTICAL, STATUS_T_NAN, STATUS_EMPTY, STATUS_TOO_LARGE = 1, 2, 4, 8
 KERNEL_RANK_STATS, KERNEL_FINALIZE, KERNEL_COMBINE, KERNEL_SYNTH = 0, 1, 2, 3
 MAX_GROUP = 2048          # largest group of the wave-resident kernels; larger ones (<= MAX_RANKED) take big_rank_kernel
@@ -34,7 +35,7 @@ class NmodParams(C.Structure):
                 ('memspace', C.c_int32), ('dtype', C.c_int32), ('tests', C.c_int32),
                 ('method', C.c_int32), ('nb', C.c_int32), ('want_mstd', C.c_int32),
                 ('weights_dif', C.c_double), ('stride0', C.c_int64), ('stride1', C.c_int64),
-                ('max_n0', C.c_int32), ('max_n1', C.c_int32), ('timer', C.c_void_p)]
+                ('max_n0', C.c_int32), ('max_n1', C.c_int32), ('timer', C.c_void_p), ('flags', C.c_int32), ('reserved', C.c_int32)]
 
 
 class NmodOut(C.Structure):
@@ -114,7 +115,7 @@ def check(rc, what='nanomod_hip'):
 
 def make_params(device=0, stream=0, memspace=MEM_HOST, dtype=DTYPE_F32, tests=TEST_ALL,
                 method=METHOD_STOUFFER, nb=2, weights_dif=2.0, want_mstd=0,
-                stride0=0, stride1=0, max_n0=0, max_n1=0, timer=None):
+                stride0=0, stride1=0, max_n0=0, max_n1=0, timer=None, flags=0):
     p = NmodParams()
     p.struct_size = C.sizeof(NmodParams)
     p.device = device
@@ -131,4 +132,6 @@ def make_params(device=0, stream=0, memspace=MEM_HOST, dtype=DTYPE_F32, tests=TE
     p.max_n0 = max_n0
     p.max_n1 = max_n1
     p.timer = timer
+    p.flags = flags
+    p.reserved = 0
     return p

@@ -100,7 +100,7 @@ void big_rank_kernel(BigArgs a) {
   constexpr int kBigLdsKeys = kBigLdsBytes / (int)sizeof(K);
   __shared__ K lds_keys[kBigLdsKeys];
   __shared__ double red[kBigThreads / 64];
-  __shared__ unsigned long long sh_base, sh_s, sh_t, sh_best;
+  __shared__ unsigned long long sh_base, sh_s, sh_t, sh_best, sh_dbest;
   const int tid = threadIdx.x;
   const int64_t count = a.class_meta[a.big_class];
   const int32_t* list = a.pos_list + a.class_meta[kClassStride + a.big_class];
@@ -114,7 +114,7 @@ void big_rank_kernel(BigArgs a) {
     const int P0 = (int)big_pow2_ceil(n0), P1 = (int)big_pow2_ceil(n1);
     if (tid == 0) {
       sh_base = atomicAdd(a.cursor, (unsigned long long)(P0 + P1));
-      sh_s = 0ull; sh_t = 0ull; sh_best = 0ull;
+      sh_s = 0ull; sh_t = 0ull; sh_best = 0ull; sh_dbest = 0ull;
     }
     __syncthreads();
     K* A = reinterpret_cast<K*>(a.scratch) + sh_base;
@@ -167,11 +167,12 @@ void big_rank_kernel(BigArgs a) {
       const unsigned long long ta = (unsigned long long)(U - L), tb = (unsigned long long)(je - js);
       s_acc += tb * (unsigned long long)(2 * m - U - L);
       t_acc += tb * tb * tb - tb + 3ull * ta * tb * (ta + tb);
-      if (a.all) {
+      {
         const double d_at = (double)U / dm - (double)je / dq;            // ks_2samp's float form: fl(c0/n0) - fl(c1/n1)
         const double d_before = (double)L / dm - (double)js / dq;
         dmax = fmax(dmax, fmax(fabs(d_at), fabs(d_before)));
-      } else {
+      }
+      if (!a.all) {
         const long long n_at = (long long)U * q - (long long)je * m, n_before = (long long)L * q - (long long)js * m;
         const unsigned long long m_at = (unsigned long long)(n_at < 0 ? -n_at : n_at);
         const unsigned long long m_before = (unsigned long long)(n_before < 0 ? -n_before : n_before);
@@ -188,14 +189,14 @@ void big_rank_kernel(BigArgs a) {
       }
       atomicAdd(&sh_s, s_acc);
       atomicAdd(&sh_t, t_acc);
-      best = (unsigned long long)__double_as_longlong(dmax);         // non-negative doubles order like their bits
     }
-    atomicMax(&sh_best, best);
+    atomicMax(&sh_dbest, (unsigned long long)__double_as_longlong(dmax));   // non-negative doubles order like their bits
+    if (!a.all) atomicMax(&sh_best, best);
     __syncthreads();
     if (tid == 0) {
+      a.ks_d_ref[pos] = __longlong_as_double((long long)sh_dbest);  // every mode: the float form K2 reports as D
       if (a.all) {
         a.mwu_s[pos] = sh_s; a.tie[pos] = sh_t;
-        a.ks_d_ref[pos] = __longlong_as_double((long long)sh_best);
       } else {
         a.ks_num[pos] = (uint32_t)sh_best;                           // <= 65 535^2 < 2^32
       }

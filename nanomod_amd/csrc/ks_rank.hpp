@@ -211,6 +211,24 @@ __device__ __forceinline__ const float* ks_search(const float* base, float x) {
   return all ? base + Lay::END : p;
 }
 
+template <int LG>
+__device__ __forceinline__ double seg_allmax_f64(double v) {
+  v = fmax(v, dpp_f64_row(v, 0)); v = fmax(v, dpp_f64_row(v, 1)); v = fmax(v, dpp_f64_row(v, 2));
+  if constexpr (LG >= 16) v = fmax(v, dpp_f64_row(v, 3));
+  if constexpr (LG >= 32) v = fmax(v, xor16_f64(v));
+  if constexpr (LG == 64) v = wave_max_f64(v);
+  return v;
+}
+
+// fl(c / n) for integers 0 <= c <= n <= 65 535, r = fl(1 / n): correctly rounded (one Newton correction of c * r;
+// checked exhaustively on the host: tests/test_abi_and_host.py)
+__device__ __forceinline__ double hist_exact_quot(int c, double n, double r) {
+  const double dc = (double)c;
+  const double q0 = __dmul_rn(dc, r);
+  const double rem = __fma_rn(-q0, n, dc);
+  return __fma_rn(rem, r, q0);
+}
+
 // second launch-bound argument = minimum waves per SIMD: keeps every form whose LDS footprint allows
 // four waves per SIMD (R <= 16; the R = 32 forms are limited to two by their LDS) at <= 128 VGPRs (the compiler otherwise spends 130-175 registers on scheduling
 // freedom and occupancy drops to 2-3); no spills result
@@ -244,6 +262,16 @@ void ks_rank_kernel(RankStatsArgs args) {
 #pragma unroll
   for (int b = 0; b < 6; ++b) sel.s[b] = ((lane >> b) & 1) ? inf : -inf;
   for (int r = gl; r < R; r += LG) keys[r * ROW + Lay::END] = inf;   // the spare column: key C (and beyond) = +inf
+  // fixed-stride batches: every position has the same sizes; fl(1/m) and fl(1/q) are taken once per block and parked
+  // in LDS behind the positions' words
+  const bool uniform = args.stride0 > 0 && args.stride1 > 0;
+  double* recip = reinterpret_cast<double*>(lds_all + kWavesPerBlock * PW * POS_WORDS);
+  if (uniform && threadIdx.x == 0) {
+    const int64_t a0 = args.stride0 < args.stride1 ? args.stride0 : args.stride1;
+    const int64_t a1 = args.stride0 < args.stride1 ? args.stride1 : args.stride0;
+    recip[0] = 1.0 / (double)a0; recip[1] = 1.0 / (double)a1;
+  }
+  __syncthreads();
 
   int64_t count = args.npos;
   const int32_t* list = nullptr;
@@ -491,20 +519,29 @@ void ks_rank_kernel(RankStatsArgs args) {
       // no ties in this wave: cumL == cumU; D_num = max_{k < m} max(a_k, q - a_k), a_k = cumL(k)*m - k*q.
       // Q samples above every s sit in bin m; clamping k*q at (m-1)*q and the running count at
       // cumL(m-1) makes every bin >= m repeat a_{m-1}.
+      // A lane owns the candidates of ITS bins k = e0+1 .. e0+R: (cumL(k), k) = a_k and (cumL(k-1), k) = a_{k-1} - q, so
+      // its maximum runs over a_{e0+1} .. a_{e0+R} and its minimum over a_{e0} .. a_{e0+R-1} (lane 0 also owns
+      // (cumL(0), 0) = a_0): no candidate is seen by two lanes, and the lanes that reach the position's maximum are
+      // exactly the ones whose bins the float-form pass has to look at.
       const int kq_max = __mul24(m - 1, q);                              // (24-bit operands: m <= 2 048, q <= 65 535)
       int kq = min(__mul24(e0, q), kq_max);
       const int cmax = q - (int)(hist[Lay::word(m)] >> 16);              // cumL(m-1)
       int c = min((int)(cum >> 16), cmax);
-      int hi = __mul24(c, m) - kq, lo = hi;                              // bin e0 itself: a valid a_k
+      int a = __mul24(c, m) - kq;                                        // a_{e0}
+      int hi = (gl == 0) ? a : -(1 << 30), lo = 1 << 30;
+      // (the running counts go back to LDS in place of the bins — stores only, no extra arithmetic: the float-form pass
+      // below reads cumL(k-1) and cumL(k) of the bins it examines from there)
+      if (gl == 0) hist[0] = (unsigned)c;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        c = min(c + (int)(h[r] >> 16), cmax);
-        kq = min(kq + q, kq_max);
-        const int a = __mul24(c, m) - kq;
-        hi = max(hi, a);
         lo = min(lo, a);
+        c = min(c + (int)(h[r] >> 16), cmax);
+        if (r < R - 1) hist[(r + 1) * ROW + gl] = (unsigned)c; else hist[gl + 1] = (unsigned)c;
+        kq = min(kq + q, kq_max);
+        a = __mul24(c, m) - kq;
+        hi = max(hi, a);
       }
-      best = (unsigned)max(hi, q - lo);
+      best = (unsigned)max(max(hi, q - lo), 0);
     } else {
       // general form with the run ends of S as masks
       // Pads are +inf, so "s_{k-1} != s_k" alone marks the run ends: it holds at k = m and fails for k > m.
@@ -518,8 +555,11 @@ void ks_rank_kernel(RankStatsArgs args) {
         const bool run_end = s_own[r] != up;
         nkq -= q;
         const int cand_b = __mul24(cl, m) + nkq;                   // v = the S value with upper rank k: cumL(k-1)*m - k*q
+        const unsigned clp16 = (unsigned)cl << 16;
         cl += (int)(h[r] >> 16);                                   // cumL(k)
         const int cu = cl - (int)(h[r] & 0xffffu);                 // cumU(k) = cumL(k) - #{x = s_{k+1}}
+        // (the bin's word becomes cumL(k-1) << 16 | cumU(k) for the float-form pass)
+        if (r < R - 1) hist[(r + 1) * ROW + gl] = clp16 | (unsigned)cu; else hist[gl + 1] = clp16 | (unsigned)cu;
         const int cand_a = __mul24(cu, m) + nkq;                   // v = the largest sample below s_{k+1}: cumU(k)*m - k*q
         const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
         hi = max(hi, max(ca, cb));
@@ -527,8 +567,70 @@ void ks_rank_kernel(RankStatsArgs args) {
       }
       best = (unsigned)max(hi, -lo);
     }
+    const unsigned lbest = best;
     best = seg_allmax_u32<LG>(best);
-    if (valid && gl == 0) args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;
+    // ---- ks_2samp forms D as max |fl(c0/n0) - fl(c1/n1)| over the pooled points.  A larger integer numerator always
+    // gives a larger float value (they differ by >= 1/(n0 n1) >> ulp), so the float form is evaluated only for the
+    // candidates that reach the integer maximum — the maximum of those is the reference's D bit for bit.  The lanes of a
+    // position take the R bins of one such lane at a time, BPL consecutive bins each, from the table the evaluation
+    // left in LDS: word k = cumL(k) when the wave saw no tie, cumL(k-1) << 16 | cumU(k) otherwise.
+    double dmax = 0.0;
+    if (!args.ks_rational_d) {
+      constexpr int BPL = (R + LG - 1) / LG;
+      const double dm = (double)m, dq = (double)q;
+      double rm, rq;
+      if (uniform) { rm = recip[0]; rq = recip[1]; }
+      else { rm = 1.0 / dm; rq = 1.0 / dq; }
+      const int seg_base = lane & ~(LG - 1);
+      const unsigned long long hits = __ballot(lbest == best && best != 0u);
+      using Mine = typename std::conditional<LG == 64, unsigned long long, unsigned>::type;
+      Mine mine = (Mine)(hits >> seg_base);
+      if constexpr (LG < 32) mine &= (Mine)((1u << LG) - 1u);
+#if defined(NMOD_EXP) && (NMOD_EXP & 4)
+      mine = 0;
+#endif
+      // the candidate (cumU(0), 0) belongs to lane 0 of the position
+      if (gl == 0 && (mine & (Mine)1)) {
+        const int cu0 = (int)(h0 >> 16) - (int)(h0 & 0xffffu);
+        if ((unsigned)__mul24(cu0, m) == best) dmax = hist_exact_quot(cu0, dq, rq);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+      while (__ballot(mine != (Mine)0) != 0ull) {
+        const bool act = mine != (Mine)0;
+        const int hl = act ? (__ffsll((long long)mine) - 1) : 0;              // the lane of this position whose bins are examined
+        mine &= mine - (Mine)1;
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+          const int rr = gl * BPL + j;                                        // bin k = hl * R + rr + 1
+          const bool in = act && rr < R;
+          const int k = hl * R + rr + 1;
+          // key k - 1 / word k - 1 = row rr of column hl; key / word k = row rr + 1 of column hl, or row 0 of column hl + 1
+          const int wp = in ? rr * ROW + hl : 0;
+          const int wk = in ? ((rr + 1 < R) ? (rr + 1) * ROW + hl : hl + 1) : 0;
+          const unsigned tp = hist[wp], tk = hist[wk];
+          const bool run_end = keys[wp] != keys[wk];
+          const int clp = slow ? (int)(tk >> 16) : (int)tp;                   // cumL(k-1)
+          const int cu = slow ? (int)(tk & 0xffffu) : (int)tk;                // cumU(k)
+          const int nkq = -__mul24(k, q);
+          const int cand_b = __mul24(clp, m) + nkq;                           // (cumL(k-1), k)
+          const int cand_a = __mul24(cu, m) + nkq;                            // (cumU(k), k)
+          const bool hb = in && run_end && (unsigned)abs(cand_b) == best;
+          const bool ha = in && run_end && (unsigned)abs(cand_a) == best;
+          const double fk = hist_exact_quot(k, dm, rm);
+          const double db = fabs(fk - hist_exact_quot(clp, dq, rq));
+          const double da = fabs(fk - hist_exact_quot(cu, dq, rq));
+          dmax = hb ? fmax(dmax, db) : dmax;
+          dmax = ha ? fmax(dmax, da) : dmax;
+        }
+      }
+      dmax = seg_allmax_f64<LG>(dmax);
+    }
+    if (valid && gl == 0) {
+      args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;
+      args.ks_d_ref[pos] = (m > 0 && q > 0) ? dmax : 0.0;
+    }
     if constexpr (FLAGS) {
       const unsigned t = seg_allmax_u32<LG>(tie_lane ? 1u : 0u);   // a sample of Q tied with a key of S anywhere in the position
       if (valid && gl == 0) args.tied[pos] = (uint8_t)t;

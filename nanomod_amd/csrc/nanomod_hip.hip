@@ -323,6 +323,7 @@ static int check_params(const nmod_params* prm) {
   if (prm->method < NMOD_METHOD_KS || prm->method > NMOD_METHOD_FISHER) return NMOD_ERR_INVALID_ARG;
   if (prm->nb < 0 || prm->nb > NMOD_MAX_NB) return NMOD_ERR_INVALID_ARG;
   if ((prm->tests & ~NMOD_TEST_ALL) != 0) return NMOD_ERR_INVALID_ARG;
+  if ((prm->flags & ~NMOD_FLAG_KS_RATIONAL_D) != 0 || prm->reserved != 0) return NMOD_ERR_INVALID_ARG;
   return NMOD_OK;
 }
 
@@ -462,6 +463,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   ra.sig0 = sig0; ra.sig1 = sig1; ra.off0 = off0; ra.off1 = off1;
   ra.stride0 = prm->stride0 > 0 ? prm->stride0 : 0; ra.stride1 = prm->stride1 > 0 ? prm->stride1 : 0;
   ra.npos = npos; ra.ks_num = ws.ks_num; ra.mwu_s = ws.mwu_s; ra.tie = ws.tie; ra.moments = ws.moments; ra.ks_d_ref = ws.ks_d_ref;
+  ra.ks_rational_d = (!all && (prm->flags & NMOD_FLAG_KS_RATIONAL_D)) ? 1 : 0;
   ra.tied = f64 ? ws.tied : nullptr;            // float32 keys of float64 samples: K1 reports the positions whose keys tie
 
   auto launch = [&](int cls, int64_t work) -> hipError_t {
@@ -583,7 +585,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   FinalizeArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.npos = npos; fa.off0 = off0; fa.off1 = off1; fa.stride0 = ra.stride0; fa.stride1 = ra.stride1;
-  fa.ks_num = ws.ks_num; fa.mwu_s = ws.mwu_s; fa.tie = ws.tie; fa.moments = ws.moments; fa.ks_d_ref = all ? ws.ks_d_ref : nullptr;
+  fa.ks_num = ws.ks_num; fa.mwu_s = ws.mwu_s; fa.tie = ws.tie; fa.moments = ws.moments; fa.ks_d_ref = ra.ks_rational_d ? nullptr : ws.ks_d_ref;   // every K1 form writes ks_2samp's float form of D (unless the caller opted out)
   fa.tests = tests; fa.want_mstd = prm->want_mstd; fa.out = *out;
   // what K1 covered: exactly the limits the classifier used (the promised / measured maxima), in every mode —
   // a position beyond them was skipped by K1 and must be flagged TOO_LARGE here, never read from the workspace

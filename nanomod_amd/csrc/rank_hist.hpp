@@ -144,23 +144,6 @@ __device__ __forceinline__ unsigned pos_allsum_u32(unsigned v) {     // sum over
   return v;
 }
 
-template <int LG>
-__device__ __forceinline__ double seg_allmax_f64(double v) {
-  v = fmax(v, dpp_f64_row(v, 0)); v = fmax(v, dpp_f64_row(v, 1)); v = fmax(v, dpp_f64_row(v, 2));
-  if constexpr (LG >= 16) v = fmax(v, dpp_f64_row(v, 3));
-  if constexpr (LG >= 32) v = fmax(v, xor16_f64(v));
-  if constexpr (LG == 64) v = wave_max_f64(v);
-  return v;
-}
-
-// fl(c / n) for an integer 0 <= c <= n <= 4096, r = fl(1 / n): correctly rounded (checked exhaustively on the host)
-__device__ __forceinline__ double hist_exact_quot(int c, double n, double r) {
-  const double dc = (double)c;
-  const double q0 = __dmul_rn(dc, r);
-  const double rem = __fma_rn(-q0, n, dc);
-  return __fma_rn(rem, r, q0);
-}
-
 #ifndef NMOD_SKIP
 #define NMOD_SKIP 0
 #endif

@@ -39,6 +39,7 @@ struct RankStatsArgs {
   uint64_t* mwu_s;                             // [npos]  (MWU)
   uint64_t* tie;                               // [npos]  (MWU)
   double* moments;                             // [npos][4] mean0, M2_0, mean1, M2_1 (WELCH)
+  int32_t ks_rational_d;                       // KS-only mode: skip the float form of D (NMOD_FLAG_KS_RATIONAL_D)
   double* ks_d_ref;                            // [npos] max |fl(c0/n0) - fl(c1/n1)| exactly as ks_2samp forms it (all-tests mode)
   uint8_t* tied;                               // [npos] or null: 1 where the position's keys tie (see ks_rank_kernel FLAGS; all-tests: any tie)
 };

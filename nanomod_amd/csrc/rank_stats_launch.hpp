@@ -68,7 +68,7 @@ inline size_t rank_stats_lds_bytes(int cls, bool all) {
     size_t LG = (size_t)ks_lanes_per_group(cs), R = (64u << cs) / LG;
     size_t w = 2 * R * (LG + 1);                                             // ks_rank_pos_words (ks_rank.hpp)
     if (LG <= 16) while ((w & 31) != LG) ++w;
-    return (size_t)ks_positions_per_wave(cs) * w * 4 * 4;                   // bytes, 4 waves per block
+    return (size_t)ks_positions_per_wave(cs) * w * 4 * 4 + 16;              // bytes, 4 waves per block, + two doubles (ks_rank.hpp: recip)
   } else if (cls >= kNumGeneralClasses) {
     int cm = cls - kNumGeneralClasses;
     size_t LG = (size_t)ks_lanes_per_group(cm), R = (64u << cm) / LG;

@@ -231,7 +231,7 @@ class DeviceDetector:
     and nothing synchronises unless max_n0/max_n1 are unknown for CSR inputs or allow groups beyond MAX_GROUP
     (one round trip sizes the scratch of the large-position pass)."""
 
-    def __init__(self, device=0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_ALL, want_mstd=False):
+    def __init__(self, device=0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_ALL, want_mstd=False, flags=0):
         import torch
         self.torch = torch
         self.lib = L.load()
@@ -241,6 +241,7 @@ class DeviceDetector:
         self.method = L.METHOD_BY_NAME[method] if isinstance(method, str) else method
         self.tests = tests
         self.want_mstd = bool(want_mstd)
+        self.flags = int(flags)          # L.FLAG_* (include/nanomod_hip.h: NMOD_FLAG_*)
         self._ws = None
         self.timer = None
 
@@ -250,7 +251,7 @@ class DeviceDetector:
                              tests=self.tests, method=self.method, nb=self.nb, weights_dif=self.weights_dif,
                              want_mstd=int(self.want_mstd), stride0=stride0, stride1=stride1,
                              max_n0=max_n0, max_n1=max_n1,
-                             timer=self.timer.handle if self.timer is not None else None)
+                             timer=self.timer.handle if self.timer is not None else None, flags=self.flags)
 
     def _dtype_of(self, t):
         torch = self.torch

@@ -60,7 +60,7 @@ def run_round(rng):
     H.compare_outputs(got, exp, True)
     assert np.array_equal(got['status'], exp['status'])
     ks = nm.detect_host(s0, off0, s1, off1, rid, nb=nb, weights_dif=2.0, method=method, tests=L.TEST_KS)
-    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 0.0, 'ks_d')
     H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
     H.assert_close_p(ks['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
     return 'npos %d sizes [%d..%d] x [%d..%d] %s nb %d %s identical %d' % (npos, lo0, hi0, lo1, hi1, mode, nb, method, ident.sum())

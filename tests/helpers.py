@@ -80,7 +80,7 @@ def compare_outputs(got, exp, with_comb=True, p_rel=1e-9):
     # two sides sum in different orders — near t = 0 only the absolute error is meaningful
     assert_close_stat(got['t_t'], exp['t_t'], 1e-11, 2e-14, 't_t')
     assert_close_p(got['t_p'], exp['t_p'], p_rel, 't_p')
-    assert_close_stat(got['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+    assert_close_stat(got['ks_d'], exp['ks_d'], 0, 0.0, 'ks_d')
     assert_close_p(got['ks_p'], exp['ks_p'], p_rel, 'ks_p')
     if with_comb:
         assert_close_stat(got['comb_st'], exp['comb_st'], 1e-9, 1e-12, 'comb_st')

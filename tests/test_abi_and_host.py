@@ -24,21 +24,21 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L._SIGNATURES), declared ^ set(L._SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.nmod_abi_version() == 1
+    assert lib.nmod_abi_version() == 2
     assert b'invalid' in lib.nmod_strerror(-1) and b'65535' in lib.nmod_strerror(-3)
 
 
 def test_struct_layout_matches_header():
     import nanomod_amd._lib as L
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu", sizeof(nmod_params), ' \
-          'offsetof(nmod_params, weights_dif), offsetof(nmod_params, max_n0), offsetof(nmod_params, timer), sizeof(nmod_out));return 0;}' % HEADER
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu", sizeof(nmod_params), ' \
+          'offsetof(nmod_params, weights_dif), offsetof(nmod_params, max_n0), offsetof(nmod_params, timer), offsetof(nmod_params, flags), sizeof(nmod_out));return 0;}' % HEADER
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, 't.c')
         open(c, 'w').write(src)
         subprocess.check_call(['gcc', c, '-o', os.path.join(d, 't')])
         got = [int(x) for x in subprocess.check_output([os.path.join(d, 't')]).split()]
     assert got == [C.sizeof(L.NmodParams), L.NmodParams.weights_dif.offset, L.NmodParams.max_n0.offset,
-                   L.NmodParams.timer.offset, C.sizeof(L.NmodOut)]
+                   L.NmodParams.timer.offset, L.NmodParams.flags.offset, C.sizeof(L.NmodOut)]
 
 
 def test_no_gpu_fails_loudly_not_silently():
@@ -286,3 +286,30 @@ def test_sign_test_records_behave_like_the_reference_list():
     assert type(back) is list and back == [as_list[i] for i in order]
     with pytest.raises(TypeError):
         hash(st)
+
+
+def test_float_form_quotient_is_correctly_rounded_for_every_count():
+    """The kernels form fl(c/n) as c*r corrected by one Newton step (hist_exact_quot, ks_rank.hpp) instead of an fp64
+    division: exhaustively equal to c / n for every 0 <= c <= n <= 65 535 (the largest group K1 ranks)."""
+    src = r"""
+#include <stdio.h>
+#include <math.h>
+int main(void) {
+  long bad = 0;
+  #pragma omp parallel for schedule(dynamic, 64) reduction(+:bad)
+  for (int n = 1; n <= 65535; n++) {
+    double dn = n, r = 1.0 / dn;
+    for (int c = 0; c <= n; c++) {
+      double dc = c, q0 = dc * r, rem = fma(-q0, dn, dc), q = fma(rem, r, q0);
+      if (q != dc / dn) bad++;
+    }
+  }
+  printf("%ld", bad);
+  return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, 'q.c')
+        open(c, 'w').write(src)
+        subprocess.check_call(['gcc', '-O2', '-fopenmp', '-mfma', '-ffp-contract=off', c, '-o', os.path.join(d, 'q'), '-lm'])
+        assert subprocess.check_output([os.path.join(d, 'q')]).decode() == '0'

@@ -172,13 +172,13 @@ def test_ks_only_mode_vs_oracle(nm, sizes, grid):
     got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
     ks = [orc.ks_2samp(sig0[off0[i]:off0[i + 1]], sig1[off1[i]:off1[i + 1]]) for i in range(npos)]
     exp_d = np.array([k[0] for k in ks]); exp_p = np.maximum(np.array([k[1] for k in ks]), orc.DBL_MIN)
-    H.assert_close_stat(got['ks_d'], exp_d, 0, 4.5e-16, 'ks_d')
+    H.assert_close_stat(got['ks_d'], exp_d, 0, 0.0, 'ks_d')
     H.assert_close_p(got['ks_p'], exp_p, 1e-9, 'ks_p')
     st, pv = orc.combine_track(exp_d, exp_p, rid, 2, 2.0, orc.METHOD_STOUFFER)
     H.assert_close_p(got['comb_p'], pv, 1e-9, 'comb_p')
     # and the exact integer numerator agrees with the all-tests kernels' D (bit-exact reference form)
     full = nm.detect_host(sig0, off0, sig1, off1, rid, method='ks')
-    assert np.max(np.abs(full['ks_d'] - got['ks_d'])) <= 2.3e-16
+    assert np.max(np.abs(full['ks_d'] - got['ks_d'])) <= 0.0
 
 
 def test_int16_milli_path_matches_float_path(nm):
@@ -205,7 +205,7 @@ def test_int16_ks_only_mode(nm):
     k1 = np.rint(sig1.astype(np.float64) * 1000).astype(np.int16)
     got = nm.detect_host(k0, off0, k1, off1, rid, tests=L.TEST_KS, method='fisher')
     ks = [orc.ks_2samp(k0[off0[i]:off0[i + 1]] / 1000.0, k1[off1[i]:off1[i + 1]] / 1000.0) for i in range(300)]
-    H.assert_close_stat(got['ks_d'], np.array([k[0] for k in ks]), 0, 4.5e-16, 'ks_d')
+    H.assert_close_stat(got['ks_d'], np.array([k[0] for k in ks]), 0, 0.0, 'ks_d')
     H.assert_close_p(got['ks_p'], np.maximum(np.array([k[1] for k in ks]), orc.DBL_MIN), 1e-9, 'ks_p')
 
 
@@ -263,7 +263,7 @@ def test_device_resident_path_and_synth(nm):
     ksp = res['ks_p'].cpu().numpy(); ksd = res['ks_d'].cpu().numpy()
     for i in idx:
         d, p = orc.ks_2samp(a[i], b[i])
-        assert abs(ksd[i] - d) <= 4.5e-16 and abs(ksp[i] - max(p, 2.2250738585072014e-308)) <= 1e-9 * p
+        assert abs(ksd[i] - d) <= 0.0 and abs(ksp[i] - max(p, 2.2250738585072014e-308)) <= 1e-9 * p
     assert ksp[8999:9002].max() < 1e-6                      # the planted shift is found
     st, pv = orc.combine_track(ksd, ksp, np.zeros(npos, np.int32), 2, 2.0, orc.METHOD_STOUFFER)
     H.assert_close_p(res['comb_p'].cpu().numpy()[idx], pv[idx], 1e-9, 'comb_p')
@@ -381,7 +381,7 @@ def test_ks_only_large_ranked_group(nm):
                          tests=L.TEST_KS, method='stouffer')
     for i, (a, b) in enumerate(zip(ca, cb)):
         d, p = orc.ks_2samp(a, b)
-        assert abs(got['ks_d'][i] - d) <= 4.5e-16 and abs(got['ks_p'][i] - max(p, orc.DBL_MIN)) <= 1e-9 * max(p, orc.DBL_MIN), i
+        assert abs(got['ks_d'][i] - d) <= 0.0 and abs(got['ks_p'][i] - max(p, orc.DBL_MIN)) <= 1e-9 * max(p, orc.DBL_MIN), i
 
 
 @pytest.mark.parametrize('mode', ['cont', 'grid1', 'const', 'i16', 'f64', 'f64ties'])
@@ -465,7 +465,7 @@ def test_large_positions_all_tests_and_ks_only(nm, grid):
     H.compare_outputs(got, exp, True)
     assert np.array_equal(got['status'], exp['status'])
     ks = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
-    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 0.0, 'ks_d')
     H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
     H.assert_close_p(ks['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
     # int16 milli-unit input through the same path
@@ -488,7 +488,7 @@ def test_large_positions_fixed_stride_and_limit(nm):
     got = nm.detect_host(sig0, None, sig1, None, rid, nb=2, weights_dif=2.0, method='fisher', stride0=n0, stride1=n1)
     H.compare_outputs(got, exp, True)
     ks = nm.detect_host(sig0, None, sig1, None, rid, nb=2, weights_dif=2.0, method='fisher', stride0=n0, stride1=n1, tests=L.TEST_KS)
-    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 0.0, 'ks_d')
     H.assert_close_p(ks['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
     big = np.zeros(65536, np.float32)
     for tests in (L.TEST_ALL, L.TEST_KS):
@@ -641,7 +641,7 @@ def test_float64_input_dtype(nm):
         if tests == L.TEST_ALL:
             H.compare_outputs(got, exp, True)
         else:
-            H.assert_close_stat(got['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+            H.assert_close_stat(got['ks_d'], exp['ks_d'], 0, 0.0, 'ks_d')
             H.assert_close_p(got['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
     r = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer').run(
         torch.as_tensor(a64, device='cuda:0'), torch.as_tensor(b64, device='cuda:0'), torch.as_tensor(rid, device='cuda:0'),
@@ -682,7 +682,7 @@ def test_float64_mixed_batch_per_position_keys(nm):
     H.compare_outputs(got, exp, True)
     assert np.array_equal(got['status'], exp['status'])
     ks = nm.detect_host(a, off0, b, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
-    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 0.0, 'ks_d')
     H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
     H.assert_close_p(ks['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
     # fixed stride: 200 v 200 arbitrary doubles, a few positions with image ties
@@ -695,7 +695,7 @@ def test_float64_mixed_batch_per_position_keys(nm):
     got = nm.detect_host(sa, None, sb, None, np.zeros(P, np.int32), stride0=n, stride1=n, nb=2, weights_dif=2.0, method='stouffer')
     H.compare_outputs(got, exp, True)
     ks = nm.detect_host(sa, None, sb, None, np.zeros(P, np.int32), stride0=n, stride1=n, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
-    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 4.5e-16, 'ks_d')
+    H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 0.0, 'ks_d')
     H.assert_close_p(ks['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
 
 
@@ -772,7 +772,7 @@ def test_full_size_properties(nm):
     assert int(r1['status'].max().item()) == 0
     ks = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS).run(a, b, rid, stride0=n, stride1=n, npos=P)
     torch.cuda.synchronize()
-    assert float((ks['ks_d'] - r1['ks_d']).abs().max().item()) <= 2.3e-16
+    assert float((ks['ks_d'] - r1['ks_d']).abs().max().item()) <= 0.0
     assert float(((ks['comb_p'] - r1['comb_p']).abs() / r1['comb_p']).max().item()) <= 1e-9
     planted = torch.arange(10000, P, 10000, device=dev)                 # (position 0 sits at the run edge: padded window, p = 1)
     assert float(r1['comb_p'][planted].max().item()) < 1e-10
@@ -825,7 +825,7 @@ def test_mtest2_on_arbitrary_float64(nm):
     for i, rec in enumerate(mo['sign_test']):
         e = orc.getKStest(ca[i], cb[i])
         assert rec[1][0][0] == e[0][0] and abs(rec[1][0][1] - e[0][1]) <= 1e-9 * e[0][1]
-        assert abs(rec[1][1][1] - e[1][1]) <= 1e-9 * e[1][1] and abs(rec[1][2][0] - e[2][0]) <= 4.5e-16
+        assert abs(rec[1][1][1] - e[1][1]) <= 1e-9 * e[1][1] and abs(rec[1][2][0] - e[2][0]) <= 0.0
         assert abs(rec[1][2][1] - e[2][1]) <= 1e-9 * e[2][1]
 
 
@@ -893,3 +893,41 @@ def test_cli_detect_on_read_folders_through_an_injected_reader(nm, method, capsy
                                                int(meta['n0'][i]), int(meta['n1'][i]), rec, method != 'ks'))
     assert got == ''.join(lines)
     capsys.readouterr()
+
+
+def test_ks_only_d_is_bit_exact_and_the_rational_flag_opts_out(nm):
+    """KS-only mode (tests == NMOD_TEST_KS): by default D is ks_2samp's float form bit for bit, like the all-tests
+    kernels; NMOD_FLAG_KS_RATIONAL_D reports the correctly rounded exact rational instead (<= 2 ulp away) and leaves the
+    p-values within 1e-9.  Ragged sizes over every KS size class, continuous and tie-heavy data, device-resident."""
+    import torch
+    import oracle_c
+    L = nm._lib
+    rng = np.random.default_rng(77)
+    P = 3000
+    n0 = rng.integers(5, 900, P); n1 = rng.integers(5, 900, P)
+    off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum(n0)
+    off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum(n1)
+    a = rng.normal(0, 1, off0[-1]).astype(np.float32); b = rng.normal(0.15, 1.1, off1[-1]).astype(np.float32)
+    a[:off0[P // 2]] = np.round(a[:off0[P // 2]], 2); b[:off1[P // 2]] = np.round(b[:off1[P // 2]], 2)
+    rid = np.zeros(P, np.int32)
+    exp = oracle_c.detect_batch(a, off0, b, off1, rid, 2, 2.0, 'stouffer', tests=1, threads=0)
+    t = lambda x: torch.from_numpy(x).cuda()
+    da, db, o0, o1, r = t(a), t(b), t(off0), t(off1), t(rid)
+    got = {}
+    for name, flags in (('exact', 0), ('rational', L.FLAG_KS_RATIONAL_D)):
+        det = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=flags)
+        res = det.run(da, db, r, off0=o0, off1=o1, max_n0=900, max_n1=900)
+        torch.cuda.synchronize()
+        got[name] = {k: v.cpu().numpy() for k, v in res.items()}
+    assert np.array_equal(got['exact']['ks_d'], exp['ks_d'])
+    assert np.max(np.abs(got['rational']['ks_d'] - exp['ks_d'])) <= 4.5e-16
+    assert np.any(got['rational']['ks_d'] != exp['ks_d'])                  # (the two forms do differ somewhere in 3000 positions)
+    for name in got:
+        H.assert_close_p(got[name]['ks_p'], exp['ks_p'], 1e-9, 'ks_p ' + name)
+        H.assert_close_p(got[name]['comb_p'], exp['comb_p'], 1e-9, 'comb_p ' + name)
+    # the flag is ignored as soon as another test is in the mask, and unknown flag bits are rejected
+    det = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_ALL, flags=L.FLAG_KS_RATIONAL_D)
+    res = det.run(da, db, r, off0=o0, off1=o1, max_n0=900, max_n1=900)
+    assert np.array_equal(res['ks_d'].cpu().numpy(), exp['ks_d'])
+    with pytest.raises(L.NanomodLibraryError):
+        nm.DeviceDetector(0, tests=L.TEST_KS, flags=8).run(da, db, r, off0=o0, off1=o1, max_n0=900, max_n1=900)

@@ -27,6 +27,7 @@
 #include <stdint.h>
 #include <type_traits>
 #include "rank_stats_packed.hpp"
+#include "packed_sort_i16.hpp"
 
 namespace nmod {
 
@@ -34,6 +35,11 @@ namespace nmod {
 static __device__ const float kKsBig4[4] = {3.4028234663852886e38f, 3.4028234663852886e38f, 3.4028234663852886e38f, 3.4028234663852886e38f};
 // ... and in the unconditional S loads: +inf, the pad value of the sort (int16 rows: 32767, replaced in finish())
 static __device__ const unsigned kKsInf4[4] = {0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u};
+// ... and of the int16 rows that are sorted as packed keys (packed_sort_i16.hpp): 32767, the pad value of that sort
+static __device__ const unsigned kKsPad16[4] = {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
+
+// int16 rows of the 16-keys-per-lane classes are sorted two keys per register (v_pk_min_i16 / v_pk_max_i16)
+__host__ __device__ constexpr bool ks_packed_sort(int R, int LG, int DTYPE) { return DTYPE == 1 && R == 16 && (LG == 8 || LG == 16); }
 
 // LDS layout: the sorted keys (and the histogram bins) of a position form an R x (LG + 1) matrix, key
 // i = R * lane + r at word r * (LG + 1) + lane: row = register, column = lane, one spare column.
@@ -95,7 +101,7 @@ struct KsRows {
 
   __device__ __forceinline__ void request(const void* sig, int64_t off, int n, int gl) {
     const T* row = reinterpret_cast<const T*>(sig) + off;
-    const T* dummy = reinterpret_cast<const T*>(kKsInf4);
+    const T* dummy = ks_packed_sort(R, LG, DTYPE) ? reinterpret_cast<const T*>(kKsPad16) : reinterpret_cast<const T*>(kKsInf4);
     const bool long_row = n >= 4;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -138,6 +144,34 @@ struct KsRows {
     if (__ballot(!long_row && n > 0) != 0ull) {
 #pragma unroll
       for (int e = 0; e < 3; ++e) x[e] = (!long_row && gl == 0 && e < n) ? (float)s[e] : x[e];
+    }
+  }
+
+  // the same rows as packed int16 keys for seg_sort_packed16: two samples per register in load order (the sort does not
+  // care which), 32767 pads — empty chunks already read a block of them
+  __device__ __forceinline__ void finish_packed(unsigned (&p)[8], int n, int gl) const {
+    static_assert(R == 16, "packed rows: 16 keys per lane");
+    const bool long_row = n >= 4;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      p[2 * k] = ((unsigned)(unsigned short)v[k].y << 16) | (unsigned)(unsigned short)v[k].x;
+      p[2 * k + 1] = ((unsigned)(unsigned short)v[k].w << 16) | (unsigned)(unsigned short)v[k].z;
+      const int idx = k * (4 * LG) + 4 * gl;
+      const int t = long_row ? n - idx : 0;          // samples of this chunk: component j is one of them iff j >= 4 - t
+      if (__ballot(t > 0 && t < 4) != 0ull) {        // a chunk that holds the end of a row: drop the overlap
+        if (t == 3) p[2 * k] = (p[2 * k] & 0xffff0000u) | 0x7fffu;           // component 0 belongs to the previous lane
+        if (t == 2 || t == 1) p[2 * k] = 0x7fff7fffu;                        // components 0 and 1 do
+        if (t == 1) p[2 * k + 1] = (p[2 * k + 1] & 0xffff0000u) | 0x7fffu;   // only component 3 is ours
+      }
+    }
+    if (__ballot(!long_row && n > 0) != 0ull) {      // rows shorter than four samples: lane 0 holds them in s[]
+      if (!long_row && gl == 0) {
+        const unsigned s0 = (0 < n) ? (unsigned)(unsigned short)s[0] : 0x7fffu;
+        const unsigned s1 = (1 < n) ? (unsigned)(unsigned short)s[1] : 0x7fffu;
+        const unsigned s2 = (2 < n) ? (unsigned)(unsigned short)s[2] : 0x7fffu;
+        p[0] = (s1 << 16) | s0;
+        p[1] = (0x7fffu << 16) | s2;
+      }
     }
   }
 };
@@ -337,11 +371,14 @@ void ks_rank_kernel(RankStatsArgs args) {
   // round of Q samples is requested before the previous round is ranked — otherwise each item pays five
   // dependent HBM round trips (measured: the load-only skeleton of this kernel ran at 3.9 TB/s).
   Item cur = describe(wave_global);
+  constexpr bool PACKED = ks_packed_sort(R, LG, DTYPE);
   float x[R];
+  unsigned pk[8];                                  // PACKED: the item's S rows as packed int16 keys (x is filled by the sort)
   {
     KsRows<R, LG, DTYPE> first;
     first.request(cur.swap ? args.sig1 : args.sig0, cur.off_s, cur.m, gl);
-    first.finish(x, cur.m, gl);
+    if constexpr (PACKED) first.finish_packed(pk, cur.m, gl);
+    else first.finish(x, cur.m, gl);
   }
   // vmcnt(0) (expcnt / lgkmcnt untouched): S rows are waited for here and at the bottom of the loop, where they
   // have long arrived — vmcnt retires in order, so a wait placed at the sort would also wait for the Q round
@@ -396,7 +433,17 @@ void ks_rank_kernel(RankStatsArgs args) {
     Q1Raw rt = load_q1(sig_q, off_q, full * (4 * LG) + gl, !coop && full * (4 * LG) + gl < q);   // first one-per-lane round
 
 #if !(defined(NMOD_EXP) && (NMOD_EXP & 1))
-    seg_sort_any<R, LG>(x, sel, lane);
+    if constexpr (PACKED) {
+      // two keys per register through the network, then the sorted keys as floats; the top C - m keys of the position
+      // are its pads (a sample may equal the pad value 32767: only the key INDEX tells them apart)
+      seg_sort_packed16<LG>(pk, lane);
+      unpack_sorted16<LG>(pk, x);
+      const int real = m - e0;                     // keys of this lane that are samples
+#pragma unroll
+      for (int r = 0; r < R; ++r) x[r] = (r < real) ? x[r] : inf;
+    } else {
+      seg_sort_any<R, LG>(x, sel, lane);
+    }
 #endif
 #pragma unroll
     for (int r = 0; r < R; ++r) keys[r * ROW + gl] = x[r];
@@ -637,7 +684,8 @@ void ks_rank_kernel(RankStatsArgs args) {
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    rows_next.finish(x, nxt.m, gl);
+    if constexpr (PACKED) rows_next.finish_packed(pk, nxt.m, gl);
+    else rows_next.finish(x, nxt.m, gl);
     cur = nxt;
   }
 }

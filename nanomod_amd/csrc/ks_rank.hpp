@@ -438,15 +438,18 @@ void ks_rank_kernel(RankStatsArgs args) {
       // are its pads (a sample may equal the pad value 32767: only the key INDEX tells them apart)
       seg_sort_packed16<LG>(pk, lane);
       unpack_sorted16<LG>(pk, x);
-      const int real = m - e0;                     // keys of this lane that are samples
-#pragma unroll
-      for (int r = 0; r < R; ++r) x[r] = (r < real) ? x[r] : inf;
     } else {
       seg_sort_any<R, LG>(x, sel, lane);
     }
 #endif
 #pragma unroll
     for (int r = 0; r < R; ++r) keys[r * ROW + gl] = x[r];
+    if constexpr (PACKED) {                        // (the pads go to LDS as +inf: predicated stores, one compare per key)
+      const int real = m - e0;                     // keys of this lane that are samples
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (r >= real) keys[r * ROW + gl] = inf;
+    }
     // clear this lane's bins e0 .. e0 + R - 1; the last lane also clears bin C
 #pragma unroll
     for (int r = 0; r < R; ++r) hist[r * ROW + gl] = 0u;

@@ -263,6 +263,43 @@ __device__ __forceinline__ double hist_exact_quot(int c, double n, double r) {
   return __fma_rn(rem, r, q0);
 }
 
+// Mean and sum of squared deviations of a group held as packed int16 keys with 32767 pads (KsRows::finish_packed), before
+// the sort: exact sums S1 = sum v (32-bit integer) and S2 = sum v^2 (fp64: every partial sum is an integer < 2^53) over
+// the lane's 16 halves, the pads' share taken out by their count, and n S2 - S1^2 — exact for n <= 2 048 — rounded
+// once.  Milli-units: mean = S1 / n / 1000, M2 = (n S2 - S1^2) / n * 1e-6.
+template <int LG>
+__device__ __forceinline__ void seg_moments_packed16(const unsigned (&p)[8], int n, int gl, double& mean, double& m2) {
+  int s1 = 0;
+  double s2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int lo = (int)(short)(p[j] & 0xffffu), hi = (int)p[j] >> 16;
+    s1 += lo + hi;
+    const double dl = (double)lo, dh = (double)hi;
+    s2 = __fma_rn(dl, dl, s2);
+    s2 = __fma_rn(dh, dh, s2);
+  }
+  // samples among the lane's 16 keys: chunk k holds samples k*4*LG + 4*gl .. + 3 of a row of n >= 4 (KsRows), lane 0 all of a shorter one
+  int valid = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) valid += min(max(n - (k * 4 * LG + 4 * gl), 0), 4);
+  valid = (n >= 4) ? valid : ((gl == 0) ? n : 0);
+  const int npad = 16 - valid;
+  s1 -= 32767 * npad;
+  s2 -= 1073676289.0 * (double)npad;                                          // 32767^2
+  unsigned v = (unsigned)s1;
+  v += (unsigned)dpp_i<NMOD_QP(1, 0, 3, 2), 0xf, 0xf, true>(0, (int)v);
+  v += (unsigned)dpp_i<NMOD_QP(2, 3, 0, 1), 0xf, 0xf, true>(0, (int)v);
+  v += (unsigned)dpp_i<kDppRowHalfMirror, 0xf, 0xf, true>(0, (int)v);
+  if constexpr (LG >= 16) v += (unsigned)dpp_i<kDppRowMirror, 0xf, 0xf, true>(0, (int)v);
+  const double S1 = (double)(int)v;                                           // |S1| <= 256 * 32 768
+  const double S2 = seg_allsum_f64<LG>(s2);                                   // <= 256 * 2^30
+  const double dn = (double)n;
+  const double num = __fma_rn(dn, S2, -S1 * S1);                              // n * M2 in milli-units^2: every term an integer < 2^53
+  mean = S1 / dn / 1000.0;
+  m2 = num / dn * 1e-6;
+}
+
 // second launch-bound argument = minimum waves per SIMD: keeps every form whose LDS footprint allows
 // four waves per SIMD (R <= 16; the R = 32 forms are limited to two by their LDS) at <= 128 VGPRs (the compiler otherwise spends 130-175 registers on scheduling
 // freedom and occupancy drops to 2-3); no spills result

@@ -260,13 +260,16 @@ void rank_hist_kernel(RankStatsArgs args) {
   __syncthreads();
 
   Item cur = describe(wave_global);
+  constexpr bool PACKED = !WIDE && ks_packed_sort(R, LG, DTYPE);           // int16 rows sorted two keys per register
   float x[R];
+  unsigned pk[8];                                  // PACKED: the item's S rows as packed int16 keys (x is filled by the sort)
   if constexpr (WIDE) {
     load_group<R, DTYPE>(x, cur.swap ? args.sig1 : args.sig0, cur.off_s, cur.m, lane);
   } else {
     KsRows<R, LG, DTYPE> first;
     first.request(cur.swap ? args.sig1 : args.sig0, cur.off_s, cur.m, gl);
-    first.finish(x, cur.m, gl);
+    if constexpr (PACKED) first.finish_packed(pk, cur.m, gl);
+    else first.finish(x, cur.m, gl);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 
@@ -303,7 +306,8 @@ void rank_hist_kernel(RankStatsArgs args) {
 #if !(NMOD_SKIP & 4)
     {
       double mean, m2;
-      seg_moments<R, LG, DTYPE>(x, m, mean, m2);
+      if constexpr (PACKED) seg_moments_packed16<LG>(pk, m, gl, mean, m2);
+      else seg_moments<R, LG, DTYPE>(x, m, mean, m2);
       if (valid && gl == 0) {
         double* mo = args.moments + pos * 4 + (swap ? 2 : 0);
         mo[0] = mean; mo[1] = m2;
@@ -311,7 +315,17 @@ void rank_hist_kernel(RankStatsArgs args) {
     }
 #endif
 #if !(NMOD_SKIP & 16)
-    seg_sort_any<R, LG>(x, sel, lane);
+    if constexpr (PACKED) {
+      // (packed_sort_i16.hpp; the top C - m keys of the position are its pads: a sample may equal the pad value 32767,
+      // only the key index tells them apart)
+      seg_sort_packed16<LG>(pk, lane);
+      unpack_sorted16<LG>(pk, x);
+      const int real = m - gl * R;
+#pragma unroll
+      for (int r = 0; r < R; ++r) x[r] = (r < real) ? x[r] : inf;
+    } else {
+      seg_sort_any<R, LG>(x, sel, lane);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) keys[r * ROW + gl] = x[r];
 #endif
@@ -825,7 +839,8 @@ void rank_hist_kernel(RankStatsArgs args) {
 #pragma unroll
       for (int r = 0; r < R; ++r) x[r] = xn[r];
     } else {
-      rows_next.finish(x, nxt.m, gl);
+      if constexpr (PACKED) rows_next.finish_packed(pk, nxt.m, gl);
+      else rows_next.finish(x, nxt.m, gl);
     }
     cur = nxt;
   }

@@ -642,11 +642,14 @@ void ks_rank_kernel(RankStatsArgs args) {
         const bool run_end = s_own[r] != up;
         nkq -= q;
         const int cand_b = __mul24(cl, m) + nkq;                   // v = the S value with upper rank k: cumL(k-1)*m - k*q
-        const unsigned clp16 = (unsigned)cl << 16;
+        const int clp = cl;
         cl += (int)(h[r] >> 16);                                   // cumL(k)
         const int cu = cl - (int)(h[r] & 0xffffu);                 // cumU(k) = cumL(k) - #{x = s_{k+1}}
-        // (the bin's word becomes cumL(k-1) << 16 | cumU(k) for the float-form pass)
-        if (r < R - 1) hist[(r + 1) * ROW + gl] = clp16 | (unsigned)cu; else hist[gl + 1] = clp16 | (unsigned)cu;
+        // (the bin's word becomes cumL(k-1) << 16 | cumU(k) for the float-form pass: two 16-bit stores, no arithmetic)
+        {
+          unsigned short* w16 = reinterpret_cast<unsigned short*>(hist + ((r < R - 1) ? (r + 1) * ROW + gl : gl + 1));
+          w16[0] = (unsigned short)cu; w16[1] = (unsigned short)clp;
+        }
         const int cand_a = __mul24(cu, m) + nkq;                   // v = the largest sample below s_{k+1}: cumU(k)*m - k*q
         const int ca = run_end ? cand_a : 0, cb = run_end ? cand_b : 0;
         hi = max(hi, max(ca, cb));

@@ -313,3 +313,13 @@ int main(void) {
         open(c, 'w').write(src)
         subprocess.check_call(['gcc', '-O2', '-fopenmp', '-mfma', '-ffp-contract=off', c, '-o', os.path.join(d, 'q'), '-lm'])
         assert subprocess.check_output([os.path.join(d, 'q')]).decode() == '0'
+
+
+def test_packed_sort_header_is_what_the_generator_emits():
+    """nanomod_amd/csrc/packed_sort_i16.hpp is generated: tools/gen_packed_sort.py walks the bitonic network on packed int16
+    keys, simulates the emitted program on random / tied / extreme keys for both lane-group sizes (its own assertion) and
+    writes the header — the committed file must be its output."""
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, 'h.hpp')
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_packed_sort.py'), out], stdout=subprocess.DEVNULL)
+        assert open(out).read() == open(os.path.join(ROOT, 'nanomod_amd', 'csrc', 'packed_sort_i16.hpp')).read()

@@ -283,7 +283,7 @@ def main():
             assert out == sorted(v for row in keys for v in row), (LG, trial)
         bodies.append(emit(net))
         costs.append('%d (LG = %d)' % (net.cost(), LG))
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'nanomod_amd', 'csrc', 'packed_sort_i16.hpp')
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'nanomod_amd', 'csrc', 'packed_sort_i16.hpp')
     with open(path, 'w') as f:
         f.write((HEADER % ', '.join(costs)).replace('%%', '%'))
         f.write('\n\n'.join(bodies))

@@ -240,6 +240,20 @@ __device__ __forceinline__ unsigned pk_lane_mirror(unsigned v, int lane) { retur
 template <int SW>
 __device__ __forceinline__ void pk_lane_stage(unsigned (&p)[8], unsigned t0, unsigned t1, unsigned t2, unsigned t3, unsigned t4,
                                               unsigned t5, unsigned t6, unsigned t7, unsigned long long low_mask) {
+#if defined(NMOD_PK_SELECT)
+  // variant without EXEC writes: both results, then a select by the lane mask (4 instructions per register)
+  const unsigned tt[8] = {t0, t1, t2, t3, t4, t5, t6, t7};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    unsigned mn, mx;
+    if constexpr (SW) asm("v_pk_min_i16 %%0, %%2, %%3 op_sel:[0,1] op_sel_hi:[1,0]\\n\\tv_pk_max_i16 %%1, %%2, %%3 op_sel:[0,1] op_sel_hi:[1,0]\\n\\tv_cndmask_b32_e64 %%0, %%1, %%0, %%4"
+                          : "=&v"(mn), "=&v"(mx) : "v"(p[j]), "v"(tt[j]), "s"(low_mask));
+    else asm("v_pk_min_i16 %%0, %%2, %%3\\n\\tv_pk_max_i16 %%1, %%2, %%3\\n\\tv_cndmask_b32_e64 %%0, %%1, %%0, %%4"
+             : "=&v"(mn), "=&v"(mx) : "v"(p[j]), "v"(tt[j]), "s"(low_mask));
+    p[j] = mn;
+  }
+  return;
+#endif
   unsigned long long save;
 #define NMOD_PK8(OP, SEL) \\
   OP " %%0, %%0, %%9" SEL "\\n\\t" OP " %%1, %%1, %%10" SEL "\\n\\t" OP " %%2, %%2, %%11" SEL "\\n\\t" OP " %%3, %%3, %%12" SEL "\\n\\t" \\

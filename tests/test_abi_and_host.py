@@ -323,3 +323,35 @@ def test_packed_sort_header_is_what_the_generator_emits():
         out = os.path.join(d, 'h.hpp')
         subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_packed_sort.py'), out], stdout=subprocess.DEVNULL)
         assert open(out).read() == open(os.path.join(ROOT, 'nanomod_amd', 'csrc', 'packed_sort_i16.hpp')).read()
+
+
+def test_hostwalk_flatten_equals_numpy():
+    """csrc/hostwalk.c (the row walk of detect.build_csr): float64 ndarrays, views, other dtypes, lists of numpy.float64 /
+    floats / ints, tuples and empty rows flatten to what numpy.concatenate gives; a short output buffer raises"""
+    hw = pytest.importorskip('nanomod_amd._hostwalk', reason='make -C nanomod_amd/csrc')
+    rng = np.random.default_rng(4)
+    big = rng.normal(0, 1, (50, 7))
+    rows = [big[3], big[:, 2], np.arange(5, dtype=np.int32), np.float32([1.5, 2.5]), [np.float64(0.25), 1, 2.5], (3.0, 4.0), [],
+            np.zeros(0), big[10].copy(), list(map(np.float64, big[11]))]
+    exp = np.concatenate([np.asarray(r, dtype=np.float64).ravel() for r in rows])
+    out = np.full(len(exp) + 3, -1.0)
+    assert hw.flatten(rows, out) == len(exp)
+    assert np.array_equal(out[:len(exp)], exp) and np.all(out[len(exp):] == -1.0)
+    assert hw.flatten(tuple(rows), out) == len(exp)
+    with pytest.raises(ValueError):
+        hw.flatten(rows, np.empty(len(exp) - 1))
+    with pytest.raises(TypeError):
+        hw.flatten([['a']], np.empty(4))
+    # through build_csr: the reference's dict-of-dict-of-list shape and the array shape give the same CSR
+    import nanomod_amd.detect as D
+    vals = np.round(rng.normal(0, 1, (300, 9)), 3)
+    def ds(as_list):
+        d = {i + 10: ([np.float64(v) for v in vals[i]] if as_list else vals[i].copy()) for i in range(300)}
+        return {'norm_mean': {('chr1', '+'): d}, 'base': {('chr1', '+'): {i + 10: 'A' for i in range(300)}}, 'basedict': {}}
+    got = []
+    for as_list in (True, False):
+        mo = {'ds2': ['a', 'b'], 'a': ds(as_list), 'b': ds(as_list), 'MinCoverage': 5, 'outLevel': 3}
+        meta, s0, o0, s1, o1, rid = D.build_csr(mo)
+        got.append((s0.copy(), o0.copy()))
+        assert len(meta['pos']) == 300 and o0[-1] == 2700
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])

@@ -265,7 +265,8 @@ __device__ __forceinline__ void pk_lane_stage(unsigned (&p)[8], unsigned t0, uns
                  NMOD_PK8("v_pk_max_i16", " op_sel:[0,1] op_sel_hi:[1,0]")
                  "s_mov_b64 exec, %%8\\n\\ts_nop 4"       // (EXEC write -> the next stage's DPP moves: 5 wait states, by hand)
                  : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "=&s"(save)
-                 : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4), "v"(t5), "v"(t6), "v"(t7), "s"(low_mask));
+                 : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4), "v"(t5), "v"(t6), "v"(t7), "s"(low_mask)
+                 : "scc");            // (s_and_b64 / s_andn2_b64 write SCC: without the clobber a loop compare can be live across the block)
   } else {
     asm("s_mov_b64 %%8, exec\\n\\ts_and_b64 exec, %%8, %%17\\n\\t"
                  NMOD_PK8("v_pk_min_i16", "")
@@ -273,7 +274,8 @@ __device__ __forceinline__ void pk_lane_stage(unsigned (&p)[8], unsigned t0, uns
                  NMOD_PK8("v_pk_max_i16", "")
                  "s_mov_b64 exec, %%8\\n\\ts_nop 4"       // (EXEC write -> the next stage's DPP moves: 5 wait states, by hand)
                  : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "=&s"(save)
-                 : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4), "v"(t5), "v"(t6), "v"(t7), "s"(low_mask));
+                 : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4), "v"(t5), "v"(t6), "v"(t7), "s"(low_mask)
+                 : "scc");            // (s_and_b64 / s_andn2_b64 write SCC: without the clobber a loop compare can be live across the block)
   }
 #undef NMOD_PK8
 }

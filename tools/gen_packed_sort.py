@@ -179,7 +179,7 @@ def emit(net):
         elif op[0] == 'xhc':
             D = op[1]
             bit = D.bit_length() - 1
-            L.append('  pk_dpp_guard();')
+            L.append('  pk_dpp_guard(p);')
             for j in range(NREG):
                 L.append('  t%d = pk_lane_xor<%d>(p[%d]);' % (j, D, j))
             L.append('  pk_lane_stage<%s>(p, t0, t1, t2, t3, t4, t5, t6, t7, 0x%016xull);' % ('0', LANE_BIT_MASK[bit]))
@@ -188,7 +188,7 @@ def emit(net):
             bit = (G >> 1).bit_length() - 1
             sws = set(sw for _, sw in src)
             assert len(sws) == 1, 'mixed half orders in a mirror stage'
-            L.append('  pk_dpp_guard();')
+            L.append('  pk_dpp_guard(p);')
             for j in range(NREG):
                 L.append('  t%d = pk_lane_mirror<%d>(p[%d], lane);' % (j, G, src[j][0]))
             L.append('  pk_lane_stage<%s>(p, t0, t1, t2, t3, t4, t5, t6, t7, 0x%016xull);' % ('1' if sws.pop() else '0', LANE_BIT_MASK[bit]))
@@ -235,7 +235,10 @@ __device__ __forceinline__ void pk_ce_within(unsigned& a) {
 }
 // a VGPR written by VALU needs two wait states before a DPP instruction reads it; the compiler's hazard recognizer does not
 // look into the inline asm above, so the distance is kept by hand in front of every group of DPP moves
-__device__ __forceinline__ void pk_dpp_guard() { asm volatile("s_nop 1"); }
+// (the registers pass through the statement, so it stays between their writers and the moves)
+__device__ __forceinline__ void pk_dpp_guard(unsigned (&p)[8]) {
+  asm volatile("s_nop 1" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+}
 template <int M>
 __device__ __forceinline__ unsigned pk_lane_xor(unsigned v) { return __float_as_uint(lane_xor<M>(__uint_as_float(v))); }
 template <int G>

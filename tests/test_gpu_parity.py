@@ -931,3 +931,56 @@ def test_ks_only_d_is_bit_exact_and_the_rational_flag_opts_out(nm):
     assert np.array_equal(res['ks_d'].cpu().numpy(), exp['ks_d'])
     with pytest.raises(L.NanomodLibraryError):
         nm.DeviceDetector(0, tests=L.TEST_KS, flags=8).run(da, db, r, off0=o0, off1=o1, max_n0=900, max_n1=900)
+
+
+@pytest.mark.parametrize('all_tests', [False, True])
+def test_int16_packed_sort_edges(nm, all_tests):
+    """The packed-int16 sorting network (16 keys per lane: smaller groups of 1..256 samples, both lane-group sizes) on the
+    cases its pads and row loads can get wrong: every smaller-group size 1..260 (rows shorter than four samples, sizes
+    that are not multiples of four, the class boundaries 64 / 128 / 256), samples EQUAL to the pad value 32767 and to
+    -32768, constant groups, and tie-heavy data; fixed-stride and CSR; against the oracle (D and U exact)."""
+    import oracle_c
+    L = nm._lib
+    rng = np.random.default_rng(2026)
+    sizes = np.arange(1, 261)
+    n0 = sizes.copy()
+    n1 = rng.integers(1, 300, len(sizes)); n1[::7] = n0[::7]
+    off0 = np.zeros(len(sizes) + 1, np.int64); off0[1:] = np.cumsum(n0)
+    off1 = np.zeros(len(sizes) + 1, np.int64); off1[1:] = np.cumsum(n1)
+    for mode in ('normal', 'extremes', 'coarse'):
+        if mode == 'normal':
+            a = np.rint(rng.normal(0, 1000, off0[-1])); b = np.rint(rng.normal(100, 1100, off1[-1]))
+        elif mode == 'extremes':
+            a = rng.choice([32767, 32766, -32768, 0, 5], off0[-1]).astype(np.float64)
+            b = rng.choice([32767, -32768, -32767, 0, 7], off1[-1]).astype(np.float64)
+        else:
+            a = np.rint(rng.normal(0, 3, off0[-1])); b = np.rint(rng.normal(0.5, 3, off1[-1]))
+        a = np.clip(a, -32768, 32767).astype(np.int16); b = np.clip(b, -32768, 32767).astype(np.int16)
+        rid = np.zeros(len(sizes), np.int32)
+        tests = 7 if all_tests else 1
+        exp = oracle_c.detect_batch(a, off0, b, off1, rid, 2, 2.0, 'stouffer', tests=tests, threads=0)
+        for swap in (False, True):
+            args = (b, off1, a, off0) if swap else (a, off0, b, off1)
+            got = nm.detect_host(*args, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_ALL if all_tests else L.TEST_KS)
+            assert np.array_equal(got['ks_d'], exp['ks_d']), (mode, swap)
+            H.assert_close_p(got['ks_p'], exp['ks_p'], 1e-9, 'ks_p %s' % mode)
+            if all_tests:
+                ident = (exp['status'] & 1) != 0
+                assert np.array_equal(got['mwu_u'][~ident], exp['mwu_u'][~ident]), (mode, swap)
+                H.assert_close_p(got['mwu_p'][~ident], exp['mwu_p'][~ident], 1e-9, 'mwu_p %s' % mode)
+                tt = exp['t_t'] * (-1.0 if swap else 1.0)
+                H.assert_close_stat(got['t_t'], tt, 1e-11, 2e-14, 't_t %s' % mode)
+    # fixed stride, sizes around the class boundaries and not multiples of four
+    for n in (3, 63, 65, 127, 130, 199, 201, 255, 256):
+        P = 64
+        a = np.rint(rng.normal(0, 800, P * n)).astype(np.int16); b = np.rint(rng.normal(50, 900, P * n)).astype(np.int16)
+        a[:n] = 32767; b[n:2 * n] = 32767
+        o = np.arange(0, (P + 1) * n, n, dtype=np.int64)
+        exp = oracle_c.detect_batch(a, o, b, o, np.zeros(P, np.int32), 2, 2.0, 'stouffer', tests=7 if all_tests else 1, threads=0)
+        got = nm.detect_host(a, None, b, None, np.zeros(P, np.int32), nb=2, weights_dif=2.0, method='stouffer',
+                             tests=L.TEST_ALL if all_tests else L.TEST_KS, stride0=n, stride1=n)
+        assert np.array_equal(got['ks_d'], exp['ks_d']), n
+        H.assert_close_p(got['comb_p'], exp['comb_p'], 1e-9, 'comb_p stride %d' % n)
+        if all_tests:
+            ident = (exp['status'] & 1) != 0
+            assert np.array_equal(got['mwu_u'][~ident], exp['mwu_u'][~ident]), n

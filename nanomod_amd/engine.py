@@ -57,11 +57,11 @@ def _join_warm_up(device):
 
 
 def detect_host(sig0, off0, sig1, off1, run_id, *, nb=2, weights_dif=2.0, method='stouffer',
-                tests=L.TEST_ALL, want_mstd=False, device=0, stride0=0, stride1=0):
+                tests=L.TEST_ALL, want_mstd=False, device=0, stride0=0, stride1=0, flags=0):
     """Run the hot path on host-resident CSR inputs; returns a dict of numpy arrays.
 
     sig0/sig1: float32 (canonical), int16 (milli-units) or float64 1-D arrays; off0/off1:
-    int64[npos+1] (or None with a fixed stride); run_id: int32[npos]."""
+    int64[npos+1] (or None with a fixed stride); run_id: int32[npos]; flags: L.FLAG_* (include/nanomod_hip.h)."""
     lib = L.load()
     _join_warm_up(device)
     sig0 = np.ascontiguousarray(sig0)
@@ -88,7 +88,7 @@ def detect_host(sig0, off0, sig1, off1, run_id, *, nb=2, weights_dif=2.0, method
             raise ValueError('run_id must be int32[npos]')
     prm = L.make_params(device=device, memspace=L.MEM_HOST, dtype=dtype, tests=tests, method=method_id,
                         nb=nb, weights_dif=weights_dif, want_mstd=int(bool(want_mstd)),
-                        stride0=stride0 if off0 is None else 0, stride1=stride1 if off1 is None else 0)
+                        stride0=stride0 if off0 is None else 0, stride1=stride1 if off1 is None else 0, flags=flags)
     res = {}
     out = L.NmodOut()
     wanted = []

@@ -439,8 +439,12 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   const bool uniform = prm->stride0 > 0 && prm->stride1 > 0;
   int64_t max0 = prm->stride0 > 0 ? prm->stride0 : prm->max_n0;
   int64_t max1 = prm->stride1 > 0 ? prm->stride1 : prm->max_n1;
-  NMOD_HIP(hipMemsetAsync(ws.meta, 0, kMetaInts * 4, stream));
+  // the class counters / cursors / maxima in ws.meta: cleared once per batch, and not at all for a fixed-stride batch of
+  // wave-resident positions (one launch, no lists: the common benchmark shape pays no memset per step)
+  bool meta_cleared = false;
   if (max0 <= 0 || max1 <= 0) {
+    NMOD_HIP(hipMemsetAsync(ws.meta, 0, kMetaInts * 4, stream));
+    meta_cleared = true;
     hipLaunchKernelGGL(max_n_kernel, dim3(1024), dim3(256), 0, stream, npos,
                        prm->stride0 > 0 ? nullptr : off0, prm->stride1 > 0 ? nullptr : off1, ws.meta);
     NMOD_HIP(hipGetLastError());
@@ -457,6 +461,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   const bool big_possible = all ? (cmax0 >= kNumSizeClasses || cmax1 >= kNumSizeClasses)
                                 : (std::min(cmax0, cmax1) >= kNumSizeClasses);
   cmax0 = std::min(cmax0, kNumSizeClasses - 1); cmax1 = std::min(cmax1, kNumSizeClasses - 1);
+  if (!meta_cleared && (!(uniform && !big_possible) || f64)) NMOD_HIP(hipMemsetAsync(ws.meta, 0, kMetaInts * 4, stream));
 
   RankStatsArgs ra;
   memset(&ra, 0, sizeof(ra));

@@ -44,8 +44,15 @@ struct RankStatsArgs {
   uint8_t* tied;                               // [npos] or null: 1 where the position's keys tie (see ks_rank_kernel FLAGS; all-tests: any tie)
 };
 
+// compare-exchange of two registers.  (fminf / fmaxf put a canonicalising v_max x, x in front of every value of unknown
+// origin — one per key loaded from memory; the keys are ordinary numbers or +-inf, so the bare instructions are used)
 __device__ __forceinline__ void ce(float& lo, float& hi) {
+#if defined(NMOD_CE_BUILTIN)
   float a = fminf(lo, hi), b = fmaxf(lo, hi);
+#else
+  float a, b;
+  asm("v_min_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3" : "=&v"(a), "=v"(b) : "v"(lo), "v"(hi));
+#endif
   lo = a; hi = b;
 }
 

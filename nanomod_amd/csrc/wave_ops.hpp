@@ -47,8 +47,14 @@ __device__ __forceinline__ float lane_xor(float x) {
   else if constexpr (M == 2) return dpp_f<NMOD_QP(2, 3, 0, 1), 0xf, 0xf, true>(0.0f, x);
   else if constexpr (M == 8) return dpp_f<0x120 + 8, 0xf, 0xf, true>(0.0f, x);   // row_ror:8 == xor 8 inside a row
   else if constexpr (M == 4) {
+#if defined(NMOD_XOR4_BANKS)
     float y = dpp_f<kDppRowShl + 4, 0xf, 0x5>(x, x);   // banks 0,2 read lane+4
     return dpp_f<kDppRowShr + 4, 0xf, 0xA>(y, x);      // banks 1,3 read lane-4
+#else
+    // l ^ 4 = (l ^ 7) ^ 3: a mirror of the 8-lane half, then of the quad — two full moves (the bank-masked pair above
+    // needs a copy of x first and writes one register twice: three dependent instructions)
+    return dpp_f<NMOD_QP(3, 2, 1, 0), 0xf, 0xf, true>(0.0f, dpp_f<kDppRowHalfMirror, 0xf, 0xf, true>(0.0f, x));
+#endif
   } else {
     static_assert(M == 16, "lane_xor: unsupported distance");
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));  // bit mode: xor 0x10

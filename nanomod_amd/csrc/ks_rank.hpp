@@ -268,7 +268,7 @@ __device__ __forceinline__ double hist_exact_quot(int c, double n, double r) {
 // the lane's 16 halves, the pads' share taken out by their count, and n S2 - S1^2 — exact for n <= 2 048 — rounded
 // once.  Milli-units: mean = S1 / n / 1000, M2 = (n S2 - S1^2) / n * 1e-6.
 template <int LG>
-__device__ __forceinline__ void seg_moments_packed16(const unsigned (&p)[8], int n, int gl, double& mean, double& m2) {
+__device__ __forceinline__ void seg_moments_packed16(const unsigned (&p)[8], int n, int gl, double& mean, double& m2, double rcp_n = 0.0) {
   int s1 = 0;
   double s2 = 0.0;
 #pragma unroll
@@ -296,8 +296,9 @@ __device__ __forceinline__ void seg_moments_packed16(const unsigned (&p)[8], int
   const double S2 = seg_allsum_f64<LG>(s2);                                   // <= 256 * 2^30
   const double dn = (double)n;
   const double num = __fma_rn(dn, S2, -S1 * S1);                              // n * M2 in milli-units^2: every term an integer < 2^53
-  mean = S1 / dn / 1000.0;
-  m2 = num / dn * 1e-6;
+  const double rn = (rcp_n != 0.0) ? rcp_n : 1.0 / dn;
+  mean = S1 * rn * 1e-3;
+  m2 = num * rn * 1e-6;
 }
 
 // second launch-bound argument = minimum waves per SIMD: keeps every form whose LDS footprint allows

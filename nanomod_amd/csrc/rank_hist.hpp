@@ -306,8 +306,9 @@ void rank_hist_kernel(RankStatsArgs args) {
 #if !(NMOD_SKIP & 4)
     {
       double mean, m2;
-      if constexpr (PACKED) seg_moments_packed16<LG>(pk, m, gl, mean, m2);
-      else seg_moments<R, LG, DTYPE>(x, m, mean, m2);
+      const double rcp_m = uniform ? recip[0] : 0.0;               // fl(1/m) of a fixed-stride batch (parked in LDS)
+      if constexpr (PACKED) seg_moments_packed16<LG>(pk, m, gl, mean, m2, rcp_m);
+      else seg_moments<R, LG, DTYPE>(x, m, mean, m2, rcp_m);
       if (valid && gl == 0) {
         double* mo = args.moments + pos * 4 + (swap ? 2 : 0);
         mo[0] = mean; mo[1] = m2;
@@ -669,9 +670,10 @@ void rank_hist_kernel(RankStatsArgs args) {
       const double KQ = (double)kqf;
       const double s1 = seg_allsum_f64<LG>(s1w), s2 = seg_allsum_f64<LG>(s2w);
       const double dn = (double)q;
-      double mu = KQ + s1 / dn;
-      double qq = s2 - s1 * s1 / dn;
-      if constexpr (DTYPE != 0) { mu = mu / 1000.0; qq = qq * 1e-6; }
+      const double rn = uniform ? recip[1] : 1.0 / dn;             // one division for mean and M2, none for a fixed-stride batch
+      double mu = KQ + s1 * rn;
+      double qq = s2 - s1 * s1 * rn;
+      if constexpr (DTYPE != 0) { mu = mu * 1e-3; qq = qq * 1e-6; }
       if (valid && gl2 == 0) {
         double* mo = args.moments + pos * 4 + (swap ? 0 : 2);
         mo[0] = mu; mo[1] = qq;
@@ -710,9 +712,10 @@ void rank_hist_kernel(RankStatsArgs args) {
       s1 = seg_allsum_f64<LG>(s1);
       s2 = seg_allsum_f64<LG>(s2);
       const double dn = (double)q;
-      double mu = KQ + s1 / dn;
-      double qq = s2 - s1 * s1 / dn;
-      if constexpr (DTYPE != 0) { mu = mu / 1000.0; qq = qq * 1e-6; }
+      const double rn = uniform ? recip[1] : 1.0 / dn;             // one division for mean and M2, none for a fixed-stride batch
+      double mu = KQ + s1 * rn;
+      double qq = s2 - s1 * s1 * rn;
+      if constexpr (DTYPE != 0) { mu = mu * 1e-3; qq = qq * 1e-6; }
       if (valid && gl2 == 0) {
         double* mo = args.moments + pos * 4 + (swap ? 0 : 2);
         mo[0] = mu; mo[1] = qq;

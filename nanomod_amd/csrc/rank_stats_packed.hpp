@@ -34,13 +34,14 @@ __device__ __forceinline__ int seg_scan_max_i32(int v) {
 }
 
 __device__ __forceinline__ double dpp_f64_row(double x, int which) {
+  // (bound_ctrl with old = 0: every lane has a valid source in these patterns, and a tied `old` would cost a copy per half)
   long long b = __double_as_longlong(x);
   int lo = (int)(unsigned)b, hi = (int)(unsigned)((unsigned long long)b >> 32);
   switch (which) {
-    case 0: lo = dpp_i<NMOD_QP(1, 0, 3, 2)>(lo, lo); hi = dpp_i<NMOD_QP(1, 0, 3, 2)>(hi, hi); break;
-    case 1: lo = dpp_i<NMOD_QP(2, 3, 0, 1)>(lo, lo); hi = dpp_i<NMOD_QP(2, 3, 0, 1)>(hi, hi); break;
-    case 2: lo = dpp_i<kDppRowHalfMirror>(lo, lo); hi = dpp_i<kDppRowHalfMirror>(hi, hi); break;
-    default: lo = dpp_i<kDppRowMirror>(lo, lo); hi = dpp_i<kDppRowMirror>(hi, hi); break;
+    case 0: lo = dpp_i<NMOD_QP(1, 0, 3, 2), 0xf, 0xf, true>(0, lo); hi = dpp_i<NMOD_QP(1, 0, 3, 2), 0xf, 0xf, true>(0, hi); break;
+    case 1: lo = dpp_i<NMOD_QP(2, 3, 0, 1), 0xf, 0xf, true>(0, lo); hi = dpp_i<NMOD_QP(2, 3, 0, 1), 0xf, 0xf, true>(0, hi); break;
+    case 2: lo = dpp_i<kDppRowHalfMirror, 0xf, 0xf, true>(0, lo); hi = dpp_i<kDppRowHalfMirror, 0xf, 0xf, true>(0, hi); break;
+    default: lo = dpp_i<kDppRowMirror, 0xf, 0xf, true>(0, lo); hi = dpp_i<kDppRowMirror, 0xf, 0xf, true>(0, hi); break;
   }
   return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
@@ -122,7 +123,7 @@ __device__ __forceinline__ void load_packed(float (&x)[R], const void* sig, int6
 // The shift keeps the cancellation in M2 at ~(1 + (mean - K)^2 / var) ulps of fp64 — np.var's two-pass result to
 // ~1e-14 — for half the instructions of two masked passes (a pad becomes K: it adds 0 to both sums).
 template <int R, int LG, int DTYPE>
-__device__ __forceinline__ void seg_moments(const float (&x)[R], int n, double& mean, double& m2) {
+__device__ __forceinline__ void seg_moments(const float (&x)[R], int n, double& mean, double& m2, double rcp_n = 0.0) {
   const float inf = __builtin_inff();
   const int lane = threadIdx.x & 63;
   float kf = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & ~(LG - 1)) << 2, __float_as_int(x[0])));
@@ -140,10 +141,11 @@ __device__ __forceinline__ void seg_moments(const float (&x)[R], int n, double& 
   s1 = seg_allsum_f64<LG>(s1);
   s2 = seg_allsum_f64<LG>(s2);
   const double dn = (double)n;
-  const double mu = K + s1 / dn;
-  const double q = s2 - s1 * s1 / dn;
+  const double rn = (rcp_n != 0.0) ? rcp_n : 1.0 / dn;                // one division for mean and M2 (none when the caller has fl(1/n))
+  const double mu = K + s1 * rn;
+  const double q = s2 - s1 * s1 * rn;
   if constexpr (DTYPE == 0) { mean = mu; m2 = q; }
-  else { mean = mu / 1000.0; m2 = q * 1e-6; }
+  else { mean = mu * 1e-3; m2 = q * 1e-6; }
 }
 
 }  // namespace nmod

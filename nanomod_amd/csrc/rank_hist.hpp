@@ -165,7 +165,10 @@ constexpr unsigned kWideEmpty = 0xffffffffu;
 #endif
 constexpr int kWideProbes = NMOD_WIDE_PROBES;      // steps of a walk before the sample is deferred
 constexpr int kWideList = 128;                     // words of the deferred list: < 64 waiting + <= 64 of one sample slot
-__host__ __device__ constexpr int wide_slots(int cq) { return 128 << cq; }
+#ifndef NMOD_WIDE_I16_BITS
+#define NMOD_WIDE_I16_BITS 8
+#endif
+constexpr int kWideI16Bits = NMOD_WIDE_I16_BITS;   // int16 samples: bits per direct-address counter
 
 template <int R, int LG, int DTYPE, bool WIDE = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (WIDE ? 2 : (R <= 16 ? NMOD_HIST_WAVES : 2)))
@@ -182,12 +185,9 @@ void rank_hist_kernel(RankStatsArgs args) {
   int wide_log = 0;                                                                // WIDE: log2 of the wave's hash slots
   int wide_passes = 1;                                                             // WIDE: hash passes over Q
   if constexpr (WIDE) {
-    if (args.class_id >= kWideBigBase) {           // Q of 2 049 .. 4 096 samples: two passes, half of the values each
-      wide_log = 12; wide_passes = 2;
-    } else {
-      const int ca = args.class_id / kNumSizeClasses, cb = args.class_id % kNumSizeClasses;
-      wide_log = 7 + (ca > cb ? ca : cb);
-    }
+    wide_log = wide_table_log(args.class_id, DTYPE);
+    // (float32) Q of 2 049 .. 4 096 samples: two passes, half of the values each
+    if (DTYPE == 0 && args.class_id >= kWideBigBase) wide_passes = 2;
   }
   const int wslots = WIDE ? (1 << wide_log) : 0;
   const int POS_WORDS = BIN_WORDS + wslots + (WIDE ? kWideList : 0);               // WIDE: the table and the deferred list behind them (16-byte aligned)
@@ -374,7 +374,141 @@ void rank_hist_kernel(RankStatsArgs args) {
 
     unsigned ppq = 0;                              // WIDE: ties inside Q from the hash table
     double s1w = 0.0, s2w = 0.0;                   // WIDE: Q's shifted moment sums
-    if constexpr (WIDE) {
+    if constexpr (WIDE && DTYPE == 1) {
+      // int16 samples: the ties inside Q from direct-address counts.  The wave's table holds one counter per VALUE of a
+      // window of the milli-unit domain (kWideI16Bits bits each, packed into 32-bit words): one returning LDS add per
+      // sample gives the number of earlier copies of its value, p - 1 — no hashing, no walks, one round trip.  A pre-pass
+      // takes min and max of Q (packed min / max on the raw words); Q is streamed once per window of [min, max]: one
+      // pass when the position's range fits the table (real events: a few hundred milli-units), the first pass fused
+      // with the ranking.
+      unsigned* ht = reinterpret_cast<unsigned*>(keys) + BIN_WORDS;
+      constexpr int CB = kWideI16Bits;                                      // bits per counter
+      constexpr int CPW_LOG = (CB == 16) ? 1 : 2;                           // log2 counters per word
+      const int wlog = wide_log + CPW_LOG;                                  // log2 values per window
+      int vmin = 0, vmax = 0;
+      if (q > 0) {
+        typedef short S2 __attribute__((ext_vector_type(2)));
+        S2 mn = {32767, 32767}, mx = {-32768, -32768};
+#pragma unroll 2
+        for (int c = 0; c < full; ++c) {
+          const Q4Raw r = load_q4(sig_q, off_q, c * (4 * LG) + 4 * gl, true);
+          const S2 a = {(short)r.x, (short)r.y}, b = {(short)r.z, (short)r.w};
+          mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(a, b));
+          mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(a, b));
+        }
+        int lo = min((int)mn.x, (int)mn.y), hi = max((int)mx.x, (int)mx.y);
+        for (int c = 0; c < tail; ++c) {
+          const int idx = min(full * (4 * LG) + c * LG + gl, q - 1);       // (a sample read twice changes neither)
+          const int v = (int)load_q1(sig_q, off_q, idx, true);
+          lo = min(lo, v); hi = max(hi, v);
+        }
+        vmax = (int)wave_max_u32((unsigned)(hi + 32768)) - 32768;
+        vmin = 32767 - (int)wave_max_u32((unsigned)(32767 - lo));
+      }
+      const int npass = ((vmax - vmin) >> wlog) + 1;
+      const int kq = (q > 0) ? (int)rk : 0;                                 // shift of Q's moment sums
+      int s1i = 0; long long s2i = 0;                                        // sum (x - kq), sum (x - kq)^2: exact integers
+      unsigned long long ovf = 0ull;                                         // (8-bit counters) a counter reached 255
+      auto count_many = [&](auto cb_tag, auto nv_tag, const int* iv, const bool* have, int wb) {
+        constexpr int BITS = decltype(cb_tag)::value, NV = decltype(nv_tag)::value;
+        constexpr int PW_LOG = (BITS == 16) ? 1 : 2;
+        unsigned old[NV], sh[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+          const unsigned u = (unsigned)(iv[e] - wb);
+          const bool in = have[e] && u < ((unsigned)wslots << PW_LOG);
+          sh[e] = (u & ((1u << PW_LOG) - 1u)) * (unsigned)BITS;
+          old[e] = 0u;
+#if !(NMOD_SKIP & 128)
+          if (in) old[e] = atomicAdd(&ht[u >> PW_LOG], 1u << sh[e]);
+#endif
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+          const unsigned c = (old[e] >> sh[e]) & ((1u << BITS) - 1u);      // earlier copies of the value: p - 1
+          ppq += __umul24(c, c) + c;                                        // p (p - 1)
+          if constexpr (BITS == 8) ovf |= __ballot(c == 255u);              // the add wrapped the counter into its neighbour
+        }
+      };
+      auto clear_table = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < wslots / 4; i += 64) reinterpret_cast<uint4*>(ht)[i] = make_uint4(0u, 0u, 0u, 0u);
+      };
+#pragma unroll 1
+      for (int pass = 0; pass < npass; ++pass) {
+        const bool first = pass == 0;                // the pass that also ranks the samples and sums their moments
+        const int wb = vmin + (pass << wlog);
+        clear_table();
+        if (!first) {
+          ra = load_q4(sig_q, off_q, 4 * gl, 0 < full);
+          rt = load_q1(sig_q, off_q, full * (4 * LG) + gl, full * (4 * LG) + gl < q);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll 1
+        for (int c = 0; c < full_w; ++c) {
+          const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
+          const int iv[4] = {(int)ra.x, (int)ra.y, (int)ra.z, (int)ra.w};
+          const bool hv[4] = {true, true, true, true};
+          if (first) {
+            float xa[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xa[e] = (float)iv[e];
+            unsigned ad[4];
+#if !(NMOD_SKIP & 512)
+            rank_many(std::integral_constant<int, 4>{}, xa, true, ad);
+#endif
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int d = iv[e] - kq; s1i += d; s2i += (long long)d * (long long)d; }
+          }
+          count_many(std::integral_constant<int, CB>{}, std::integral_constant<int, 4>{}, iv, hv, wb);
+          ra = rb;
+        }
+#pragma unroll 1
+        for (int c = 0; c < tail_w; ++c) {
+          const int idx_now = full * (4 * LG) + c * LG + gl;
+          const bool have = idx_now < q;
+          const int iv1[1] = {(int)rt};
+          const int idx = full * (4 * LG) + (c + 1) * LG + gl;
+          rt = load_q1(sig_q, off_q, idx, idx < q);
+          const bool hv[1] = {have};
+          if (first) {
+            const float xq1[1] = {have ? (float)iv1[0] : big};
+            unsigned a1[1];
+#if !(NMOD_SKIP & 512)
+            rank_many(std::integral_constant<int, 1>{}, xq1, have, a1);
+#endif
+            const int d = have ? iv1[0] - kq : 0;
+            s1i += d; s2i += (long long)d * (long long)d;
+          }
+          count_many(std::integral_constant<int, CB>{}, std::integral_constant<int, 1>{}, iv1, hv, wb);
+        }
+      }
+      if constexpr (CB == 8) {
+        // 256 or more samples of Q with one value (a constant stretch of signal): the 8-bit counts are void — the ties
+        // of this position are counted again with 16-bit counters, half the window per pass, one sample per lane and trip
+        if (ovf != 0ull) {
+          ppq = 0u;
+          const int np16 = ((vmax - vmin) >> (wide_log + 1)) + 1;
+#pragma unroll 1
+          for (int pass = 0; pass < np16; ++pass) {
+            const int wb = vmin + (pass << (wide_log + 1));
+            clear_table();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for (int i0 = 0; i0 < q; i0 += 64) {
+              const bool hv[1] = {i0 + lane < q};
+              const int iv1[1] = {(int)load_q1(sig_q, off_q, i0 + lane, hv[0])};
+              count_many(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{}, iv1, hv, wb);
+            }
+          }
+        }
+      }
+      // exact sums to doubles (|s1| < 2^23 and s2 < 2^39 per lane): the common moments code below reduces them
+      s1w = (double)s1i; s2w = (double)s2i;
+    } else if constexpr (WIDE) {
       unsigned* ht = reinterpret_cast<unsigned*>(keys) + BIN_WORDS;
       const float kqf = (q > 0) ? (float)rk : 0.0f;
       const double KQ = (double)kqf;

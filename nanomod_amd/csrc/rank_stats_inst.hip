@@ -109,7 +109,7 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
   if (!ks) return hipErrorInvalidValue;
   fn = pick_ks(cls - kKsClassBase, args.tied != nullptr);
 #endif
-  const size_t lds = rank_stats_lds_bytes(cls, ALL);
+  const size_t lds = rank_stats_lds_bytes(cls, ALL, DT);
   if (ks || packed) {
     const int pw = ks ? ks_positions_per_wave(cls - kKsClassBase) : packed_positions_per_wave(cls - kNumGeneralClasses);
     work_items = (work_items + pw - 1) / pw;
@@ -125,7 +125,7 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
     // (one WIDE instance serves every class of the larger group: its limit is that of the largest)
     size_t lds_limit = lds;
 #if NMOD_INST_ALL
-    if (wide) lds_limit = rank_stats_lds_bytes(kWideBigBase + wide_class_of_s(cls), ALL);
+    if (wide) lds_limit = rank_stats_lds_bytes(kWideBigBase + wide_class_of_s(cls), ALL, DT);
 #endif
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit);

@@ -45,6 +45,18 @@ inline bool wide_class(int cls) {
   if (cls >= kWideBigBase) return cls < kWideBigBase + kNumWideBig;
   return cls < kNumGeneralClasses && (cls / kNumSizeClasses <= 2 || cls % kNumSizeClasses <= 2);
 }
+// log2 of the 32-bit words of a wave's tie table in the WIDE form (rank_hist.hpp).  float32: the multiset hash table,
+// 128 << (class of the larger group) slots, at least twice the samples it can receive (4 096 for the two-pass classes).
+// int16: direct-address counters over a window of the value domain, the same size for every class.
+#ifndef NMOD_WIDE_I16_LOG
+#define NMOD_WIDE_I16_LOG 11
+#endif
+__host__ __device__ static inline int wide_table_log(int cls, int dtype) {
+  if (dtype == 1) return NMOD_WIDE_I16_LOG;
+  if (cls >= kWideBigBase) return 12;
+  const int c0 = cls / kNumSizeClasses, c1 = cls % kNumSizeClasses;
+  return 7 + (c0 < c1 ? c1 : c0);
+}
 inline int wide_class_of_s(int cls) {              // capacity class of the smaller group of a WIDE class
   if (cls >= kWideBigBase) return cls - kWideBigBase;
   return cls / kNumSizeClasses < cls % kNumSizeClasses ? cls / kNumSizeClasses : cls % kNumSizeClasses;
@@ -54,14 +66,12 @@ inline int ks_lanes_per_group(int cs) { return cs <= 1 ? 8 : (cs == 2 ? 16 : (8 
 inline int ks_positions_per_wave(int cs) { return 64 / ks_lanes_per_group(cs); }
 // packed all-tests classes (rank_hist.hpp): the same (R, LG) per capacity as the KS-only classes 0..4
 inline int packed_positions_per_wave(int cm) { return ks_positions_per_wave(cm); }
-inline size_t rank_stats_lds_bytes(int cls, bool all) {
+static inline size_t rank_stats_lds_bytes(int cls, bool all, int dtype) {
   size_t words;
   if (wide_class(cls)) {
-    // rank_hist_kernel WIDE (rank_hist.hpp): keys + bins of S (rounded to 16 bytes) + the wave's hash table, + two doubles
-    const int c0 = cls / kNumSizeClasses, c1 = cls % kNumSizeClasses;
+    // rank_hist_kernel WIDE (rank_hist.hpp): keys + bins of S (rounded to 16 bytes) + the wave's tie table, + two doubles
     const size_t R = (size_t)1 << wide_class_of_s(cls);
-    const int cq = cls >= kWideBigBase ? kNumSizeClasses - 1 : (c0 < c1 ? c1 : c0);
-    const size_t w = ((2 * R * 65 + 3) & ~(size_t)3) + ((size_t)128 << cq) + 128;   // + kWideList (rank_hist.hpp)
+    const size_t w = ((2 * R * 65 + 3) & ~(size_t)3) + ((size_t)1 << wide_table_log(cls, dtype)) + 128;   // + kWideList (rank_hist.hpp)
     return w * 4 * 4 + 16;
   } else if (cls >= kKsClassBase) {
     int cs = cls - kKsClassBase;

@@ -384,13 +384,16 @@ def test_ks_only_large_ranked_group(nm):
         assert abs(got['ks_d'][i] - d) <= 0.0 and abs(got['ks_p'][i] - max(p, orc.DBL_MIN)) <= 1e-9 * max(p, orc.DBL_MIN), i
 
 
-@pytest.mark.parametrize('mode', ['cont', 'grid1', 'const', 'i16', 'f64', 'f64ties'])
+@pytest.mark.parametrize('mode', ['cont', 'grid1', 'const', 'i16', 'i16const', 'i16span', 'i16heavy', 'f64', 'f64ties'])
 def test_unequal_classes_streamed_larger_group(nm, mode):
     """positions whose groups fall in different capacity classes with the smaller one <= 256 samples: the WIDE form of
     rank_hist_kernel (smaller group sorted, larger one streamed and counted in a per-wave hash table), the larger group up
     to 2 048 in one pass and 2 049 .. 4 096 in two; either group may be the larger one.  `const`: every sample of a
     position equal — the longest probe chains and the largest tie sums (256 keys tied with 4 096 samples: a b (a + b)
-    and the sum of t^3 - t pass 2^32)"""
+    and the sum of t^3 - t pass 2^32).  int16 input counts the ties of the larger group in direct-address 8-bit counters
+    over a window of the value domain: `i16const` (hundreds of equal samples: the counters overflow and the position is
+    recounted with 16-bit ones), `i16span` (values over the whole int16 range: one pass per window), `i16heavy` (a
+    heavy value of 255 / 256 / 257 copies among spread ones: the edge of the overflow test)"""
     import nanomod_oracle as orc
     rng = np.random.default_rng(zlib.crc32(mode.encode()))
     sizes = [(50, 1000), (1000, 50), (3, 130), (64, 65), (65, 2048), (130, 700), (256, 2048), (256, 4096), (4096, 256),
@@ -400,7 +403,18 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
         x = rng.normal(0, 1, a); y = rng.normal(0.3 if i % 2 else 0.0, 1.2, b)
         if mode == 'grid1':
             x, y = np.round(x, 1), np.round(y, 1)
-        elif mode == 'const':
+        elif mode == 'i16span':
+            x = rng.integers(-32768, 32768, a) / 1000.0; y = rng.integers(-32768, 32768, b) / 1000.0
+            y[::5] = y[0]; x[::4] = y[1 % b]
+            if i % 4 == 0:
+                y[:] = np.where(rng.random(b) < 0.5, -32.768, 32.767)   # the two ends of the domain only
+        elif mode == 'i16heavy':
+            big, small = (x, y) if a > b else (y, x)
+            k = (255, 256, 257)[i % 3]
+            if len(big) > k:
+                big[rng.permutation(len(big))[:k]] = 0.123
+            small[: len(small) // 2] = 0.123
+        elif mode in ('const', 'i16const'):
             x[:] = 0.25; y[:] = 0.25
             if i % 3 == 0:
                 y[: b // 2] = -1.5                    # two runs in the larger group, one of them tied with all of the smaller
@@ -408,7 +422,7 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
     off0 = np.zeros(len(sizes) + 1, np.int64); off0[1:] = np.cumsum([len(c) for c in ca])
     off1 = np.zeros(len(sizes) + 1, np.int64); off1[1:] = np.cumsum([len(c) for c in cb])
     rid = np.zeros(len(sizes), np.int32)
-    if mode == 'i16':
+    if mode.startswith('i16'):
         sig0 = np.round(np.concatenate(ca) * 1000).astype(np.int16); sig1 = np.round(np.concatenate(cb) * 1000).astype(np.int16)
         r0, r1 = sig0.astype(np.float64) / 1000, sig1.astype(np.float64) / 1000
     elif mode.startswith('f64'):

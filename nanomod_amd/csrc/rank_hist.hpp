@@ -165,10 +165,6 @@ constexpr unsigned kWideEmpty = 0xffffffffu;
 #endif
 constexpr int kWideProbes = NMOD_WIDE_PROBES;      // steps of a walk before the sample is deferred
 constexpr int kWideList = 128;                     // words of the deferred list: < 64 waiting + <= 64 of one sample slot
-#ifndef NMOD_WIDE_I16_BITS
-#define NMOD_WIDE_I16_BITS 8
-#endif
-constexpr int kWideI16Bits = NMOD_WIDE_I16_BITS;   // int16 samples: bits per direct-address counter
 
 template <int R, int LG, int DTYPE, bool WIDE = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (WIDE ? 2 : (R <= 16 ? NMOD_HIST_WAVES : 2)))
@@ -304,9 +300,16 @@ void rank_hist_kernel(RankStatsArgs args) {
 
     // ---- S: moments, sort, keys to LDS, ties inside S
 #if !(NMOD_SKIP & 4)
+    // WIDE: fl(1/m) and fl(1/q) once per position, for both groups' moments and the float form of D (this form has the
+    // registers to keep them; the packed form re-derives them where needed)
+    double rm_w = 0.0, rq_w = 0.0;
+    if constexpr (WIDE) {
+      if (uniform) { rm_w = recip[0]; rq_w = recip[1]; }
+      else { rm_w = 1.0 / (double)m; rq_w = 1.0 / (double)q; }
+    }
     {
       double mean, m2;
-      const double rcp_m = uniform ? recip[0] : 0.0;               // fl(1/m) of a fixed-stride batch (parked in LDS)
+      const double rcp_m = WIDE ? rm_w : (uniform ? recip[0] : 0.0);   // fl(1/m) of a fixed-stride batch (parked in LDS)
       if constexpr (PACKED) seg_moments_packed16<LG>(pk, m, gl, mean, m2, rcp_m);
       else seg_moments<R, LG, DTYPE>(x, m, mean, m2, rcp_m);
       if (valid && gl == 0) {
@@ -367,7 +370,12 @@ void rank_hist_kernel(RankStatsArgs args) {
 #pragma unroll
       for (int e = 0; e < NV; ++e) {
         unsigned* bin = reinterpret_cast<unsigned*>(const_cast<float*>(lp[e])) + HIST_OFF;
+#if !(NMOD_SKIP & 1024)
         if (have) atomicAdd(bin, inc[e]);
+#else
+        asm volatile("" :: "v"(bin), "v"(inc[e]));
+        if (have) atomicAdd(hist + (threadIdx.x & 63), inc[e]);          // (timing experiment: a conflict-free address)
+#endif
         ad[e] = (unsigned)(uintptr_t)bin - (unsigned)(uintptr_t)keys;      // byte offset inside the position's LDS (< 64 KB)
       }
     };
@@ -375,134 +383,106 @@ void rank_hist_kernel(RankStatsArgs args) {
     unsigned ppq = 0;                              // WIDE: ties inside Q from the hash table
     double s1w = 0.0, s2w = 0.0;                   // WIDE: Q's shifted moment sums
     if constexpr (WIDE && DTYPE == 1) {
-      // int16 samples: the ties inside Q from direct-address counts.  The wave's table holds one counter per VALUE of a
-      // window of the milli-unit domain (kWideI16Bits bits each, packed into 32-bit words): one returning LDS add per
-      // sample gives the number of earlier copies of its value, p - 1 — no hashing, no walks, one round trip.  A pre-pass
-      // takes min and max of Q (packed min / max on the raw words); Q is streamed once per window of [min, max]: one
-      // pass when the position's range fits the table (real events: a few hundred milli-units), the first pass fused
-      // with the ranking.
+      // int16 samples: the ties inside Q from direct-address counts.  The wave's table holds one 8-bit counter per VALUE
+      // of a window of the milli-unit domain (four per 32-bit word: 8 192 values in 8 KB): one returning LDS add per
+      // sample gives the number of earlier copies of its value, p - 1 — no hashing, no walks, one round trip.  The
+      // window is centred on the median of S (the two groups are reads of one position: real events spread a few hundred
+      // milli-units around their level).  A position with a sample of Q outside the window, or with a value that occurs
+      // 256 times (the counter wraps into its neighbour), is counted again after the pass, see below.
       unsigned* ht = reinterpret_cast<unsigned*>(keys) + BIN_WORDS;
-      constexpr int CB = kWideI16Bits;                                      // bits per counter
-      constexpr int CPW_LOG = (CB == 16) ? 1 : 2;                           // log2 counters per word
-      const int wlog = wide_log + CPW_LOG;                                  // log2 values per window
-      int vmin = 0, vmax = 0;
-      if (q > 0) {
-        typedef short S2 __attribute__((ext_vector_type(2)));
-        S2 mn = {32767, 32767}, mx = {-32768, -32768};
-#pragma unroll 2
-        for (int c = 0; c < full; ++c) {
-          const Q4Raw r = load_q4(sig_q, off_q, c * (4 * LG) + 4 * gl, true);
-          const S2 a = {(short)r.x, (short)r.y}, b = {(short)r.z, (short)r.w};
-          mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(a, b));
-          mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(a, b));
-        }
-        int lo = min((int)mn.x, (int)mn.y), hi = max((int)mx.x, (int)mx.y);
-        for (int c = 0; c < tail; ++c) {
-          const int idx = min(full * (4 * LG) + c * LG + gl, q - 1);       // (a sample read twice changes neither)
-          const int v = (int)load_q1(sig_q, off_q, idx, true);
-          lo = min(lo, v); hi = max(hi, v);
-        }
-        vmax = (int)wave_max_u32((unsigned)(hi + 32768)) - 32768;
-        vmin = 32767 - (int)wave_max_u32((unsigned)(32767 - lo));
-      }
-      const int npass = ((vmax - vmin) >> wlog) + 1;
+      const int wlog = wide_log + 2;                                         // log2 values per window
+      const int wb = (int)keys[Lay::word(m > 0 ? (m >> 1) : 0)] - (1 << (wlog - 1));   // (m = 0: key 0 is the +inf pad -> any window)
       const int kq = (q > 0) ? (int)rk : 0;                                 // shift of Q's moment sums
       int s1i = 0; long long s2i = 0;                                        // sum (x - kq), sum (x - kq)^2: exact integers
-      unsigned long long ovf = 0ull;                                         // (8-bit counters) a counter reached 255
-      auto count_many = [&](auto cb_tag, auto nv_tag, const int* iv, const bool* have, int wb) {
+      unsigned long long redo = 0ull;                                        // lanes that saw a counter at 255 or a sample outside
+      auto count_many = [&](auto cb_tag, auto nv_tag, const int* iv, const bool* have, int base) {
         constexpr int BITS = decltype(cb_tag)::value, NV = decltype(nv_tag)::value;
         constexpr int PW_LOG = (BITS == 16) ? 1 : 2;
         unsigned old[NV], sh[NV];
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
-          const unsigned u = (unsigned)(iv[e] - wb);
-          const bool in = have[e] && u < ((unsigned)wslots << PW_LOG);
+          const unsigned u = (unsigned)(iv[e] - base);
+          const bool in = u < ((unsigned)wslots << PW_LOG);
           sh[e] = (u & ((1u << PW_LOG) - 1u)) * (unsigned)BITS;
           old[e] = 0u;
 #if !(NMOD_SKIP & 128)
-          if (in) old[e] = atomicAdd(&ht[u >> PW_LOG], 1u << sh[e]);
+          if (have[e] && in) old[e] = atomicAdd(&ht[u >> PW_LOG], 1u << sh[e]);
 #endif
+          if constexpr (BITS == 8) redo |= __ballot(have[e] && !in);
         }
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
           const unsigned c = (old[e] >> sh[e]) & ((1u << BITS) - 1u);      // earlier copies of the value: p - 1
           ppq += __umul24(c, c) + c;                                        // p (p - 1)
-          if constexpr (BITS == 8) ovf |= __ballot(c == 255u);              // the add wrapped the counter into its neighbour
+          if constexpr (BITS == 8) redo |= __ballot(c == 255u);             // the add wrapped the counter into its neighbour
         }
       };
       auto clear_table = [&]() {
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < wslots / 4; i += 64) reinterpret_cast<uint4*>(ht)[i] = make_uint4(0u, 0u, 0u, 0u);
-      };
-#pragma unroll 1
-      for (int pass = 0; pass < npass; ++pass) {
-        const bool first = pass == 0;                // the pass that also ranks the samples and sums their moments
-        const int wb = vmin + (pass << wlog);
-        clear_table();
-        if (!first) {
-          ra = load_q4(sig_q, off_q, 4 * gl, 0 < full);
-          rt = load_q1(sig_q, off_q, full * (4 * LG) + gl, full * (4 * LG) + gl < q);
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0x0F70);
+      };
+      clear_table();
+      __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll 1
-        for (int c = 0; c < full_w; ++c) {
-          const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
-          const int iv[4] = {(int)ra.x, (int)ra.y, (int)ra.z, (int)ra.w};
-          const bool hv[4] = {true, true, true, true};
-          if (first) {
-            float xa[4];
+      for (int c = 0; c < full_w; ++c) {
+        const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
+        const int iv[4] = {(int)ra.x, (int)ra.y, (int)ra.z, (int)ra.w};
+        const bool hv[4] = {true, true, true, true};
+        float xa[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xa[e] = (float)iv[e];
-            unsigned ad[4];
+        for (int e = 0; e < 4; ++e) xa[e] = (float)iv[e];
+        unsigned ad[4];
 #if !(NMOD_SKIP & 512)
-            rank_many(std::integral_constant<int, 4>{}, xa, true, ad);
+        rank_many(std::integral_constant<int, 4>{}, xa, true, ad);
 #endif
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const int d = iv[e] - kq; s1i += d; s2i += (long long)d * (long long)d; }
-          }
-          count_many(std::integral_constant<int, CB>{}, std::integral_constant<int, 4>{}, iv, hv, wb);
-          ra = rb;
-        }
-#pragma unroll 1
-        for (int c = 0; c < tail_w; ++c) {
-          const int idx_now = full * (4 * LG) + c * LG + gl;
-          const bool have = idx_now < q;
-          const int iv1[1] = {(int)rt};
-          const int idx = full * (4 * LG) + (c + 1) * LG + gl;
-          rt = load_q1(sig_q, off_q, idx, idx < q);
-          const bool hv[1] = {have};
-          if (first) {
-            const float xq1[1] = {have ? (float)iv1[0] : big};
-            unsigned a1[1];
-#if !(NMOD_SKIP & 512)
-            rank_many(std::integral_constant<int, 1>{}, xq1, have, a1);
-#endif
-            const int d = have ? iv1[0] - kq : 0;
-            s1i += d; s2i += (long long)d * (long long)d;
-          }
-          count_many(std::integral_constant<int, CB>{}, std::integral_constant<int, 1>{}, iv1, hv, wb);
-        }
+        for (int e = 0; e < 4; ++e) { const int d = iv[e] - kq; s1i += d; s2i += (long long)d * (long long)d; }
+        count_many(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{}, iv, hv, wb);
+        ra = rb;
       }
-      if constexpr (CB == 8) {
-        // 256 or more samples of Q with one value (a constant stretch of signal): the 8-bit counts are void — the ties
-        // of this position are counted again with 16-bit counters, half the window per pass, one sample per lane and trip
-        if (ovf != 0ull) {
-          ppq = 0u;
-          const int np16 = ((vmax - vmin) >> (wide_log + 1)) + 1;
 #pragma unroll 1
-          for (int pass = 0; pass < np16; ++pass) {
-            const int wb = vmin + (pass << (wide_log + 1));
-            clear_table();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+      for (int c = 0; c < tail_w; ++c) {
+        const int idx_now = full * (4 * LG) + c * LG + gl;
+        const bool have = idx_now < q;
+        const int iv1[1] = {(int)rt};
+        const int idx = full * (4 * LG) + (c + 1) * LG + gl;
+        rt = load_q1(sig_q, off_q, idx, idx < q);
+        const bool hv[1] = {have};
+        const float xq1[1] = {have ? (float)iv1[0] : big};
+        unsigned a1[1];
+#if !(NMOD_SKIP & 512)
+        rank_many(std::integral_constant<int, 1>{}, xq1, have, a1);
+#endif
+        const int d = have ? iv1[0] - kq : 0;
+        s1i += d; s2i += (long long)d * (long long)d;
+        count_many(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, iv1, hv, wb);
+      }
+      // The exceptions — a sample outside the window (a range beyond 8 units, or groups far apart), or 256 samples of
+      // one value (a constant stretch of signal): the counts are void.  The ties of the position are counted again the
+      // plain way: min and max of Q, then one pass per window of [min, max] with 16-bit counters, one sample per lane
+      // and trip.
+      if (redo != 0ull) {
+        ppq = 0u;
+        int lo = 32767, hi = -32768;
 #pragma unroll 1
-            for (int i0 = 0; i0 < q; i0 += 64) {
-              const bool hv[1] = {i0 + lane < q};
-              const int iv1[1] = {(int)load_q1(sig_q, off_q, i0 + lane, hv[0])};
-              count_many(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{}, iv1, hv, wb);
-            }
+        for (int i0 = 0; i0 < q; i0 += 64) {
+          const int v = (int)load_q1(sig_q, off_q, min(i0 + lane, q - 1), true);   // (a sample read twice changes neither)
+          lo = min(lo, v); hi = max(hi, v);
+        }
+        const int vmax = (int)wave_max_u32((unsigned)(hi + 32768)) - 32768;
+        const int vmin = 32767 - (int)wave_max_u32((unsigned)(32767 - lo));
+        const int np16 = ((vmax - vmin) >> (wide_log + 1)) + 1;
+#pragma unroll 1
+        for (int pass = 0; pass < np16; ++pass) {
+          const int base = vmin + (pass << (wide_log + 1));
+          clear_table();
+#pragma unroll 1
+          for (int i0 = 0; i0 < q; i0 += 64) {
+            const bool hv[1] = {i0 + lane < q};
+            const int iv1[1] = {(int)load_q1(sig_q, off_q, i0 + lane, hv[0])};
+            count_many(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{}, iv1, hv, base);
           }
         }
       }
@@ -803,8 +783,7 @@ void rank_hist_kernel(RankStatsArgs args) {
       const float kqf = (q > 0) ? (float)rk : 0.0f;
       const double KQ = (double)kqf;
       const double s1 = seg_allsum_f64<LG>(s1w), s2 = seg_allsum_f64<LG>(s2w);
-      const double dn = (double)q;
-      const double rn = uniform ? recip[1] : 1.0 / dn;             // one division for mean and M2, none for a fixed-stride batch
+      const double rn = rq_w;
       double mu = KQ + s1 * rn;
       double qq = s2 - s1 * s1 * rn;
       if constexpr (DTYPE != 0) { mu = mu * 1e-3; qq = qq * 1e-6; }
@@ -867,7 +846,8 @@ void rank_hist_kernel(RankStatsArgs args) {
       asm volatile("" : "+v"(mo), "+v"(qo));    // (not the (double)m of the moments, kept alive since then)
       const double dm = (double)mo, dq = (double)qo;
       double rm, rq;
-      if (uniform) { rm = recip[0]; rq = recip[1]; }
+      if constexpr (WIDE) { rm = rm_w; rq = rq_w; }
+      else if (uniform) { rm = recip[0]; rq = recip[1]; }
       else { rm = 1.0 / dm; rq = 1.0 / dq; }
       // hit lanes of this lane's position as a bit mask (bit j: lane j of the group reached the maximum)
       const unsigned long long hits = __ballot(lbest == best && best != 0u);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz of the HIP path against the C oracle (run on the GPU box: python tests/fuzz_gpu.py [rounds]).
 Random ragged batches: group sizes from 1 to ~9000 with random size ranges per batch, continuous / gridded /
-heavily tied values, optional int16 input, both test masks.  Test infrastructure, like everything under oracle/."""
+heavily tied values, optional int16 input (also heavily tied and spread over the whole domain), both test masks.  Test infrastructure, like everything under oracle/."""
 import os
 import sys
 
@@ -23,7 +23,7 @@ def run_round(rng):
     hi1 = int(rng.choice([3, 8, 40, 64, 65, 130, 260, 600, 1100, 2048, 2500, 9000]))
     lo0 = int(rng.integers(1, hi0 + 1)) if rng.random() < 0.5 else 1
     lo1 = int(rng.integers(1, hi1 + 1)) if rng.random() < 0.5 else 1
-    mode = rng.choice(['cont', 'grid2', 'grid0', 'i16', 'f64', 'f64near'])
+    mode = rng.choice(['cont', 'grid2', 'grid0', 'i16', 'i16t', 'i16w', 'f64', 'f64near'])
     npos = int(rng.integers(1, (400 if max(hi0, hi1) <= 600 else 40) // (4 if mode.startswith('f64') else 1) + 1))
     n0 = rng.integers(lo0, hi0 + 1, npos); n1 = rng.integers(lo1, hi1 + 1, npos)
     off0 = np.zeros(npos + 1, np.int64); off0[1:] = np.cumsum(n0)
@@ -33,7 +33,11 @@ def run_round(rng):
         a, b = np.round(a, 2), np.round(b, 2)
     elif mode == 'grid0':
         a, b = np.round(a, 0), np.round(b, 0)
-    if mode == 'i16':
+    if mode == 'i16t':                        # int16 with heavy ties: up to hundreds of copies of a value (8-bit counters wrap)
+        a, b = np.round(a, 1), np.round(b, int(rng.integers(0, 3)))
+    elif mode == 'i16w':                      # int16 over most of the domain: many count windows
+        a, b = np.clip(a * 8, -32.7, 32.7), np.clip(b * 8, -32.7, 32.7)
+    if mode.startswith('i16'):
         s0 = np.round(a * 1000).astype(np.int16); s1 = np.round(b * 1000).astype(np.int16)
         r0, r1 = s0.astype(np.float64) / 1000, s1.astype(np.float64) / 1000
     elif mode in ('f64', 'f64near'):

@@ -467,8 +467,31 @@ void ks_rank_kernel(RankStatsArgs args) {
     const Item nxt = describe(it + wave_stride);
     KsRows<R, LG, DTYPE> rows_next;
     rows_next.request(nxt.swap ? args.sig1 : args.sig0, nxt.off_s, nxt.m, gl);
-    Q4Raw ra = load_q4(sig_q, off_q, 4 * gl, !coop && 0 < full);              // the round being ranked next (raw)
-    Q1Raw rt = load_q1(sig_q, off_q, full * (4 * LG) + gl, !coop && full * (4 * LG) + gl < q);   // first one-per-lane round
+    // (PIPE_COOP: in the coop schedule these are the first rounds of the wave's FIRST position, 64 lanes wide)
+    constexpr bool PIPE_COOP = LG == 8;             // the forms ragged coverage lands in; the others keep the plain coop loop
+    auto row_of_slot = [&](int sl, const void*& sg, int64_t& of, int& qn) {
+      const int src = sl * LG;
+      // (readlane returns int: go through unsigned, or a low word >= 2^31 would sign-extend into the high word)
+      auto rl64 = [&](unsigned long long v) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+        return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+      };
+      sg = reinterpret_cast<const void*>((uintptr_t)rl64((unsigned long long)(uintptr_t)sig_q));
+      of = (int64_t)rl64((unsigned long long)off_q);
+      qn = __builtin_amdgcn_readlane(q, src);
+    };
+    const void* sig_c = sig_q; int64_t off_c = off_q; int q_c = q;          // coop: the position being ranked by the wave
+    int idx_a = 4 * gl, idx_t = full * (4 * LG) + gl;
+    bool have_a = !coop && 0 < full, have_t = !coop && idx_t < q;
+    if constexpr (PIPE_COOP) {
+      if (coop) {
+        row_of_slot(0, sig_c, off_c, q_c);
+        idx_a = 4 * lane; idx_t = (q_c / 256) * 256 + lane; have_a = q_c >= 256; have_t = idx_t < q_c;
+      }
+    }
+    Q4Raw ra = load_q4(sig_c, off_c, idx_a, have_a);                          // the round being ranked next (raw)
+    Q1Raw rt = load_q1(sig_c, off_c, idx_t, have_t);                          // first one-per-lane round
 
 #if !(defined(NMOD_EXP) && (NMOD_EXP & 1))
     if constexpr (PACKED) {
@@ -540,6 +563,39 @@ void ks_rank_kernel(RankStatsArgs args) {
     } else {
       const int cfull = q / 256;
       slots = (cfull * 4 + (q - cfull * 256 + 63) / 64) * 64;        // per position: what the 64 lanes will process
+      if constexpr (PIPE_COOP) {
+      // software pipeline over (position, round): the first rounds of the NEXT position are requested before this
+      // position's are ranked, and every round before the previous one is ranked (one exposed HBM round trip per
+      // round otherwise: 0.56 issue utilisation on configs[4])
+#pragma unroll 1
+      for (int sl = 0; sl < PW; ++sl) {
+        const void* sig_n = sig_c; int64_t off_n = off_c; int q_n = 0;
+        if (sl + 1 < PW) row_of_slot(sl + 1, sig_n, off_n, q_n);
+        const int nfs = q_n / 256;
+        const Q4Raw na = load_q4(sig_n, off_n, 4 * lane, nfs > 0);
+        const Q1Raw nt = load_q1(sig_n, off_n, nfs * 256 + lane, nfs * 256 + lane < q_n);
+        const float* kb = lds_all + (wave * PW + sl) * POS_WORDS;
+        const int fs = q_c / 256, ts = (q_c - fs * 256 + 63) / 64;
+#pragma unroll 2
+        for (int c = 0; c < fs; ++c) {
+          // (past the last round: the last round again — a load that is never used, from an address that exists)
+          const Q4Raw rb = load_q4(sig_c, off_c, min(c + 1, fs - 1) * 256 + 4 * lane, true);
+          float xq[4];
+          q4_values(xq, ra, true);
+          rank_and_count(std::integral_constant<int, 4>{}, std::true_type{}, kb, xq);
+          ra = rb;
+        }
+#pragma unroll 1
+        for (int c = 0; c < ts; ++c) {
+          const int idx_now = fs * 256 + c * 64 + lane;
+          const Q1Raw r1 = load_q1(sig_c, off_c, idx_now + 64, idx_now + 64 < q_c);
+          float xq[1] = {q1_value(rt, idx_now < q_c)};
+          rank_and_count(std::integral_constant<int, 1>{}, std::true_type{}, kb, xq);
+          rt = r1;
+        }
+        sig_c = sig_n; off_c = off_n; q_c = q_n; ra = na; rt = nt;
+      }
+      } else {
 #pragma unroll 1
       for (int sl = 0; sl < PW; ++sl) {
         const int src = sl * LG;
@@ -569,6 +625,7 @@ void ks_rank_kernel(RankStatsArgs args) {
           rank_and_count(std::integral_constant<int, 1>{}, std::true_type{}, kb, xq);
         }
       }
+      }   // !PIPE_COOP
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -178,14 +178,15 @@ void rank_hist_kernel(RankStatsArgs args) {
   using Lay = KsLayout<R, LG>;
   constexpr int ROW = Lay::ROW;
   constexpr int BIN_WORDS = WIDE ? ((ks_rank_pos_words(R, LG) + 3) & ~3) : ks_rank_pos_words(R, LG);   // keys + bins of a position
-  int wide_log = 0;                                                                // WIDE: log2 of the wave's hash slots
+  int wide_log = 0;                                                                // WIDE, int16: log2 of the words of the counter table
   int wide_passes = 1;                                                             // WIDE: hash passes over Q
   if constexpr (WIDE) {
-    wide_log = wide_table_log(args.class_id, DTYPE);
+    wide_log = NMOD_WIDE_I16_LOG;
     // (float32) Q of 2 049 .. 4 096 samples: two passes, half of the values each
     if (DTYPE == 0 && args.class_id >= kWideBigBase) wide_passes = 2;
   }
-  const int wslots = WIDE ? (1 << wide_log) : 0;
+  const int wslots = WIDE ? wide_table_words(args.class_id, DTYPE) : 0;           // words of the wave's tie table
+  const unsigned nslots = (unsigned)wide_table_slots(wslots);                      // float32: hash slots in use (a prime)
   const int POS_WORDS = BIN_WORDS + wslots + (WIDE ? kWideList : 0);               // WIDE: the table and the deferred list behind them (16-byte aligned)
   constexpr int HIST_OFF = Lay::REGION;        // words from key 0 to bin 0
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
@@ -500,17 +501,19 @@ void rank_hist_kernel(RankStatsArgs args) {
       // value still gets its own place p in 1..b whatever the order of arrival, so the sum of p (p - 1) is the same.)
       unsigned* lst = ht + wslots;                   // the deferred samples (kWideList words)
       int lcnt = 0;                                  // how many (the same in every lane)
-      const unsigned mask = (unsigned)(wslots - 1);
+      // (the table size is a prime, not a power of two — 1 597 slots for Q <= 1 024, 3 067 for Q <= 2 048: five and three
+      // blocks per CU instead of four and two; any step in 1 .. nslots - 1 visits every slot: here 1 .. 512)
       auto walk_to_end = [&](unsigned bits, bool act) {
         const unsigned hsh = bits * 2654435761u;
-        unsigned hh = hsh >> (32 - wide_log);
-        const unsigned st = (hsh >> 6) | 1u;
+        unsigned hh = ((hsh >> 12) * nslots) >> 20;         // 20 hash bits x a 13-bit prime: below 2^32
+        const unsigned st = 1u + (hsh & 511u);
         unsigned dup = 0u;
         while (__ballot(act) != 0ull) {
           const unsigned old = atomicCAS(&ht[hh], kWideEmpty, act ? bits : kWideEmpty);   // (idle lanes: empty -> empty)
           dup += (act && old == bits) ? 1u : 0u;
           act = act && old != kWideEmpty;
-          hh = (hh + st) & mask;
+          hh += st;
+          hh = min(hh, hh - nslots);                          // (below nslots the difference wraps to a huge value)
         }
         ppq += dup * (dup + 1u);                     // the p-th of its value, p = dup + 1: p (p - 1)
       };
@@ -529,10 +532,10 @@ void rank_hist_kernel(RankStatsArgs args) {
         for (int e = 0; e < NV; ++e) {
           bits[e] = __float_as_uint(xq[e] + 0.0f);                             // (-0.0 -> +0.0: one key per value)
           const unsigned hsh = bits[e] * 2654435761u;
-          hh[e] = hsh >> (32 - wide_log);
-          st[e] = (hsh >> 6) | 1u;
+          hh[e] = ((hsh >> 12) * nslots) >> 20;
+          st[e] = 1u + (hsh & 511u);
           // (two passes: the values are split by one more hash bit; each pass holds one half in the table)
-          const bool mine = wide_passes == 1 || ((hsh >> 5) & 1u) == (unsigned)pass;
+          const bool mine = wide_passes == 1 || ((hsh >> 9) & 1u) == (unsigned)pass;
           dup[e] = 0u; act[e] = have[e] && mine;
         }
 #if (NMOD_SKIP & (128 | 256))
@@ -549,7 +552,8 @@ void rank_hist_kernel(RankStatsArgs args) {
           for (int e = 0; e < NV; ++e) {
             dup[e] += (act[e] && old[e] == bits[e]) ? 1u : 0u;
             act[e] = act[e] && old[e] != kWideEmpty;
-            hh[e] = (hh[e] + st[e]) & mask;
+            hh[e] += st[e];
+            hh[e] = min(hh[e], hh[e] - nslots);
           }
         }
 #pragma unroll

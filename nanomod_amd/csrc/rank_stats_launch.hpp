@@ -45,18 +45,43 @@ inline bool wide_class(int cls) {
   if (cls >= kWideBigBase) return cls < kWideBigBase + kNumWideBig;
   return cls < kNumGeneralClasses && (cls / kNumSizeClasses <= 2 || cls % kNumSizeClasses <= 2);
 }
-// log2 of the 32-bit words of a wave's tie table in the WIDE form (rank_hist.hpp).  float32: the multiset hash table,
-// 128 << (class of the larger group) slots, at least twice the samples it can receive (4 096 for the two-pass classes).
-// int16: direct-address counters over a window of the value domain, the same size for every class.
+// 32-bit words of a wave's tie table in the WIDE form (rank_hist.hpp).  int16: direct-address counters over a window of the
+// value domain, 1 << NMOD_WIDE_I16_LOG words for every class.  float32: the multiset hash table; its slots in use are the
+// largest prime below the words (double hashing with any step then visits every slot), sized by the class of the larger
+// group so that the load stays below 0.67 AND one more block fits a CU than with the next power of two:
+//   Q <= 512: 1 024 words (1 021 slots)   Q <= 1 024: 1 600 (1 597; five blocks per CU)   Q <= 2 048: 3 068 (3 067; three
+//   blocks per CU)   the two-pass classes (Q <= 4 096, split by a hash bit): 4 100 (4 099: a pass may receive every sample)
 #ifndef NMOD_WIDE_I16_LOG
 #define NMOD_WIDE_I16_LOG 11
 #endif
-__host__ __device__ static inline int wide_table_log(int cls, int dtype) {
-  if (dtype == 1) return NMOD_WIDE_I16_LOG;
-  if (cls >= kWideBigBase) return 12;
+__host__ __device__ constexpr int wide_table_words(int cls, int dtype) {
+  if (dtype == 1) return 1 << NMOD_WIDE_I16_LOG;
+#if defined(NMOD_WIDE_POW2)
+  if (cls >= kWideBigBase) return 4096;
+  { const int a = cls / kNumSizeClasses, b = cls % kNumSizeClasses; return 128 << (a < b ? b : a); }
+#endif
+  if (cls >= kWideBigBase) return 4100;            // (one pass may receive all 4 096 samples: every sample one value)
   const int c0 = cls / kNumSizeClasses, c1 = cls % kNumSizeClasses;
-  return 7 + (c0 < c1 ? c1 : c0);
+  const int cq = c0 < c1 ? c1 : c0;
+  return cq <= 3 ? 1024 : (cq == 4 ? 1600 : 3068);
 }
+__host__ __device__ constexpr int wide_table_slots(int words) {
+  switch (words) {
+    case 1024: return 1021;
+    case 1600: return 1597;
+    case 3068: return 3067;
+    case 4100: return 4099;
+    case 2048: return 2039;
+    case 4096: return 4093;
+    case 512: return 509;
+    case 256: return 251;
+    case 128: return 127;
+    default: return words > 8 ? (words - 1) | 1 : 7;     // (not reached: every size above has its prime)
+  }
+}
+// (a table never fills: a class's slots hold every sample the larger group can have, even when all are one value)
+static_assert(wide_table_slots(wide_table_words(0 * kNumSizeClasses + 3, 0)) >= 512 && wide_table_slots(wide_table_words(0 * kNumSizeClasses + 4, 0)) >= 1024 &&
+              wide_table_slots(wide_table_words(0 * kNumSizeClasses + 5, 0)) >= 2048 && wide_table_slots(wide_table_words(kWideBigBase, 0)) >= kWideBigMaxQ, "tie table sizes");
 inline int wide_class_of_s(int cls) {              // capacity class of the smaller group of a WIDE class
   if (cls >= kWideBigBase) return cls - kWideBigBase;
   return cls / kNumSizeClasses < cls % kNumSizeClasses ? cls / kNumSizeClasses : cls % kNumSizeClasses;
@@ -71,7 +96,7 @@ static inline size_t rank_stats_lds_bytes(int cls, bool all, int dtype) {
   if (wide_class(cls)) {
     // rank_hist_kernel WIDE (rank_hist.hpp): keys + bins of S (rounded to 16 bytes) + the wave's tie table, + two doubles
     const size_t R = (size_t)1 << wide_class_of_s(cls);
-    const size_t w = ((2 * R * 65 + 3) & ~(size_t)3) + ((size_t)1 << wide_table_log(cls, dtype)) + 128;   // + kWideList (rank_hist.hpp)
+    const size_t w = ((2 * R * 65 + 3) & ~(size_t)3) + (size_t)wide_table_words(cls, dtype) + 128;   // + kWideList (rank_hist.hpp)
     return w * 4 * 4 + 16;
   } else if (cls >= kKsClassBase) {
     int cs = cls - kKsClassBase;

@@ -178,16 +178,14 @@ void rank_hist_kernel(RankStatsArgs args) {
   using Lay = KsLayout<R, LG>;
   constexpr int ROW = Lay::ROW;
   constexpr int BIN_WORDS = WIDE ? ((ks_rank_pos_words(R, LG) + 3) & ~3) : ks_rank_pos_words(R, LG);   // keys + bins of a position
-  int wide_log = 0;                                                                // WIDE, int16: log2 of the words of the counter table
   int wide_passes = 1;                                                             // WIDE: hash passes over Q
   if constexpr (WIDE) {
-    wide_log = NMOD_WIDE_I16_LOG;
     // (float32) Q of 2 049 .. 4 096 samples: two passes, half of the values each
     if (DTYPE == 0 && args.class_id >= kWideBigBase) wide_passes = 2;
   }
   const int wslots = WIDE ? wide_table_words(args.class_id, DTYPE) : 0;           // words of the wave's tie table
   const unsigned nslots = (unsigned)wide_table_slots(wslots);                      // float32: hash slots in use (a prime)
-  const int POS_WORDS = BIN_WORDS + wslots + (WIDE ? kWideList : 0);               // WIDE: the table and the deferred list behind them (16-byte aligned)
+  const int POS_WORDS = BIN_WORDS + wslots + ((WIDE && DTYPE == 0) ? kWideList : 0);   // WIDE: the table (float32: and the deferred list) behind them, 16-byte aligned
   constexpr int HIST_OFF = Lay::REGION;        // words from key 0 to bin 0
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
 
@@ -391,8 +389,7 @@ void rank_hist_kernel(RankStatsArgs args) {
       // milli-units around their level).  A position with a sample of Q outside the window, or with a value that occurs
       // 256 times (the counter wraps into its neighbour), is counted again after the pass, see below.
       unsigned* ht = reinterpret_cast<unsigned*>(keys) + BIN_WORDS;
-      const int wlog = wide_log + 2;                                         // log2 values per window
-      const int wb = (int)keys[Lay::word(m > 0 ? (m >> 1) : 0)] - (1 << (wlog - 1));   // (m = 0: key 0 is the +inf pad -> any window)
+      const int wb = (int)keys[Lay::word(m > 0 ? (m >> 1) : 0)] - 2 * wslots;   // four values per word (m = 0: key 0 is the +inf pad -> any window)
       const int kq = (q > 0) ? (int)rk : 0;                                 // shift of Q's moment sums
       int s1i = 0; long long s2i = 0;                                        // sum (x - kq), sum (x - kq)^2: exact integers
       unsigned long long redo = 0ull;                                        // lanes that saw a counter at 255 or a sample outside
@@ -474,10 +471,10 @@ void rank_hist_kernel(RankStatsArgs args) {
         }
         const int vmax = (int)wave_max_u32((unsigned)(hi + 32768)) - 32768;
         const int vmin = 32767 - (int)wave_max_u32((unsigned)(32767 - lo));
-        const int np16 = ((vmax - vmin) >> (wide_log + 1)) + 1;
+        const int np16 = (vmax - vmin) / (2 * wslots) + 1;                    // two 16-bit counters per word
 #pragma unroll 1
         for (int pass = 0; pass < np16; ++pass) {
-          const int base = vmin + (pass << (wide_log + 1));
+          const int base = vmin + pass * (2 * wslots);
           clear_table();
 #pragma unroll 1
           for (int i0 = 0; i0 < q; i0 += 64) {

@@ -46,16 +46,16 @@ inline bool wide_class(int cls) {
   return cls < kNumGeneralClasses && (cls / kNumSizeClasses <= 2 || cls % kNumSizeClasses <= 2);
 }
 // 32-bit words of a wave's tie table in the WIDE form (rank_hist.hpp).  int16: direct-address counters over a window of the
-// value domain, 1 << NMOD_WIDE_I16_LOG words for every class.  float32: the multiset hash table; its slots in use are the
+// value domain, NMOD_WIDE_I16_WORDS words for every class.  float32: the multiset hash table; its slots in use are the
 // largest prime below the words (double hashing with any step then visits every slot), sized by the class of the larger
-// group so that the load stays below 0.67 AND one more block fits a CU than with the next power of two:
-//   Q <= 512: 1 024 words (1 021 slots)   Q <= 1 024: 1 600 (1 597; five blocks per CU)   Q <= 2 048: 3 068 (3 067; three
-//   blocks per CU)   the two-pass classes (Q <= 4 096, split by a hash bit): 4 100 (4 099: a pass may receive every sample)
-#ifndef NMOD_WIDE_I16_LOG
-#define NMOD_WIDE_I16_LOG 11
+// group: Q <= 512: 1 024 words (1 021 slots); Q <= 1 024: 2 048 (2 039; four blocks per CU — 1 600 words = five blocks
+// measured no faster); Q <= 2 048: 3 068 (3 067, load <= 0.67: THREE blocks per CU instead of the two of 4 096 words,
+// +5 % on configs[4]); the two-pass classes (Q <= 4 096, split by a hash bit): 4 100 (4 099: a pass may receive every sample).
+#ifndef NMOD_WIDE_I16_WORDS
+#define NMOD_WIDE_I16_WORDS 2048                   // 8 192 values, four blocks per CU (1 912 words = five blocks: measured 10 % slower)
 #endif
 __host__ __device__ constexpr int wide_table_words(int cls, int dtype) {
-  if (dtype == 1) return 1 << NMOD_WIDE_I16_LOG;
+  if (dtype == 1) return NMOD_WIDE_I16_WORDS;
 #if defined(NMOD_WIDE_POW2)
   if (cls >= kWideBigBase) return 4096;
   { const int a = cls / kNumSizeClasses, b = cls % kNumSizeClasses; return 128 << (a < b ? b : a); }
@@ -63,7 +63,7 @@ __host__ __device__ constexpr int wide_table_words(int cls, int dtype) {
   if (cls >= kWideBigBase) return 4100;            // (one pass may receive all 4 096 samples: every sample one value)
   const int c0 = cls / kNumSizeClasses, c1 = cls % kNumSizeClasses;
   const int cq = c0 < c1 ? c1 : c0;
-  return cq <= 3 ? 1024 : (cq == 4 ? 1600 : 3068);
+  return cq <= 3 ? 1024 : (cq == 4 ? 2048 : 3068);
 }
 __host__ __device__ constexpr int wide_table_slots(int words) {
   switch (words) {
@@ -96,7 +96,7 @@ static inline size_t rank_stats_lds_bytes(int cls, bool all, int dtype) {
   if (wide_class(cls)) {
     // rank_hist_kernel WIDE (rank_hist.hpp): keys + bins of S (rounded to 16 bytes) + the wave's tie table, + two doubles
     const size_t R = (size_t)1 << wide_class_of_s(cls);
-    const size_t w = ((2 * R * 65 + 3) & ~(size_t)3) + (size_t)wide_table_words(cls, dtype) + 128;   // + kWideList (rank_hist.hpp)
+    const size_t w = ((2 * R * 65 + 3) & ~(size_t)3) + (size_t)wide_table_words(cls, dtype) + (dtype == 1 ? 0 : 128);   // float32: + kWideList (rank_hist.hpp)
     return w * 4 * 4 + 16;
   } else if (cls >= kKsClassBase) {
     int cs = cls - kKsClassBase;

@@ -153,12 +153,14 @@ __device__ __forceinline__ unsigned pos_allsum_u32(unsigned v) {     // sum over
 // WIDE (LG = 64, R = 1, 2 or 4; one position per wave): positions whose groups fall in DIFFERENT capacity classes, the
 // smaller one S of at most 256 samples, the other Q of up to 4 096 (config 5: ~1000 v ~50 reads).  S is sorted and
 // ranked into exactly as above; Q streams through the ranking rounds in a loop (nothing of it is kept), and the ties
-// inside Q — the scatter + clean-up needs Q to fit the words of S — are counted by a per-wave hash table in LDS:
-// open addressing that inserts EVERY sample (a multiset): an arrival passes all earlier copies of its key on the way
-// along the key's probe sequence to the first empty slot, so it knows its place p in its run and adds p (p - 1).
-// The table has 128 << cq slots, cq = capacity class of Q (the larger of the launch's two classes, args.class_id):
-// at least twice the samples it can receive.  A Q of 2 049 .. 4 096 samples (classes kWideBigBase + class of S) takes the
-// 4 096-slot table twice: the values are split by one more hash bit and Q is streamed once per half.
+// inside Q — the scatter + clean-up needs Q to fit the words of S — are counted in a per-wave table in LDS behind the
+// bins.  float32: a hash table, open addressing that inserts EVERY sample (a multiset): an arrival passes all earlier
+// copies of its key on the way along the key's probe sequence to the first empty slot, so it knows its place p in its
+// run and adds p (p - 1).  The table's size follows the capacity class of Q (the larger of the launch's two classes,
+// args.class_id; rank_stats_launch.hpp: wide_table_words / wide_table_slots — a prime number of slots, never fewer than
+// the samples a pass can receive).  A Q of 2 049 .. 4 096 samples (classes kWideBigBase + class of S) takes its table
+// twice: the values are split by one more hash bit and Q is streamed once per half.  int16: no hash — one 8-bit counter
+// per VALUE of a window of the milli-unit domain (see the streaming section below).
 constexpr unsigned kWideEmpty = 0xffffffffu;
 #ifndef NMOD_WIDE_PROBES
 #define NMOD_WIDE_PROBES 2

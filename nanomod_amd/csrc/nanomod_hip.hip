@@ -965,7 +965,7 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
   if (big) { snprintf(buf, buflen, "big_rank_kernel<%s>", dt); return NMOD_OK; }
   if (!all) {
     const int cs = std::min(c0, c1);
-    const int LG = ks_lanes_per_group(cs), R = (64 << cs) / LG;
+    const int LG = ksonly_lanes_per_group(cs), R = (64 << cs) / LG;
     snprintf(buf, buflen, "ks_rank_kernel<%d,%d,%s>", R, LG, dt);
     return NMOD_OK;
   }

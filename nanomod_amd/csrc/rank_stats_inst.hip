@@ -71,7 +71,7 @@ KernelFn pick_ks(int cs, bool flags) {
       case 0: return ks_rank_kernel<8, 8, DT, true>;
       case 1: return ks_rank_kernel<16, 8, DT, true>;
       case 2: return ks_rank_kernel<16, 16, DT, true>;
-      case 3: return ks_rank_kernel<32, 16, DT, true>;
+      case 3: return ks_rank_kernel<16, 32, DT, true>;
       case 4: return ks_rank_kernel<32, 32, DT, true>;
       default: return ks_rank_kernel<32, 64, DT, true>;
     }
@@ -82,7 +82,7 @@ KernelFn pick_ks(int cs, bool flags) {
     case 0: return ks_rank_kernel<8, 8, DT>;
     case 1: return ks_rank_kernel<16, 8, DT>;
     case 2: return ks_rank_kernel<16, 16, DT>;
-    case 3: return ks_rank_kernel<32, 16, DT>;
+    case 3: return ks_rank_kernel<16, 32, DT>;
     case 4: return ks_rank_kernel<32, 32, DT>;
     default: return ks_rank_kernel<32, 64, DT>;
   }
@@ -111,7 +111,7 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
 #endif
   const size_t lds = rank_stats_lds_bytes(cls, ALL, DT);
   if (ks || packed) {
-    const int pw = ks ? ks_positions_per_wave(cls - kKsClassBase) : packed_positions_per_wave(cls - kNumGeneralClasses);
+    const int pw = ks ? ksonly_positions_per_wave(cls - kKsClassBase) : packed_positions_per_wave(cls - kNumGeneralClasses);
     work_items = (work_items + pw - 1) / pw;
   }
   // the dynamic-LDS attribute and the occupancy of a kernel are looked up once per (device, class), not on every launch

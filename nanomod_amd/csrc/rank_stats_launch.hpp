@@ -86,9 +86,14 @@ inline int wide_class_of_s(int cls) {              // capacity class of the smal
   if (cls >= kWideBigBase) return cls - kWideBigBase;
   return cls / kNumSizeClasses < cls % kNumSizeClasses ? cls / kNumSizeClasses : cls % kNumSizeClasses;
 }
-// KS-only classes: capacity 64 << cs sorted in (R, LG) = (8,8) (16,8) (16,16) (32,16) (32,32) (32,64)
+// capacity 64 << cs sorted in (R, LG) = (8,8) (16,8) (16,16) (32,16) (32,32) (32,64): the packed all-tests classes 0..4;
+// the KS-only classes take (16,32) for cs = 3 (below)
 inline int ks_lanes_per_group(int cs) { return cs <= 1 ? 8 : (cs == 2 ? 16 : (8 << (cs - 2))); }
 inline int ks_positions_per_wave(int cs) { return 64 / ks_lanes_per_group(cs); }
+// KS-only form: capacity 512 (cs = 3) as 16 keys x 32 lanes — two positions per wave at four waves per SIMD (117 registers,
+// 8.4 KB of LDS per wave) instead of 32 x 16 with four positions at two waves per SIMD (176 registers, 17.4 KB)
+inline int ksonly_lanes_per_group(int cs) { return cs == 3 ? 32 : ks_lanes_per_group(cs); }
+inline int ksonly_positions_per_wave(int cs) { return 64 / ksonly_lanes_per_group(cs); }
 // packed all-tests classes (rank_hist.hpp): the same (R, LG) per capacity as the KS-only classes 0..4
 inline int packed_positions_per_wave(int cm) { return ks_positions_per_wave(cm); }
 static inline size_t rank_stats_lds_bytes(int cls, bool all, int dtype) {
@@ -100,10 +105,10 @@ static inline size_t rank_stats_lds_bytes(int cls, bool all, int dtype) {
     return w * 4 * 4 + 16;
   } else if (cls >= kKsClassBase) {
     int cs = cls - kKsClassBase;
-    size_t LG = (size_t)ks_lanes_per_group(cs), R = (64u << cs) / LG;
+    size_t LG = (size_t)ksonly_lanes_per_group(cs), R = (64u << cs) / LG;
     size_t w = 2 * R * (LG + 1);                                             // ks_rank_pos_words (ks_rank.hpp)
     if (LG <= 16) while ((w & 31) != LG) ++w;
-    return (size_t)ks_positions_per_wave(cs) * w * 4 * 4 + 16;              // bytes, 4 waves per block, + two doubles (ks_rank.hpp: recip)
+    return (size_t)ksonly_positions_per_wave(cs) * w * 4 * 4 + 16;              // bytes, 4 waves per block, + two doubles (ks_rank.hpp: recip)
   } else if (cls >= kNumGeneralClasses) {
     int cm = cls - kNumGeneralClasses;
     size_t LG = (size_t)ks_lanes_per_group(cm), R = (64u << cm) / LG;

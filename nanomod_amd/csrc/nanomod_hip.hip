@@ -972,7 +972,7 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
   const int cls = launch_class_of(c0, c1);
   if (cls >= kNumGeneralClasses) {
     const int cm = cls - kNumGeneralClasses;
-    const int LG = ks_lanes_per_group(cm), R = (64 << cm) / LG;
+    const int LG = packed_lanes_per_group(cm), R = (64 << cm) / LG;
     snprintf(buf, buflen, "rank_hist_kernel<%d,%d,%s>", R, LG, dt);
   } else if (wide_class(cls)) {
     snprintf(buf, buflen, "rank_hist_kernel<%d,64,%s,wide>", 1 << std::min(c0, c1), dt);

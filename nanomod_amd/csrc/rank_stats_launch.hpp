@@ -95,7 +95,8 @@ inline int ks_positions_per_wave(int cs) { return 64 / ks_lanes_per_group(cs); }
 inline int ksonly_lanes_per_group(int cs) { return cs == 3 ? 32 : ks_lanes_per_group(cs); }
 inline int ksonly_positions_per_wave(int cs) { return 64 / ksonly_lanes_per_group(cs); }
 // packed all-tests classes (rank_hist.hpp): the same (R, LG) per capacity as the KS-only classes 0..4
-inline int packed_positions_per_wave(int cm) { return ks_positions_per_wave(cm); }
+inline int packed_lanes_per_group(int cm) { return cm == 3 ? 32 : ks_lanes_per_group(cm); }   // (capacity 512 as 16 x 32, like the KS-only form)
+inline int packed_positions_per_wave(int cm) { return 64 / packed_lanes_per_group(cm); }
 static inline size_t rank_stats_lds_bytes(int cls, bool all, int dtype) {
   size_t words;
   if (wide_class(cls)) {
@@ -111,7 +112,7 @@ static inline size_t rank_stats_lds_bytes(int cls, bool all, int dtype) {
     return (size_t)ksonly_positions_per_wave(cs) * w * 4 * 4 + 16;              // bytes, 4 waves per block, + two doubles (ks_rank.hpp: recip)
   } else if (cls >= kNumGeneralClasses) {
     int cm = cls - kNumGeneralClasses;
-    size_t LG = (size_t)ks_lanes_per_group(cm), R = (64u << cm) / LG;
+    size_t LG = (size_t)packed_lanes_per_group(cm), R = (64u << cm) / LG;
     size_t w = 2 * R * (LG + 1);                                             // ks_rank_pos_words (ks_rank.hpp)
     if (LG <= 16) while ((w & 31) != LG) ++w;
     return (size_t)packed_positions_per_wave(cm) * w * 4 * 4 + 16;             // + two doubles (rank_hist.hpp: recip)

@@ -72,7 +72,7 @@ KernelFn pick_ks(int cs, bool flags) {
       case 1: return ks_rank_kernel<16, 8, DT, true>;
       case 2: return ks_rank_kernel<16, 16, DT, true>;
       case 3: return ks_rank_kernel<16, 32, DT, true>;
-      case 4: return ks_rank_kernel<32, 32, DT, true>;
+      case 4: return ks_rank_kernel<16, 64, DT, true>;
       default: return ks_rank_kernel<32, 64, DT, true>;
     }
   }
@@ -83,7 +83,7 @@ KernelFn pick_ks(int cs, bool flags) {
     case 1: return ks_rank_kernel<16, 8, DT>;
     case 2: return ks_rank_kernel<16, 16, DT>;
     case 3: return ks_rank_kernel<16, 32, DT>;
-    case 4: return ks_rank_kernel<32, 32, DT>;
+    case 4: return ks_rank_kernel<16, 64, DT>;
     default: return ks_rank_kernel<32, 64, DT>;
   }
 }

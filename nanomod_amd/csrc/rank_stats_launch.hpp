@@ -91,8 +91,9 @@ inline int wide_class_of_s(int cls) {              // capacity class of the smal
 inline int ks_lanes_per_group(int cs) { return cs <= 1 ? 8 : (cs == 2 ? 16 : (8 << (cs - 2))); }
 inline int ks_positions_per_wave(int cs) { return 64 / ks_lanes_per_group(cs); }
 // KS-only form: capacity 512 (cs = 3) as 16 keys x 32 lanes — two positions per wave at four waves per SIMD (117 registers,
-// 8.4 KB of LDS per wave) instead of 32 x 16 with four positions at two waves per SIMD (176 registers, 17.4 KB)
-inline int ksonly_lanes_per_group(int cs) { return cs == 3 ? 32 : ks_lanes_per_group(cs); }
+// 8.4 KB of LDS per wave) instead of 32 x 16 with four positions at two waves per SIMD (176 registers, 17.4 KB); capacity
+// 1 024 (cs = 4) as 16 x 64 for the same reason
+inline int ksonly_lanes_per_group(int cs) { return cs == 3 ? 32 : (cs == 4 ? 64 : ks_lanes_per_group(cs)); }
 inline int ksonly_positions_per_wave(int cs) { return 64 / ksonly_lanes_per_group(cs); }
 // packed all-tests classes (rank_hist.hpp): the same (R, LG) per capacity as the KS-only classes 0..4
 inline int packed_lanes_per_group(int cm) { return cm == 3 ? 32 : ks_lanes_per_group(cm); }   // (capacity 512 as 16 x 32, like the KS-only form)

@@ -171,7 +171,7 @@ constexpr int kWideList = 128;                     // words of the deferred list
 template <int R, int LG, int DTYPE, bool WIDE = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (WIDE ? 2 : (R <= 16 ? NMOD_HIST_WAVES : 2)))
 void rank_hist_kernel(RankStatsArgs args) {
-  static_assert(WIDE ? (LG == 64 && (R == 1 || R == 2 || R == 4)) : (LG == 8 || LG == 16 || LG == 32), "lanes per sorted group");
+  static_assert(WIDE ? (LG == 64 && (R == 1 || R == 2 || R == 4)) : (LG == 8 || LG == 16 || LG == 32 || LG == 64), "lanes per sorted group");
   static_assert(WIDE || (R >= 8 && R <= 32 && (R & (R - 1)) == 0), "registers per lane");
   static_assert(R * LG <= 1024, "32-bit tie sums and 15-bit counts need sorted groups of at most 1024 samples");   // (WIDE: Q <= 4096 < 2^15)
   constexpr int PW = 64 / LG;                  // positions per wave

@@ -59,7 +59,7 @@ KernelFn pick_packed(int cm) {
     case 1: return rank_hist_kernel<16, 8, DT>;
     case 2: return rank_hist_kernel<16, 16, DT>;
     case 3: return rank_hist_kernel<16, 32, DT>;
-    default: return rank_hist_kernel<32, 32, DT>;
+    default: return rank_hist_kernel<16, 64, DT>;
   }
 }
 #else

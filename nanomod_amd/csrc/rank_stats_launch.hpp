@@ -6,8 +6,8 @@
 //                  rank_pair_kernel<1<<c0, 1<<c1> (rank_all.hpp), both groups sorted, 64 lanes per group;
 //   packed class   36 + cm          (36..40): rank_hist_kernel (rank_hist.hpp), both groups in capacity 64 << cm,
 //                  used when max(c0,c1) = cm <= 4 and min(c0,c1) >= cm - 1:
-//                  cm 0..1 -> (R, LG) = (8,8) (16,8): eight positions per wave; cm 2..3 -> (16,16) (32,16): four;
-//                  cm 4 -> (32,32): two.
+//                  cm 0..1 -> (R, LG) = (8,8) (16,8): eight positions per wave; cm 2 -> (16,16): four; cm 3 -> (16,32): two;
+//                  cm 4 -> (16,64): one (16 keys per lane keep every form at four waves per SIMD).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -96,7 +96,7 @@ inline int ks_positions_per_wave(int cs) { return 64 / ks_lanes_per_group(cs); }
 inline int ksonly_lanes_per_group(int cs) { return cs == 3 ? 32 : (cs == 4 ? 64 : ks_lanes_per_group(cs)); }
 inline int ksonly_positions_per_wave(int cs) { return 64 / ksonly_lanes_per_group(cs); }
 // packed all-tests classes (rank_hist.hpp): the same (R, LG) per capacity as the KS-only classes 0..4
-inline int packed_lanes_per_group(int cm) { return cm == 3 ? 32 : ks_lanes_per_group(cm); }   // (capacity 512 as 16 x 32, like the KS-only form)
+inline int packed_lanes_per_group(int cm) { return cm == 3 ? 32 : (cm == 4 ? 64 : ks_lanes_per_group(cm)); }   // (capacities 512 / 1 024 as 16 x 32 / 16 x 64, like the KS-only forms)
 inline int packed_positions_per_wave(int cm) { return 64 / packed_lanes_per_group(cm); }
 static inline size_t rank_stats_lds_bytes(int cls, bool all, int dtype) {
   size_t words;

@@ -355,3 +355,23 @@ def test_hostwalk_flatten_equals_numpy():
         got.append((s0.copy(), o0.copy()))
         assert len(meta['pos']) == 300 and o0[-1] == 2700
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+
+
+def test_dispatch_forms_keep_16_keys_per_lane():
+    """what runs for the uniform sizes of BASELINE.json's configs: every wave-resident form up to 1 024 samples sorts
+    at most 16 keys per lane (four waves per SIMD) — the description is host code, no device needed"""
+    import ctypes as C
+    from nanomod_amd import _lib as L
+    lib = L.load()
+    want = {
+        (1, 100, 100): b'ks_rank_kernel<16,8,f32>', (1, 200, 200): b'ks_rank_kernel<16,16,f32>',
+        (1, 500, 500): b'ks_rank_kernel<16,32,f32>', (1, 1000, 1000): b'ks_rank_kernel<16,64,f32>',
+        (1, 2000, 2000): b'ks_rank_kernel<32,64,f32>', (1, 50, 1000): b'ks_rank_kernel<8,8,f32>',
+        (7, 200, 200): b'rank_hist_kernel<16,16,f32>', (7, 500, 500): b'rank_hist_kernel<16,32,f32>',
+        (7, 1000, 1000): b'rank_hist_kernel<16,64,f32>', (7, 50, 1000): b'rank_hist_kernel<1,64,f32,wide>',
+    }
+    buf = C.create_string_buffer(96)
+    for (tests, a, b), name in want.items():
+        prm = L.make_params(tests=tests)
+        assert lib.nmod_describe_dispatch(C.byref(prm), a, b, buf, 96) == 0
+        assert buf.value == name, (tests, a, b, buf.value)

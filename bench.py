@@ -44,6 +44,8 @@ PLANT_PERIOD = 10000
 PLANT_SHIFT = 0.8
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GUIDE_GBS = 6290.0    # same guide: measured float4 copy
+# instruction budget of the design per position (VALU wave-instructions), by (mode, n0, n1)
+FLOOR_INSTR = {('ks', 200, 200): 342 + 39, ('all', 200, 200): 640}
 KS_D_RATIONAL_ABS = 4.5e-16    # gate on D under NMOD_FLAG_KS_RATIONAL_D (2 ulp); without the flag D is bit for bit
 
 PRESETS = {
@@ -111,6 +113,93 @@ def ragged_sizes(seed, pos_begin, npos, group):
     return np.clip(np.rint(mu * np.exp(0.5 * z)), lo, hi).astype(np.int64)
 
 
+def synth_rows(seed, pos_begin, npos, group, n_per_pos, plant_period, plant_shift, i16):
+    """numpy restatement of the device generator (include/nanomod_hip.h: nmod_synth_fill / nmod_synth_fill_csr; bit-equal,
+    tests/test_gpu_parity.py) as an [npos, n_per_pos] array: the CPU legs make the workload's rows without a GPU."""
+    import numpy as np
+    with np.errstate(over='ignore'):
+        pos = (np.arange(npos, dtype=np.int64) + pos_begin)[:, None]
+        read = np.arange(n_per_pos, dtype=np.uint64)[None, :]
+        x = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (pos * 2 + group).astype(np.uint64)
+        x = x ^ (read * np.uint64(0xD1B54A32D192ED03))
+        x = x ^ (x >> np.uint64(30)); x = x * np.uint64(0xBF58476D1CE4E5B9)
+        x = x ^ (x >> np.uint64(27)); x = x * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    m = np.uint64(0xffff)
+    sm = ((x & m) + ((x >> np.uint64(16)) & m) + ((x >> np.uint64(32)) & m) + (x >> np.uint64(48))).astype(np.int64)
+    v = (sm - 131070).astype(np.float32) * np.float32(2.6428997e-05)
+    if group == 1 and plant_period > 0:
+        mm = pos % plant_period
+        v = np.where((mm == 0) | (mm == 1) | (mm == plant_period - 1), v + np.float32(plant_shift), v).astype(np.float32)
+    if i16:
+        return np.rint(v * np.float32(1000.0)).astype(np.int16)
+    return v
+
+
+def refpy_worker(idx, go, results, cfg):
+    """One process of the reference-shaped CPU leg: the reference's own shape of the computation — per position,
+    in Python, the three scipy-1.2.1-style tests of getKStest (myDetect.py:327-343) through oracle/nanomod_oracle.py, then
+    the window combine over the process's track (myDetect.py:373-414).  Started before the parent touches a GPU; never
+    touches one itself; idles on `go` until the parent's CPU-baseline leg."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import numpy as np
+    import nanomod_oracle as orc
+    orc.getKStest(np.arange(8.0), np.arange(8.0) + 0.5)                       # imports and first-call work done before the clock
+    go.wait()
+    t0 = time.time()
+    seed, n0, n1, csr, i16, method = cfg['seed'], cfg['n0'], cfg['n1'], cfg['csr'], cfg['i16'], cfg['method']
+    scale = 1e-3 if i16 else 1.0
+    block = 200 if csr else 1000
+    pos = cfg['pos_begin'] + idx * cfg['stride']
+    done, ksd, ksp = 0, [], []
+    while done < cfg['min_positions'] or time.time() - t0 < cfg['budget_s']:
+        if csr:
+            s0 = ragged_sizes(seed, pos, block, 0); s1 = ragged_sizes(seed, pos, block, 1)
+        else:
+            s0 = np.full(block, n0); s1 = np.full(block, n1)
+        a = synth_rows(seed, pos, block, 0, int(s0.max()), PLANT_PERIOD, PLANT_SHIFT, i16)
+        b = synth_rows(seed, pos, block, 1, int(s1.max()), PLANT_PERIOD, PLANT_SHIFT, i16)
+        for i in range(block):
+            r = orc.getKStest(a[i, :s0[i]].astype(np.float64) * scale, b[i, :s1[i]].astype(np.float64) * scale)
+            ksd.append(r[2][0]); ksp.append(r[2][1])
+        pos += block; done += block
+        if done >= cfg['max_positions']:
+            break
+    orc.combine_track(np.array(ksd), np.array(ksp), np.zeros(done, np.int32), NB, WDIF,
+                      orc.METHOD_STOUFFER if method == 'stouffer' else orc.METHOD_FISHER)
+    results.put((idx, done, t0, time.time()))
+
+
+def start_refpy_workers(cfg, procs):
+    """spawn (fresh interpreters, nothing inherited) the reference-shaped workers; they import, warm up and wait"""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    go, results = ctx.Event(), ctx.Queue()
+    ps = [ctx.Process(target=refpy_worker, args=(i, go, results, cfg), daemon=True) for i in range(procs)]
+    for p_ in ps:
+        p_.start()
+    return {'go': go, 'results': results, 'procs': ps, 'cfg': cfg}
+
+
+def collect_refpy(h):
+    import queue
+    h['go'].set()
+    got = []
+    deadline = time.time() + 900
+    while len(got) < len(h['procs']):
+        try:
+            got.append(h['results'].get(timeout=2))
+        except queue.Empty:
+            dead = [p_ for p_ in h['procs'] if not p_.is_alive() and p_.exitcode not in (0, None)]
+            if dead or time.time() > deadline:
+                raise RuntimeError('reference-shaped CPU leg: %d worker(s) failed' % max(len(dead), 1))
+    for p_ in h['procs']:
+        p_.join(timeout=30)
+    positions = sum(g[1] for g in got)
+    wall = max(g[3] for g in got) - min(g[2] for g in got)
+    return positions, wall, min(g[1] for g in got)
+
+
 def oracle_run(a, off0, b, off1, npos, method, tests, threads):
     """The checker: oracle/nanomod_oracle.c on the first `npos` rows (CSR views of a, b).  Returns (outputs, seconds)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -122,7 +211,7 @@ def oracle_run(a, off0, b, off1, npos, method, tests, threads):
     return out, time.perf_counter() - t0
 
 
-def cpu_baseline(rows, what, method, tests, threads, target_seconds=12.0):
+def cpu_baseline(rows, what, method, tests, threads, target_seconds=12.0, refpy=None):
     """The oracle timed on this box's host cores on a bounded sample of the same workload (the first rows of rank 0's
     device-resident input, copied back): all usable cores, and one core."""
     import numpy as np
@@ -136,25 +225,114 @@ def cpu_baseline(rows, what, method, tests, threads, target_seconds=12.0):
     dt = sum(oracle_run(a, off0, b, off1, sample, method, tests, threads)[1] for _ in range(reps))
     one = int(min(cap, max(2000, rate / max(threads, 1) * 4.0)))                      # ~4 s on one core
     dt1 = oracle_run(a, off0, b, off1, one, method, tests, 1)[1]
-    # the reference's own shape of the computation — one scipy-style call sequence per position in Python, one core,
-    # all three tests as getKStest always computes them — on a small sample, for scale
-    import nanomod_oracle as orc
-    npy = min(300, cap)
-    scale = 1e-3 if a.dtype == np.int16 else 1.0
-    t0 = time.perf_counter()
-    ksp = [orc.getKStest(a[off0[i]:off0[i + 1]].astype(np.float64) * scale, b[off1[i]:off1[i + 1]].astype(np.float64) * scale)[2][1]
-           for i in range(npy)]
-    orc.combine_track(np.zeros(npy), np.array(ksp), np.zeros(npy, np.int32), NB, WDIF,
-                      orc.METHOD_STOUFFER if method == 'stouffer' else orc.METHOD_FISHER)
-    dpy = time.perf_counter() - t0
+    # the reference's own shape of the computation — one scipy-style call sequence per position in Python, all three tests as
+    # getKStest always computes them — on every usable core: one process per core, >= 20 000 positions each
+    if refpy is not None:
+        positions, wall, least = collect_refpy(refpy)
+        procs = len(refpy['procs'])
+        ref_shaped = {'value': positions / wall, 'unit': 'positions/s', 'cores': procs, 'positions': positions, 'wall_seconds': wall,
+                      'sample': 'oracle/nanomod_oracle.py getKStest (MWU + Welch-t + KS, the scipy 1.2.1 formulas) per position + the window '
+                                'combine, %d processes (multiprocessing spawn, started before the first GPU call) x >= %d positions of the same '
+                                'generator (%s), %d positions in %.1f s wall; the whole workload at this rate: %.0f s'
+                                % (procs, least, what, positions, wall, refpy['cfg']['workload_positions'] / (positions / wall))}
+    else:
+        import nanomod_oracle as orc
+        npy = min(300, cap)
+        scale = 1e-3 if a.dtype == np.int16 else 1.0
+        t0 = time.perf_counter()
+        ksp = [orc.getKStest(a[off0[i]:off0[i + 1]].astype(np.float64) * scale, b[off1[i]:off1[i + 1]].astype(np.float64) * scale)[2][1]
+               for i in range(npy)]
+        orc.combine_track(np.zeros(npy), np.array(ksp), np.zeros(npy, np.int32), NB, WDIF,
+                          orc.METHOD_STOUFFER if method == 'stouffer' else orc.METHOD_FISHER)
+        dpy = time.perf_counter() - t0
+        ref_shaped = {'value': npy / dpy, 'unit': 'positions/s', 'cores': 1, 'positions': npy, 'wall_seconds': dpy,
+                      'sample': 'oracle/nanomod_oracle.py getKStest + combine per position on the first %d positions, one core' % npy}
     return {'value': sample * reps / dt, 'unit': 'positions/s', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model(),
             'sample': 'first %d positions of the same workload (%s) x %d passes, oracle/nanomod_oracle.c '
                       'with OpenMP on %d threads (cgroup CPU quota), %.1f s' % (sample, what, reps, threads, dt),
             'one_core': {'value': one / dt1, 'unit': 'positions/s', 'cores': 1,
                          'sample': 'first %d positions, same library, 1 thread, %.1f s' % (one, dt1)},
-            'reference_shaped_python': {'value': npy / dpy, 'unit': 'positions/s', 'cores': 1,
-                                        'sample': 'oracle/nanomod_oracle.py getKStest + combine per position on the first %d '
-                                                  'positions (the reference computes MWU, Welch and KS for every position)' % npy}}
+            'reference_shaped_python': ref_shaped}
+
+
+def host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out):
+    """The host-resident entry (NMOD_MEM_HOST; what a drop-in mtest2 hands over — everything on this path is host memory in
+    the reference, myDetect.py:416-445) on the SAME rows as the headline: pageable numpy arrays, the same arrays page-locked
+    in place, and int16 milli-unit arrays.  The path is PCIe-bound, so its roofline is the pinned hipMemcpy rate, measured
+    here in the same run.  Results are compared bit for bit with the device-resident pass."""
+    import ctypes
+    import numpy as np
+    L = nm._lib
+    lib = L.load()
+    dev = 'cuda:%d' % dev_index
+    b0 = blocks[0]
+    npos = b0['n']
+    # ---- the PCIe roofline: pinned host -> device copies of 1 GiB, HIP events on the copy stream
+    pin = torch.empty(1 << 28, dtype=torch.float32).pin_memory()
+    dst = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    dst.copy_(pin, non_blocking=True); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        dst.copy_(pin, non_blocking=True)
+    e1.record(); torch.cuda.synchronize()
+    h2d_gbs = 3 * pin.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    e0.record()
+    for _ in range(3):
+        pin.copy_(dst, non_blocking=True)
+    e1.record(); torch.cuda.synchronize()
+    d2h_gbs = 3 * pin.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del pin, dst
+    rid = np.zeros(npos, np.int32)
+
+    def run(a, b, reps):
+        best, st, res = None, None, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = nm.detect_host(a, None, b, None, rid, nb=nb, weights_dif=wdif, method=method, tests=tests, stride0=n0, stride1=n1, device=dev_index)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best = dt
+                st = L.NmodHostStats()
+                lib.nmod_last_host_stats(ctypes.byref(st))
+        return best, st, res
+
+    def record(label, a, b, reps, check):
+        dt, st, res = run(a, b, reps)
+        rec = {'input': label, 'positions_per_s': npos / dt, 'seconds': dt, 'h2d_GBps': st.h2d_bytes / dt / 1e9,
+               'frac_of_pinned_h2d': st.h2d_bytes / dt / 1e9 / h2d_gbs, 'chunks': st.chunks, 'slots': st.slots,
+               'copy_threads': st.copy_threads, 'pinned_input': bool(st.pinned_input), 'device_bytes': st.device_bytes,
+               'h2d_bytes': st.h2d_bytes, 'd2h_bytes': st.d2h_bytes}
+        if check is not None:
+            rec['equals_device_resident_pass'] = bool(all(np.array_equal(res[k], check[k].cpu().numpy(), equal_nan=True) for k in res if k in check))
+        return rec, res
+
+    out = {'pinned_h2d_GBps': h2d_gbs, 'pinned_d2h_GBps': d2h_gbs, 'positions': npos,
+           'note': 'nmod_detect_batch(NMOD_MEM_HOST) on the headline rows held in host memory: chunks of positions through pinned bounce '
+                   'slots, H2D of chunk k+1 / K1+K2 of chunk k / D2H of chunk k-1 on three streams, one K3 over the whole KS track; '
+                   'best of the runs listed; roofline = the pinned H2D rate measured above'}
+    a = b0['sig0'].cpu().numpy(); b = b0['sig1'].cpu().numpy()
+    nm.detect_host(a[:n0 * 4096], None, b[:n1 * 4096], None, rid[:4096], nb=nb, weights_dif=wdif, method=method, tests=tests, stride0=n0, stride1=n1, device=dev_index)
+    dtype_name = 'float32' if a.dtype == np.float32 else 'int16'
+    out['pageable_%s' % dtype_name], _ = record('pageable numpy %s' % dtype_name, a, b, 3, ref_out)
+    cudart = torch.cuda.cudart()
+    ok = all(int(cudart.cudaHostRegister(x.ctypes.data, x.nbytes, 0)) == 0 for x in (a, b))
+    if ok:
+        out['pinned_%s' % dtype_name], _ = record('the same arrays page-locked in place (hipHostRegister)', a, b, 3, ref_out)
+        for x in (a, b):
+            cudart.cudaHostUnregister(x.ctypes.data)
+    if want_i16 and a.dtype == np.float32:
+        # the same rows as int16 milli-units (the format of real events): device pass for the check, then the host entry
+        det16 = nm.DeviceDetector(dev_index, nb=nb, weights_dif=wdif, method=method, tests=tests)
+        q0 = torch.empty(npos * n0, dtype=torch.int16, device=dev); q1 = torch.empty(npos * n1, dtype=torch.int16, device=dev)
+        det16.synth_fill(q0, SEED, b0['lo_h'], npos, 0, n0, PLANT_PERIOD, PLANT_SHIFT)
+        det16.synth_fill(q1, SEED, b0['lo_h'], npos, 1, n1, PLANT_PERIOD, PLANT_SHIFT)
+        ref16 = det16.run(q0, q1, b0['rid'], stride0=n0, stride1=n1, npos=npos)
+        torch.cuda.synchronize()
+        a16 = q0.cpu().numpy(); b16 = q1.cpu().numpy()
+        del q0, q1
+        out['pageable_int16'], _ = record('pageable numpy int16 (milli-units)', a16, b16, 3, ref16)
+    return out
 
 
 def profile_record(lib_path, key):
@@ -216,9 +394,13 @@ def main():
     ap.add_argument('--force-collective', action='store_true', help='N=1: initialise RCCL with one rank and issue the all-gather anyway')
     ap.add_argument('--cpu-sample', type=int, default=0, help='cap on positions for the CPU baseline / verification (0 = 1 M)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline (the verification still runs)')
-    ap.add_argument('--no-real-ties', action='store_true', help='skip the second, tie-heavy measurement of the default run')
-    ap.add_argument('--exact-d', action='store_true', help='KS-only configurations: D as ks_2samp\'s float form bit for bit (the library default) '
-                    'instead of NMOD_FLAG_KS_RATIONAL_D; the default run reports this rate beside the headline')
+    ap.add_argument('--refpy-positions', type=int, default=20000, help='reference-shaped Python CPU leg: at least this many positions per process')
+    ap.add_argument('--refpy-seconds', type=float, default=6.0, help='reference-shaped Python CPU leg: at least this many seconds per process')
+    ap.add_argument('--no-side', '--no-real-ties', dest='no_side', action='store_true',
+                    help='skip the side measurements of the default run (all tests, int16, rational D, tie-heavy input)')
+    ap.add_argument('--no-host-path', action='store_true', help='skip the host-resident (NMOD_MEM_HOST, PCIe-bound) measurement')
+    ap.add_argument('--rational-d', action='store_true', help='KS-only configurations: time NMOD_FLAG_KS_RATIONAL_D (D as the exact rational, <= 2 ulp '
+                    'from ks_2samp\'s float form) instead of the library default (D bit for bit); the default run reports this rate as a side figure')
     ap.add_argument('--launch-only', action='store_true', help='ranks print RANK / WORLD_SIZE and exit before any GPU call (launcher test)')
     args = ap.parse_args()
 
@@ -234,6 +416,17 @@ def main():
         print(json.dumps({'launch_only': True, 'rank': rank, 'local_rank': local_rank, 'world_size': world,
                           'master': '%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'))}), flush=True)
         return
+
+    # the reference-shaped CPU leg: one fresh process per usable core, started BEFORE this process touches a GPU (they idle
+    # until the CPU-baseline leg and never load the HIP library)
+    refpy = None
+    if world == 1 and rank == 0 and not args.no_cpu:
+        pz = PRESETS[args.config]
+        at = bool(args.all_tests or pz['all_tests'])
+        refpy = start_refpy_workers({'seed': SEED, 'n0': args.n0 or pz['n0'], 'n1': args.n1 or pz['n1'], 'csr': pz['layout'] == 'csr',
+                                     'i16': args.dtype == 'i16', 'method': 'fisher' if at else 'stouffer', 'pos_begin': 0,
+                                     'stride': 1_000_000, 'min_positions': args.refpy_positions, 'max_positions': 50 * args.refpy_positions,
+                                     'budget_s': args.refpy_seconds, 'workload_positions': args.positions or pz['positions']}, usable_cpus())
 
     import numpy as np
     import torch
@@ -265,9 +458,9 @@ def main():
     total = B * world * chunks                     # the synthetic genome is padded to whole blocks
     method = 'fisher' if all_tests else 'stouffer'
     tests = L.TEST_ALL if all_tests else L.TEST_KS
-    # KS-only (a mode the reference never runs): the timed configuration reports D as the exact rational, <= 2 ulp from
-    # ks_2samp's float form (include/nanomod_hip.h: NMOD_FLAG_KS_RATIONAL_D); --exact-d times the library default
-    rational_d = (not all_tests) and not args.exact_d
+    # the timed configuration is the library default: D as ks_2samp's float form bit for bit.  --rational-d times the
+    # opt-out (include/nanomod_hip.h: NMOD_FLAG_KS_RATIONAL_D, KS-only mode), which the default run reports as a side figure
+    rational_d = (not all_tests) and args.rational_d
     det = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests,
                             flags=L.FLAG_KS_RATIONAL_D if rational_d else 0)
     d_gate = [KS_D_RATIONAL_ABS if rational_d else 0.0]
@@ -354,15 +547,19 @@ def main():
             o1 = np.arange(0, (cap + 1) * n1, n1, dtype=np.int64)
         return b0['sig0'][:int(o0[-1])].cpu().numpy(), o0, b0['sig1'][:int(o1[-1])].cpu().numpy(), o1
 
-    def verify_against_oracle(rows, vn):
+    def verify_against_oracle(rows, vn, outs=None, leg_all=None, leg_method=None, gate=None):
         """one finished pass of rank 0's first block against the oracle on its first vn positions (tests/helpers.py gates)"""
-        exp, _ = oracle_run(rows[0], rows[1], rows[2], rows[3], vn, method, 7 if all_tests else 1, usable_cpus())
+        outs = blocks[0]['out'] if outs is None else outs
+        leg_all = all_tests if leg_all is None else leg_all
+        leg_method = method if leg_method is None else leg_method
+        gate = d_gate[0] if gate is None else gate
+        exp, _ = oracle_run(rows[0], rows[1], rows[2], rows[3], vn, leg_method, 7 if leg_all else 1, usable_cpus())
         v = {'positions': vn, 'against': 'oracle/nanomod_oracle.c on the first positions of rank 0, same input'}
-        names = ['ks_d', 'ks_p', 'comb_st', 'comb_p'] + (['mwu_u', 'mwu_p', 't_t', 't_p'] if all_tests else [])
+        names = ['ks_d', 'ks_p', 'comb_st', 'comb_p'] + (['mwu_u', 'mwu_p', 't_t', 't_p'] if leg_all else [])
         inner = slice(0, vn - NB)                   # the sample's last nb positions see neighbours the oracle run did not
         ok = True
         for k in names:
-            g = blocks[0]['out'][k][:vn].cpu().numpy()[inner]
+            g = outs[k][:vn].cpu().numpy()[inner]
             e = exp[k][inner]
             fin = np.isfinite(e)
             same_special = bool(np.array_equal(g[~fin], e[~fin], equal_nan=True))
@@ -376,7 +573,7 @@ def main():
             if k.endswith('_p'):
                 good = bool(np.all(err <= 1e-9 * np.abs(e[fin]) + 1e-300)) and ab <= 1e-6
             elif k == 'ks_d':
-                good = ab <= d_gate[0]
+                good = ab <= gate
             elif k == 'mwu_u':
                 good = ab == 0.0
             elif k == 't_t':
@@ -438,57 +635,85 @@ def main():
         copy_gbs = 2 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
-    # ---- the same step on tie-heavy input (real NanoMod events are 3-decimal values): a second, shorter measurement
-    # beside the headline of the default run; the buffers are refilled in place
-    real_ties = None
-    if world == 1 and args.ties == 'few' and not args.no_real_ties and args.config in ('ecoli', 'alltests') and not args.force_collective:
+    # ---- side measurements of the default run (N = 1): the same step, 10 timed steps each, every one checked against the
+    # oracle on 20 000 positions before it is timed
+    def side_leg(det_x, sig_keys, outs, leg_all, leg_method, gate, note):
+        def run_once():
+            for b in blocks:
+                det_x.run(b[sig_keys[0]], b[sig_keys[1]], b['rid'], stride0=n0, stride1=n1, npos=b['n'], out=outs)
+        run_once(); torch.cuda.synchronize()
+        cap = min(20_000, blocks[0]['n'])
+        o0 = np.arange(0, (cap + 1) * n0, n0, dtype=np.int64); o1 = np.arange(0, (cap + 1) * n1, n1, dtype=np.int64)
+        rows = (blocks[0][sig_keys[0]][:cap * n0].cpu().numpy(), o0, blocks[0][sig_keys[1]][:cap * n1].cpu().numpy(), o1)
+        v = verify_against_oracle(rows, cap, outs, leg_all, leg_method, gate)
+        for _ in range(3):
+            run_once()
+        tm = nm.EventTimer(64)
+        det_x.timer = tm
+        ks = max(1, min(args.steps, 10))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(ks):
+            run_once()
+        barrier()
+        el = time.perf_counter() - t0
+        det_x.timer = None
+        k1, kn = tm.read(L.KERNEL_RANK_STATS); k2, _ = tm.read(L.KERNEL_FINALIZE); k3, _ = tm.read(L.KERNEL_COMBINE)
+        sb = 2 if blocks[0][sig_keys[0]].dtype == torch.int16 else 4
+        algo_leg = algorithmic_bytes(n0, n1, sb, 4 if leg_all else 2, False)
+        gbs = algo_leg * n_local / ((k1 + k2 + k3) / max(kn, 1) * 1e-3) / 1e9
+        if not v['ok']:
+            verify['ok'] = False
+            print('bench.py: verification of a side measurement FAILED (%s): %r' % (note, v), file=sys.stderr)
+        return {'value': total * ks / el, 'unit': 'positions/s', 'steps': ks, 'ms_per_step': el / ks * 1e3,
+                'kernel_avg_ms': k1 / max(kn, 1), 'algorithmic_bytes_per_position': algo_leg,
+                'roofline_frac': gbs / HBM_PEAK_GBS, 'achieved_GBps': gbs, 'note': note, 'verify': v}
+
+    side = {}
+    simple = world == 1 and not csr and not args.force_collective and not args.no_side and chunks == 1
+    if simple and args.config == 'ecoli' and args.dtype == 'f32' and args.ties == 'few' and not all_tests:
+        # (a) all three tests + Fisher on the same buffers: what every real getKStest call computes (myDetect.py:331-343), BASELINE configs[2]
+        det_all = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method='fisher', tests=L.TEST_ALL)
+        outs_all = det_all.alloc_outputs(blocks[0]['n'])
+        side['all_tests'] = side_leg(det_all, ('sig0', 'sig1'), outs_all, True, 'fisher', 0.0,
+                                     'BASELINE configs[2] on the same buffers: KS + MWU + Welch-t per position + Fisher window=5 (rank_hist_kernel)')
+        del outs_all
+        # (b) the same rows as int16 milli-units, the format of real events (myRefBaseSignalAnnotation.py:1108): 844 B / position
+        for b in blocks:
+            b['q0'] = torch.empty(b['n'] * n0, dtype=torch.int16, device=dev); b['q1'] = torch.empty(b['n'] * n1, dtype=torch.int16, device=dev)
+            det.synth_fill(b['q0'], SEED, b['lo_h'], b['n'], 0, n0, PLANT_PERIOD, PLANT_SHIFT)
+            det.synth_fill(b['q1'], SEED, b['lo_h'], b['n'], 1, n1, PLANT_PERIOD, PLANT_SHIFT)
+        det_q = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests, flags=det.flags)
+        side['int16'] = side_leg(det_q, ('q0', 'q1'), blocks[0]['out'], False, method, d_gate[0],
+                                 'the same generator as int16 milli-units (844 algorithmic bytes per position): ks_rank_kernel<16,16,i16>, packed v_pk_min/max_i16 sort')
+        for b in blocks:
+            del b['q0'], b['q1']
+        # (c) NMOD_FLAG_KS_RATIONAL_D: D as the correctly rounded rational (<= 2 ulp from ks_2samp's float form) — an opt-out no
+        # reference-shaped entry point uses; rounds 1-3 quoted this rate as the headline
+        if not rational_d:
+            det_r = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests, flags=L.FLAG_KS_RATIONAL_D)
+            side['rational_d'] = side_leg(det_r, ('sig0', 'sig1'), blocks[0]['out'], False, method, KS_D_RATIONAL_ABS,
+                                          'flags = NMOD_FLAG_KS_RATIONAL_D (skips the float-form pass of D; gate 4.5e-16); the headline of BENCH_r01..r03')
+    if simple and args.ties == 'few' and args.dtype == 'f32' and args.config in ('ecoli', 'alltests'):
+        # (d) tie-heavy input (real NanoMod events are 3-decimal values): the buffers are refilled in place — last, nothing
+        # after this leg sees the headline's rows
         for b in blocks:
             fill(b, 'real')
-        step(False); state.wait(); torch.cuda.synchronize()
-        rows_t = host_rows(min(20_000, blocks[0]['n']))
-        vt = verify_against_oracle(rows_t, len(rows_t[1]) - 1)
-        for _ in range(3):
-            step(False)
-        t2 = nm.EventTimer(64)
-        det.timer = t2
-        ks = max(1, min(args.steps, 10))
-        el2 = timed(False, ks)
-        det.timer = None
-        r1, rn = t2.read(L.KERNEL_RANK_STATS)
-        real_ties = {'value': total * ks / el2, 'unit': 'positions/s', 'steps': ks, 'ms_per_step': el2 / ks * 1e3,
-                     'kernel_avg_ms': r1 / max(rn, 1),
-                     'data': 'the same generator on the 3-decimal grid (round(1000 x) / 1000 as float32): ties between and '
-                             'inside the groups as in real events' if args.dtype == 'f32' else 'int16 milli-units: identical to the headline input',
-                     'verify': vt}
-        if not vt['ok']:
-            verify['ok'] = False
-            print('bench.py: verification of the tie-heavy pass FAILED: %r' % vt, file=sys.stderr)
-
-    # ---- the library default in KS-only mode (D bit for bit): a second, shorter measurement beside the headline
-    exact_d = None
-    if world == 1 and rational_d and real_ties is not None:
+        side['real_ties'] = side_leg(det, ('sig0', 'sig1'), blocks[0]['out'], all_tests, method, d_gate[0],
+                                     'the same generator on the 3-decimal grid (round(1000 x) / 1000 as float32): ties between and inside the groups as in real events')
         for b in blocks:
             fill(b, args.ties)
-        det.flags = 0
-        d_gate[0] = 0.0
-        step(False); state.wait(); torch.cuda.synchronize()
-        rows_e = host_rows(min(20_000, blocks[0]['n']))
-        ve = verify_against_oracle(rows_e, len(rows_e[1]) - 1)
-        for _ in range(3):
-            step(False)
-        t3 = nm.EventTimer(64)
-        det.timer = t3
-        ks = max(1, min(args.steps, 10))
-        el3 = timed(False, ks)
-        det.timer = None
-        e1, en = t3.read(L.KERNEL_RANK_STATS)
-        exact_d = {'value': total * ks / el3, 'unit': 'positions/s', 'steps': ks, 'ms_per_step': el3 / ks * 1e3,
-                   'kernel_avg_ms': e1 / max(en, 1), 'verify': ve,
-                   'note': 'flags = 0: ks_d is max|fl(c0/n0) - fl(c1/n1)| exactly as ks_2samp forms it (what mtest2 / the CLI always get: '
-                           'they run all three tests, whose kernels are bit-exact in D without a flag)'}
-        if not ve['ok']:
+        step(False); state.wait(); torch.cuda.synchronize()     # the headline rows and outputs are back for what follows
+
+    # ---- the host-resident entry on the same rows (NMOD_MEM_HOST): PCIe-bound, its own roofline
+    host_path = None
+    if world == 1 and not csr and not args.no_host_path and chunks == 1 and not args.force_collective:
+        host_path = host_path_leg(nm, torch, local_rank, blocks, n0, n1, NB, WDIF, method, tests,
+                                  want_i16=(args.dtype == 'f32'), ref_out=blocks[0]['out'])
+        bad = [k for k, v in host_path.items() if isinstance(v, dict) and v.get('equals_device_resident_pass') is False]
+        if bad:
             verify['ok'] = False
-            print('bench.py: verification of the exact-D pass FAILED: %r' % ve, file=sys.stderr)
+            print('bench.py: the host-resident entry differs from the device-resident pass: %r' % bad, file=sys.stderr)
 
     line = None
     if rank == 0:
@@ -511,7 +736,7 @@ def main():
         kbuf = ctypes.create_string_buffer(96)
         L.check(L.load().nmod_describe_dispatch(ctypes.byref(prm), n0, n1, kbuf, 96), 'nmod_describe_dispatch')
         shape = 'ragged' if csr else '%dv%d' % (n0, n1)
-        key = '%s_%s_%s_%d%s' % ('all' if all_tests else 'ks', args.dtype, shape, int(pos_per_launch), ('_realties' if args.ties == 'real' else '') + ('_exactd' if (args.exact_d and not all_tests) else ''))
+        key = '%s_%s_%s_%d%s' % ('all' if all_tests else 'ks', args.dtype, shape, int(pos_per_launch), ('_realties' if args.ties == 'real' else '') + ('_rationald' if rational_d else ''))
         rec = profile_record(L.LIB_PATH, key) or {}
         tests_txt = 'KS + MWU + Welch-t + Fisher window=%d' % (2 * NB + 1) if all_tests else 'KS + weighted Stouffer window=%d' % (2 * NB + 1)
         reads_txt = ('n0 ~ LogNormal(ln 1000, 0.5) in [5, 4000], n1 ~ LogNormal(ln 50, 0.5) in [5, 400] (means %.0f v %.0f), CSR'
@@ -530,8 +755,8 @@ def main():
                        'preset': args.config, 'positions_total': total, 'positions_per_gpu': total // world, 'n0': n0, 'n1': n1,
                        'layout': 'csr' if csr else 'fixed stride', 'neighborPvalues': NB, 'WeightsDif': WDIF, 'ties': args.ties,
                        'ks_d': ('exact rational max|c0 n1 - c1 n0| / (n0 n1), correctly rounded (NMOD_FLAG_KS_RATIONAL_D; <= 2 ulp from '
-                                'ks_2samp\'s float form, gate 4.5e-16; the bit-exact default is timed in `exact_d`)') if rational_d else
-                               'ks_2samp\'s float form bit for bit (library default)',
+                                'ks_2samp\'s float form, gate 4.5e-16)') if rational_d else
+                               'ks_2samp\'s float form bit for bit (library default, flags = 0)',
                        'rccl_ranks': dist.get_world_size() if dist is not None else 0,
                        'backend': dist.get_backend() if dist is not None else None,
                        'parallelism': ('block-cyclic position sharding x%d, %d rounds of %d-position blocks, +-%d halo recomputed; '
@@ -542,10 +767,13 @@ def main():
                              'ms_per_step': compute_elapsed / args.steps * 1e3,
                              'note': 'the same K steps without the all-gather (tracks stay sharded)' if gather else
                                      'identical to value: one rank has nothing to gather'},
-            'roofline': {'bound': 'hbm', 'limiter': 'valu-issue', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': {'bound': 'valu-issue', 'yardstick': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': rec.get('hbm_bytes_per_launch'), 'traffic_source': rec.get('source'),
-                         'note': 'HBM is the mandated yard-stick (sort / search / scan, no MFMA); the kernel is bound by VALU '
-                                 'instruction issue (see `valu`), not by bytes: traffic ~ 1.0 x algorithmic',
+                         'note': 'achieved / peak / frac are against HBM, the mandated yard-stick (sort / search / scan, no MFMA); what '
+                                 'bounds the kernel is VALU instruction issue (see `valu`): traffic ~ 1.0 x algorithmic, ~0.9 of the issue '
+                                 'slots taken, clock held near 2.2 GHz by the power limit.  `floor_instr_per_position` is the budget of this '
+                                 'design (DESIGN.md 5c: sort of the smaller group + one binary search per sample + prefix-sum evaluation)',
+                         'floor_instr_per_position': FLOOR_INSTR.get(('all' if all_tests else 'ks', n0, n1)),
                          'definition': 'SURVEY.md 8(d) bytes/position x positions per launch / HIP-event time of K1 + K2 + K3 of that launch',
                          'algorithmic_bytes_per_position': algo, 'positions_per_launch': pos_per_launch, 'profile_key': key,
                          'path_avg_ms': path_per_block_s * 1e3,
@@ -563,12 +791,11 @@ def main():
                              'with this library binary (null: this binary has not been profiled)'},
             'verify': verify,
         }
-        if real_ties is not None:
-            line['real_ties'] = real_ties
-        if exact_d is not None:
-            line['exact_d'] = exact_d
+        line.update(side)
+        if host_path is not None:
+            line['host_path'] = host_path
         if not args.no_cpu and world == 1:           # the CPU baseline is an N=1 figure
-            line['cpu_baseline'] = cpu_baseline(cpu_rows, '%s, %s' % (reads_txt, tests_txt), method, 7 if all_tests else 1, usable_cpus())
+            line['cpu_baseline'] = cpu_baseline(cpu_rows, '%s, %s' % (reads_txt, tests_txt), method, 7 if all_tests else 1, usable_cpus(), refpy=refpy)
     ok = torch.tensor([1 if (rank != 0 or verify['ok']) else 0], device=dev)
     if dist is not None:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)

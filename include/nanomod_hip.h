@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NMOD_ABI_VERSION 2
+#define NMOD_ABI_VERSION 3
 
 /* sample dtype of sig0 / sig1 */
 enum {
@@ -141,15 +141,48 @@ int64_t nmod_workspace_bytes(const nmod_params* prm, int64_t npos);
  * inputs, (ii) the maxima allow groups beyond NMOD_MAX_GROUP (the scratch of the
  * large-position pass is sized from the classifier's totals and allocated
  * stream-ordered), (iii) dtype is NMOD_DTYPE_F64 (the probe's verdict).
- * NMOD_MEM_HOST: pointers are host memory; the library stages through device
- * memory it allocates and frees inside the call (workspace may be NULL) and
- * returns after the results are back. */
+ * NMOD_MEM_HOST (what a drop-in mtest2 hands over: everything on this path is host
+ * memory in the reference, myDetect.py:416-445): pointers are host memory, workspace
+ * may be NULL, prm->stream is not used and the call returns after the results are
+ * back.  The batch is cut into chunks of positions that go through pinned bounce
+ * slots (skipped for arrays that are already page-locked) and three library-owned
+ * streams: the H2D copy of chunk k+1, K1 + K2 of chunk k and the D2H copy of chunk
+ * k-1 overlap; the KS track stays on the device and ONE K3 runs over the whole
+ * batch at the end, so chunk cuts never change a window.  Device footprint:
+ * slots x (chunk + workspace + results) + 36 B per position, from the library's
+ * pool; the pinned ring and the streams are cached per device until
+ * nmod_trim_scratch().  See nmod_host_pipeline_config / nmod_last_host_stats. */
 int nmod_detect_batch(const nmod_params* prm, int64_t npos,
                       const void* sig0, const int64_t* off0,
                       const void* sig1, const int64_t* off1,
                       const int32_t* run_id,
                       void* workspace, int64_t workspace_bytes,
                       nmod_out* out);
+
+/* Tunables of the NMOD_MEM_HOST pipeline, process-wide; 0 keeps / restores the default.  chunk_bytes: sample bytes per
+ * chunk (default min(32 MiB, batch / 8), at least 1 MiB; env NMOD_HOST_CHUNK_BYTES); slots: ring depth 2..8 (default 3; env
+ * NMOD_HOST_SLOTS); threads: host threads filling a bounce slot (default 4, capped by the cgroup CPU quota; env
+ * NMOD_HOST_THREADS); mode: 0 = copy straight from arrays that are page-locked, bounce the rest; 2 = always bounce. */
+int nmod_host_pipeline_config(int64_t chunk_bytes, int32_t slots, int32_t threads, int32_t mode);
+
+/* What the calling thread's last NMOD_MEM_HOST nmod_detect_batch did. */
+typedef struct nmod_host_stats {
+  int64_t chunks;            /* chunks the batch was cut into */
+  int64_t slots;             /* ring depth used */
+  int64_t copy_threads;      /* host threads that filled the bounce slots (1 when the input was page-locked) */
+  int64_t pinned_input;      /* 1: sig0 / sig1 were page-locked and copied from where they are */
+  int64_t chunk_positions;   /* positions of the largest chunk */
+  int64_t device_bytes;      /* device memory held during the call (ring + per-batch tracks) */
+  int64_t pinned_bytes;      /* pinned host ring */
+  int64_t h2d_bytes;         /* bytes copied host -> device */
+  int64_t d2h_bytes;         /* bytes copied device -> host */
+} nmod_host_stats;
+int nmod_last_host_stats(nmod_host_stats* st);
+
+/* "arch=gfx950 abi=3 ... | <translation unit>: NMOD_SKIP=0 NMOD_EXP=0 ..." — the value of every experiment macro
+ * (phase-skip and variant switches of the kernel headers) in each translation unit of THIS binary.  A product build
+ * reports NMOD_SKIP=0 NMOD_EXP=0 everywhere (tests/test_abi_and_host.py). */
+const char* nmod_build_info(void);
 
 /* KS statistic: ks_d is ks_2samp's own float form max|fl(c0/n0) - fl(c1/n1)| bit for bit in every mode (myDetect.py:341 ->
  * scipy 1.2.1), tests == NMOD_TEST_KS included: the kernels find the exact integer maximum of |c0*n1 - c1*n0| and evaluate the
@@ -160,7 +193,8 @@ int nmod_detect_batch(const nmod_params* prm, int64_t npos,
  * roofline.kernel and what the rocprofv3 kernel trace shows.  No device work. */
 int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char* buf, int32_t buflen);
 
-/* Returns the slabs cached in the library's scratch pool of `device` to the driver (see the header comment). */
+/* Returns the slabs cached in the library's scratch pool of `device` to the driver (see the header comment), and frees the
+ * pinned ring + streams the NMOD_MEM_HOST pipeline caches for it. */
 int nmod_trim_scratch(int32_t device);
 
 /* Replaces combin_pvalues / get_combin_pvalue on a whole KS track

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (NMOD_HIP_LIB: another build of the same library, for A/B measurements of kernel variants on one box)
 LIB_PATH = os.environ.get('NMOD_HIP_LIB') or os.path.join(_HERE, 'libnanomod_hip.so')
 
-NMOD_ABI_VERSION = 2
+NMOD_ABI_VERSION = 3
 DTYPE_F32, DTYPE_I16_MILLI, DTYPE_F64 = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 METHOD_KS, METHOD_STOUFFER, METHOD_FISHER = 0, 1, 2
@@ -42,6 +42,11 @@ class NmodOut(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in OUT_FIELDS] + [('status', C.c_void_p)]
 
 
+class NmodHostStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ('chunks', 'slots', 'copy_threads', 'pinned_input', 'chunk_positions',
+                                         'device_bytes', 'pinned_bytes', 'h2d_bytes', 'd2h_bytes')]
+
+
 class NanomodLibraryError(RuntimeError):
     pass
 
@@ -69,6 +74,9 @@ _SIGNATURES = {
     'nmod_selftest': (C.c_int, [C.c_int32]),
     'nmod_format_probe': (C.c_int, [C.POINTER(C.c_double), C.c_int64, C.c_int32, C.c_char_p, C.c_int64]),
     'nmod_trim_scratch': (C.c_int, [C.c_int32]),
+    'nmod_host_pipeline_config': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    'nmod_last_host_stats': (C.c_int, [C.POINTER(NmodHostStats)]),
+    'nmod_build_info': (C.c_char_p, []),
     'nmod_describe_dispatch': (C.c_int, [C.POINTER(NmodParams), C.c_int64, C.c_int64, C.c_char_p, C.c_int32]),
     'nmod_write_sign_test': (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_void_p,
                                        C.c_char_p] + [C.c_void_p] * 10 + [C.c_int32]),

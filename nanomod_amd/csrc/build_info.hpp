@@ -1,0 +1,61 @@
+// The values of every experiment macro of this translation unit as one string (nmod_build_info, include/nanomod_hip.h):
+// the phase-skip / variant switches compile into the product kernels, so the shipped binary says what it was built with.
+// Include AFTER the kernel headers (their #ifndef defaults must have been seen).
+#pragma once
+#define NMOD_STR2(x) #x
+#define NMOD_STR(x) NMOD_STR2(x)
+#ifdef NMOD_EXP
+#define NMOD_BI_EXP NMOD_STR(NMOD_EXP)
+#else
+#define NMOD_BI_EXP "0"
+#endif
+#ifdef NMOD_SKIP
+#define NMOD_BI_SKIP NMOD_STR(NMOD_SKIP)
+#else
+#define NMOD_BI_SKIP "0"
+#endif
+#ifdef NMOD_HIST_WAVES
+#define NMOD_BI_HIST_WAVES NMOD_STR(NMOD_HIST_WAVES)
+#else
+#define NMOD_BI_HIST_WAVES "4"
+#endif
+#ifdef NMOD_WIDE_PROBES
+#define NMOD_BI_WIDE_PROBES NMOD_STR(NMOD_WIDE_PROBES)
+#else
+#define NMOD_BI_WIDE_PROBES "2"
+#endif
+#ifdef NMOD_WIDE_I16_WORDS
+#define NMOD_BI_WIDE_I16_WORDS NMOD_STR(NMOD_WIDE_I16_WORDS)
+#else
+#define NMOD_BI_WIDE_I16_WORDS "2048"
+#endif
+#ifdef NMOD_SWZ_MASK
+#define NMOD_BI_SWZ_MASK NMOD_STR(NMOD_SWZ_MASK)
+#else
+#define NMOD_BI_SWZ_MASK "0"
+#endif
+#ifdef NMOD_PK_SELECT
+#define NMOD_BI_PK_SELECT "1"
+#else
+#define NMOD_BI_PK_SELECT "0"
+#endif
+#ifdef NMOD_CE_BUILTIN
+#define NMOD_BI_CE_BUILTIN "1"
+#else
+#define NMOD_BI_CE_BUILTIN "0"
+#endif
+#ifdef NMOD_WIDE_POW2
+#define NMOD_BI_WIDE_POW2 "1"
+#else
+#define NMOD_BI_WIDE_POW2 "0"
+#endif
+#ifdef NMOD_XOR4_BANKS
+#define NMOD_BI_XOR4_BANKS "1"
+#else
+#define NMOD_BI_XOR4_BANKS "0"
+#endif
+#define NMOD_BUILD_FLAGS                                                                                              \
+  "NMOD_SKIP=" NMOD_BI_SKIP " NMOD_EXP=" NMOD_BI_EXP " NMOD_HIST_WAVES=" NMOD_BI_HIST_WAVES                            \
+  " NMOD_WIDE_PROBES=" NMOD_BI_WIDE_PROBES " NMOD_WIDE_I16_WORDS=" NMOD_BI_WIDE_I16_WORDS " NMOD_SWZ_MASK=" NMOD_BI_SWZ_MASK \
+  " NMOD_PK_SELECT=" NMOD_BI_PK_SELECT " NMOD_CE_BUILTIN=" NMOD_BI_CE_BUILTIN " NMOD_WIDE_POW2=" NMOD_BI_WIDE_POW2     \
+  " NMOD_XOR4_BANKS=" NMOD_BI_XOR4_BANKS

@@ -32,12 +32,13 @@ static int put_generic(PyObject* row, double* dst, Py_ssize_t room, Py_ssize_t* 
 }
 
 static PyObject* flatten(PyObject* self, PyObject* args) {
-  PyObject* rows; Py_buffer out;
+  PyObject* rows; PyObject* out_obj; Py_buffer out;
   (void)self;
-  if (!PyArg_ParseTuple(args, "Ow*", &rows, &out)) return NULL;
+  if (!PyArg_ParseTuple(args, "OO", &rows, &out_obj)) return NULL;
+  if (PyObject_GetBuffer(out_obj, &out, PyBUF_WRITABLE | PyBUF_FORMAT | PyBUF_ND) < 0) return NULL;   /* (with the format: "w*" hides the element type) */
   PyObject* fast_rows = PySequence_Fast(rows, "rows must be a list or tuple");
   if (!fast_rows) { PyBuffer_Release(&out); return NULL; }
-  if (out.itemsize != 8 && out.len % 8 != 0) {
+  if (out.itemsize != 8 || out.len % 8 != 0 || out.ndim != 1 || (out.format && strcmp(out.format, "d") != 0)) {
     Py_DECREF(fast_rows); PyBuffer_Release(&out);
     PyErr_SetString(PyExc_ValueError, "out must be a float64 buffer"); return NULL;
   }
@@ -58,6 +59,9 @@ static PyObject* flatten(PyObject* self, PyObject* args) {
     }
     if (PyList_CheckExact(r[i]) || PyTuple_CheckExact(r[i])) {
       if (put_generic(r[i], dst + at, cap - at, &wrote) < 0) goto fail;
+    } else if (PyArray_Check(r[i]) && PyArray_NDIM((PyArrayObject*)r[i]) != 1) {
+      /* len(row) of a 2-D row counts its first axis: the caller's sample counts and this walk would disagree */
+      PyErr_SetString(PyExc_ValueError, "every per-position row must be one-dimensional"); goto fail;
     } else if (PyArray_Check(r[i]) && PyArray_TYPE((PyArrayObject*)r[i]) == NPY_DOUBLE && PyArray_IS_C_CONTIGUOUS((PyArrayObject*)r[i])) {
       PyArrayObject* a = (PyArrayObject*)r[i];               /* (the buffer protocol costs ~0.8 us per array: numpy fills in a format string) */
       wrote = (Py_ssize_t)PyArray_SIZE(a);

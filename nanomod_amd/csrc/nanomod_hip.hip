@@ -13,6 +13,7 @@
 #include <mutex>
 #include <thread>
 #include <functional>
+#include <condition_variable>
 
 #include "../../include/nanomod_hip.h"
 #include "rank_stats.hpp"
@@ -20,6 +21,7 @@
 #include "pvalue_kernels.hpp"
 #include "big_rank.hpp"
 #include "rank_all.hpp"
+#include "build_info.hpp"
 
 namespace nmod {
 
@@ -613,138 +615,48 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   return NMOD_OK;
 }
 
-// ---------------------------------------------------------------- host staging
+// ---------------------------------------------------------------- host staging (nmod_combine_track's small buffers)
 struct DevBuf {
   void* p = nullptr;
   ~DevBuf() { if (p) hipFree(p); }
   hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
 };
 
-// sig_on_device: the samples are already device-resident (the float64 front end), everything else is host memory
-static int detect_host(const nmod_params* prm, int64_t npos, const void* sig0, const int64_t* off0,
-                       const void* sig1, const int64_t* off1, const int32_t* run_id, nmod_out* out,
-                       bool sig_on_device = false, const F64Src* f64 = nullptr) {
-  if (npos == 0) return NMOD_OK;
-  if (!sig0 || !sig1 || !out) return NMOD_ERR_INVALID_ARG;
-  if ((prm->stride0 <= 0 && !off0) || (prm->stride1 <= 0 && !off1)) return NMOD_ERR_INVALID_ARG;
-  hipStream_t stream = (hipStream_t)prm->stream;
-  const size_t esz = prm->dtype == NMOD_DTYPE_F32 ? 4 : 2;
-  const int64_t tot0 = prm->stride0 > 0 ? prm->stride0 * npos : off0[npos] - off0[0];
-  const int64_t tot1 = prm->stride1 > 0 ? prm->stride1 * npos : off1[npos] - off1[0];
-  nmod_params dp = *prm;
-  dp.memspace = NMOD_MEM_DEVICE;
-  // the offsets are in host memory here, so the size check is free
-  int64_t m0 = prm->stride0 > 0 ? prm->stride0 : 0, m1 = prm->stride1 > 0 ? prm->stride1 : 0;
-  if (prm->stride0 <= 0) for (int64_t i = 0; i < npos; ++i) m0 = std::max(m0, off0[i + 1] - off0[i]);
-  if (prm->stride1 <= 0) for (int64_t i = 0; i < npos; ++i) m1 = std::max(m1, off1[i + 1] - off1[i]);
-  if (std::max(m0, m1) > NMOD_MAX_RANKED) return NMOD_ERR_TOO_LARGE;
-  dp.max_n0 = (int32_t)std::max<int64_t>(m0, 1); dp.max_n1 = (int32_t)std::max<int64_t>(m1, 1);
-
-  DevBuf d_sig0, d_sig1, d_off0, d_off1, d_run, d_ws, d_out;
-  const int64_t base0 = prm->stride0 > 0 ? 0 : off0[0], base1 = prm->stride1 > 0 ? 0 : off1[0];
-  const void* ds0 = (const char*)sig0 + base0 * esz;
-  const void* ds1 = (const char*)sig1 + base1 * esz;
-  if (!sig_on_device) {
-    NMOD_HIP(d_sig0.alloc(tot0 * esz)); NMOD_HIP(d_sig1.alloc(tot1 * esz));
-    NMOD_HIP(hipMemcpyAsync(d_sig0.p, ds0, tot0 * esz, hipMemcpyHostToDevice, stream));
-    NMOD_HIP(hipMemcpyAsync(d_sig1.p, ds1, tot1 * esz, hipMemcpyHostToDevice, stream));
-    ds0 = d_sig0.p; ds1 = d_sig1.p;
-  }
-  std::vector<int64_t> r0, r1;             // offsets rebased to the staged copy
-  if (prm->stride0 <= 0) {
-    r0.resize(npos + 1); for (int64_t i = 0; i <= npos; ++i) r0[i] = off0[i] - base0;
-    NMOD_HIP(d_off0.alloc((npos + 1) * 8));
-    NMOD_HIP(hipMemcpyAsync(d_off0.p, r0.data(), (npos + 1) * 8, hipMemcpyHostToDevice, stream));
-  }
-  if (prm->stride1 <= 0) {
-    r1.resize(npos + 1); for (int64_t i = 0; i <= npos; ++i) r1[i] = off1[i] - base1;
-    NMOD_HIP(d_off1.alloc((npos + 1) * 8));
-    NMOD_HIP(hipMemcpyAsync(d_off1.p, r1.data(), (npos + 1) * 8, hipMemcpyHostToDevice, stream));
-  }
-  if (run_id) {
-    NMOD_HIP(d_run.alloc(npos * 4));
-    NMOD_HIP(hipMemcpyAsync(d_run.p, run_id, npos * 4, hipMemcpyHostToDevice, stream));
-  }
-  const int64_t wsb = nmod_workspace_bytes(&dp, npos);
-  NMOD_HIP(d_ws.alloc(wsb));
-  // one device slab for the 12 fp64 tracks + status
-  NMOD_HIP(d_out.alloc((size_t)npos * (12 * 8 + 1)));
-  double* slab = (double*)d_out.p;
-  nmod_out dout;
-  double** hp = (double**)out;             // the 12 leading members are double*
-  double** dpv = (double**)&dout;
-  for (int k = 0; k < 12; ++k) dpv[k] = hp[k] ? slab + (int64_t)k * npos : nullptr;
-  dout.status = out->status ? (uint8_t*)(slab + 12 * npos) : nullptr;
-
-  // (sig_on_device: the staged offsets are rebased by base0 / base1, and so are the pointers — keys and float64 samples)
-  F64Src fsrc;
-  if (f64) { fsrc = *f64; fsrc.d0 += base0; fsrc.d1 += base1; }
-  int rc = detect_device(&dp, npos, ds0, (const int64_t*)d_off0.p, ds1, (const int64_t*)d_off1.p,
-                         (const int32_t*)d_run.p, d_ws.p, wsb, &dout, f64 ? &fsrc : nullptr);
-  if (rc != NMOD_OK) { hipStreamSynchronize(stream); return rc; }
-  // copy back exactly the tracks detect_device wrote (same predicate: the KS pair exists iff KS was asked for or
-  // the combine ran, and the combine runs only when both of its outputs were given)
-  const bool want_comb = prm->method != NMOD_METHOD_KS && out->comb_st && out->comb_p;
-  for (int k = 0; k < 12; ++k) {
-    if (!hp[k]) continue;
-    if (!want_comb && (k == 6 || k == 7)) continue;                    // comb_* untouched
-    if (!prm->want_mstd && k >= 8) continue;
-    if (k < 2 && !(prm->tests & NMOD_TEST_MWU)) continue;
-    if ((k == 2 || k == 3) && !(prm->tests & NMOD_TEST_WELCH)) continue;
-    if ((k == 4 || k == 5) && !(prm->tests & NMOD_TEST_KS) && !want_comb) continue;
-    NMOD_HIP(hipMemcpyAsync(hp[k], dpv[k], npos * 8, hipMemcpyDeviceToHost, stream));
-  }
-  if (out->status) NMOD_HIP(hipMemcpyAsync(out->status, dout.status, npos, hipMemcpyDeviceToHost, stream));
-  NMOD_HIP(hipStreamSynchronize(stream));
-  return NMOD_OK;
-}
-
 // ---------------------------------------------------------------- float64 front end
 // Gives every position order-preserving float32 keys (f64_encode_kernel) and runs the batch on them; see F64Args.
+// Device memory only (the host entry hands its chunks over as device memory, host_pipeline.hpp).  bounds: the first and
+// one-past-last element of each array in use, {b0, e0, b1, e1}, when the caller knows them (no round trip for the offsets).
 static int detect_f64(const nmod_params* prm, int64_t npos, const void* sig0, const int64_t* off0,
                       const void* sig1, const int64_t* off1, const int32_t* run_id, void* workspace,
-                      int64_t workspace_bytes, nmod_out* out) {
+                      int64_t workspace_bytes, nmod_out* out, const int64_t* bounds = nullptr) {
   if (npos == 0) return NMOD_OK;
   if (!sig0 || !sig1 || !out) return NMOD_ERR_INVALID_ARG;
   if ((prm->stride0 <= 0 && !off0) || (prm->stride1 <= 0 && !off1)) return NMOD_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)prm->stream;
-  const bool host = prm->memspace == NMOD_MEM_HOST;
   // sample counts and the first sample of each array (offsets need not start at 0)
   int64_t b0 = 0, e0 = prm->stride0 * npos, b1 = 0, e1 = prm->stride1 * npos;
-  if (prm->stride0 <= 0) {
-    if (host) { b0 = off0[0]; e0 = off0[npos]; }
-    else { int64_t t[2]; NMOD_HIP(hipMemcpyAsync(&t[0], off0, 8, hipMemcpyDeviceToHost, stream));
-           NMOD_HIP(hipMemcpyAsync(&t[1], off0 + npos, 8, hipMemcpyDeviceToHost, stream)); NMOD_HIP(hipStreamSynchronize(stream)); b0 = t[0]; e0 = t[1]; }
-  }
-  if (prm->stride1 <= 0) {
-    if (host) { b1 = off1[0]; e1 = off1[npos]; }
-    else { int64_t t[2]; NMOD_HIP(hipMemcpyAsync(&t[0], off1, 8, hipMemcpyDeviceToHost, stream));
-           NMOD_HIP(hipMemcpyAsync(&t[1], off1 + npos, 8, hipMemcpyDeviceToHost, stream)); NMOD_HIP(hipStreamSynchronize(stream)); b1 = t[0]; e1 = t[1]; }
+  if (bounds) { b0 = bounds[0]; e0 = bounds[1]; b1 = bounds[2]; e1 = bounds[3]; }
+  else {
+    if (prm->stride0 <= 0) {
+      int64_t t[2]; NMOD_HIP(hipMemcpyAsync(&t[0], off0, 8, hipMemcpyDeviceToHost, stream));
+      NMOD_HIP(hipMemcpyAsync(&t[1], off0 + npos, 8, hipMemcpyDeviceToHost, stream)); NMOD_HIP(hipStreamSynchronize(stream)); b0 = t[0]; e0 = t[1];
+    }
+    if (prm->stride1 <= 0) {
+      int64_t t[2]; NMOD_HIP(hipMemcpyAsync(&t[0], off1, 8, hipMemcpyDeviceToHost, stream));
+      NMOD_HIP(hipMemcpyAsync(&t[1], off1 + npos, 8, hipMemcpyDeviceToHost, stream)); NMOD_HIP(hipStreamSynchronize(stream)); b1 = t[0]; e1 = t[1];
+    }
   }
   const int64_t n0 = e0 - b0, n1 = e1 - b1;
   if (n0 < 0 || n1 < 0) return NMOD_ERR_INVALID_ARG;
-  DevBuf st0, st1, d_o0, d_o1;
   DevScratch enc0, enc1, d_cls3;                    // stream-ordered, from the library's pool: no device-wide synchronisation per batch
-  const double* d0 = (const double*)sig0 + b0;       // first sample in use
-  const double* d1 = (const double*)sig1 + b1;
-  const int64_t* doff0 = off0; const int64_t* doff1 = off1;
-  if (host) {
-    NMOD_HIP(st0.alloc((size_t)n0 * 8)); NMOD_HIP(st1.alloc((size_t)n1 * 8));
-    NMOD_HIP(hipMemcpyAsync(st0.p, d0, (size_t)n0 * 8, hipMemcpyHostToDevice, stream));
-    NMOD_HIP(hipMemcpyAsync(st1.p, d1, (size_t)n1 * 8, hipMemcpyHostToDevice, stream));
-    d0 = (const double*)st0.p; d1 = (const double*)st1.p;
-    // the encoder walks the rows on the device: it needs the offsets there (detect_host stages its own, rebased copy)
-    if (prm->stride0 <= 0) { NMOD_HIP(d_o0.alloc((npos + 1) * 8)); NMOD_HIP(hipMemcpyAsync(d_o0.p, off0, (npos + 1) * 8, hipMemcpyHostToDevice, stream)); doff0 = (const int64_t*)d_o0.p; }
-    if (prm->stride1 <= 0) { NMOD_HIP(d_o1.alloc((npos + 1) * 8)); NMOD_HIP(hipMemcpyAsync(d_o1.p, off1, (npos + 1) * 8, hipMemcpyHostToDevice, stream)); doff1 = (const int64_t*)d_o1.p; }
-  }
   NMOD_HIP(enc0.alloc((size_t)n0 * 4, stream, prm->device)); NMOD_HIP(enc1.alloc((size_t)n1 * 4, stream, prm->device));
   NMOD_HIP(d_cls3.alloc((size_t)npos, stream, prm->device));
   // pointers in the index space of the offsets (sample i of the arrays sits at [i], whatever the first offset is)
   F64Src src;
-  src.d0 = d0 - b0; src.d1 = d1 - b1; src.cls3 = (uint8_t*)d_cls3.p;
+  src.d0 = (const double*)sig0; src.d1 = (const double*)sig1; src.cls3 = (uint8_t*)d_cls3.p;
   F64Args fx;
   memset(&fx, 0, sizeof(fx));
-  fx.d0 = src.d0; fx.d1 = src.d1; fx.off0 = doff0; fx.off1 = doff1;
+  fx.d0 = src.d0; fx.d1 = src.d1; fx.off0 = off0; fx.off1 = off1;
   fx.stride0 = prm->stride0 > 0 ? prm->stride0 : 0; fx.stride1 = prm->stride1 > 0 ? prm->stride1 : 0;
   fx.npos = npos; fx.k0 = (float*)enc0.p - b0; fx.k1 = (float*)enc1.p - b1; fx.cls3 = src.cls3;
   int num_cus = 0;
@@ -754,14 +666,14 @@ static int detect_f64(const nmod_params* prm, int64_t npos, const void* sig0, co
   NMOD_HIP(hipGetLastError());
   nmod_params ep = *prm;
   ep.dtype = NMOD_DTYPE_F32;
-  int rc;
-  if (host) rc = detect_host(&ep, npos, fx.k0, off0, fx.k1, off1, run_id, out, true, &src);
-  else rc = detect_device(&ep, npos, fx.k0, off0, fx.k1, off1, run_id, workspace, workspace_bytes, out, &src);
-  // the key buffers go back to the pool in stream order (the host path has synchronised already)
+  int rc = detect_device(&ep, npos, fx.k0, off0, fx.k1, off1, run_id, workspace, workspace_bytes, out, &src);
+  // the key buffers go back to the pool in stream order
   const hipError_t r0 = enc0.release(stream), r1 = enc1.release(stream), r2 = d_cls3.release(stream);
   if (rc == NMOD_OK && (r0 != hipSuccess || r1 != hipSuccess || r2 != hipSuccess)) { g_last_hip = r0 != hipSuccess ? r0 : (r1 != hipSuccess ? r1 : r2); rc = NMOD_ERR_HIP; }
   return rc;
 }
+
+#include "host_pipeline.hpp"
 
 // ---------------------------------------------------------------- self test kernels
 __global__ void selftest_perm_kernel(int* out) {
@@ -872,10 +784,9 @@ int nmod_detect_batch(const nmod_params* prm, int64_t npos, const void* sig0, co
   if (npos < 0) return NMOD_ERR_INVALID_ARG;
   if (nmod_device_count() <= prm->device || prm->device < 0) return NMOD_ERR_NO_DEVICE;
   NMOD_HIP(hipSetDevice(prm->device));
+  if (prm->memspace == NMOD_MEM_HOST) return detect_host_pipelined(prm, npos, sig0, off0, sig1, off1, run_id, out);
   if (prm->dtype == NMOD_DTYPE_F64) return detect_f64(prm, npos, sig0, off0, sig1, off1, run_id, workspace, workspace_bytes, out);
-  if (prm->memspace == NMOD_MEM_DEVICE)
-    return detect_device(prm, npos, sig0, off0, sig1, off1, run_id, workspace, workspace_bytes, out);
-  return detect_host(prm, npos, sig0, off0, sig1, off1, run_id, out);
+  return detect_device(prm, npos, sig0, off0, sig1, off1, run_id, workspace, workspace_bytes, out);
 }
 
 int nmod_combine_track(const nmod_params* prm, int64_t npos, const double* ks_d, const double* ks_p,
@@ -982,8 +893,37 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
   return NMOD_OK;
 }
 
+int nmod_host_pipeline_config(int64_t chunk_bytes, int32_t slots, int32_t threads, int32_t mode) {
+  if (chunk_bytes < 0 || slots < 0 || slots > kHpMaxSlots || threads < 0 || threads > 256 || mode < 0 || mode > 2) return NMOD_ERR_INVALID_ARG;
+  g_hp_chunk_bytes.store(chunk_bytes); g_hp_slots.store(slots); g_hp_threads.store(threads); g_hp_mode.store(mode);
+  return NMOD_OK;
+}
+
+int nmod_last_host_stats(nmod_host_stats* st) {
+  if (!st) return NMOD_ERR_INVALID_ARG;
+  *st = g_host_stats;
+  return NMOD_OK;
+}
+
+const char* nmod_build_info(void) {
+  static std::once_flag once;
+  static std::string info;
+  std::call_once(once, [] {
+    char head[96];
+    snprintf(head, sizeof(head), "arch=gfx950 abi=%d hip=%d.%d", NMOD_ABI_VERSION, HIP_VERSION_MAJOR, HIP_VERSION_MINOR);
+    info = head;
+    info += " | abi_tu: " NMOD_BUILD_FLAGS;
+    info += std::string(" | k1_f32_ks: ") + rank_stats_build_flags_d0_a0();
+    info += std::string(" | k1_f32_all: ") + rank_stats_build_flags_d0_a1();
+    info += std::string(" | k1_i16_ks: ") + rank_stats_build_flags_d1_a0();
+    info += std::string(" | k1_i16_all: ") + rank_stats_build_flags_d1_a1();
+  });
+  return info.c_str();
+}
+
 int nmod_trim_scratch(int32_t device) {
   if (device < 0 || device >= kMaxDevices) return NMOD_ERR_INVALID_ARG;
+  hp_trim(device);                                // the pinned ring + streams of the host-resident entry
   std::lock_guard<std::mutex> lock(g_pool_mutex);
   if (g_pool[device]) NMOD_HIP(hipMemPoolTrimTo(g_pool[device], 0));
   return NMOD_OK;

@@ -504,7 +504,7 @@ void rank_hist_kernel(RankStatsArgs args) {
       // blocks per CU instead of four and two; any step in 1 .. nslots - 1 visits every slot: here 1 .. 512)
       auto walk_to_end = [&](unsigned bits, bool act) {
         const unsigned hsh = bits * 2654435761u;
-        unsigned hh = ((hsh >> 12) * nslots) >> 20;         // 20 hash bits x a 13-bit prime: below 2^32
+        unsigned hh = ((hsh >> 13) * nslots) >> 19;         // 19 hash bits x at most 4 099 slots: (2^19 - 1) * 4 099 < 2^32, no wrap
         const unsigned st = 1u + (hsh & 511u);
         unsigned dup = 0u;
         while (__ballot(act) != 0ull) {
@@ -531,7 +531,7 @@ void rank_hist_kernel(RankStatsArgs args) {
         for (int e = 0; e < NV; ++e) {
           bits[e] = __float_as_uint(xq[e] + 0.0f);                             // (-0.0 -> +0.0: one key per value)
           const unsigned hsh = bits[e] * 2654435761u;
-          hh[e] = ((hsh >> 12) * nslots) >> 20;
+          hh[e] = ((hsh >> 13) * nslots) >> 19;                               // (19 bits: the product stays below 2^32 for every table size)
           st[e] = 1u + (hsh & 511u);
           // (two passes: the values are split by one more hash bit; each pass holds one half in the table)
           const bool mine = wide_passes == 1 || ((hsh >> 9) & 1u) == (unsigned)pass;

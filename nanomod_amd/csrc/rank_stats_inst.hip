@@ -8,6 +8,7 @@
 #include "rank_all.hpp"
 #include "rank_hist.hpp"
 #include "rank_stats_launch.hpp"
+#include "build_info.hpp"
 
 #ifndef NMOD_INST_DTYPE
 #error "define NMOD_INST_DTYPE and NMOD_INST_ALL"
@@ -93,6 +94,10 @@ KernelFn pick_ks(int cs, bool flags) {
 #define NMOD_CAT2(a, b) a##b
 #define NMOD_CAT(a, b) NMOD_CAT2(a, b)
 #define NMOD_LAUNCH_NAME NMOD_CAT(NMOD_CAT(launch_rank_stats_d, NMOD_INST_DTYPE), NMOD_CAT(_a, NMOD_INST_ALL))
+#define NMOD_FLAGS_NAME NMOD_CAT(NMOD_CAT(rank_stats_build_flags_d, NMOD_INST_DTYPE), NMOD_CAT(_a, NMOD_INST_ALL))
+
+// the experiment macros THIS translation unit's kernels were compiled with (nmod_build_info)
+const char* NMOD_FLAGS_NAME() { return NMOD_BUILD_FLAGS; }
 
 hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_t stream,
                             const RankStatsArgs& args) {

@@ -129,5 +129,10 @@ hipError_t launch_rank_stats_d0_a0(int cls, int num_cus, int64_t work_items, hip
 hipError_t launch_rank_stats_d0_a1(int cls, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);
 hipError_t launch_rank_stats_d1_a0(int cls, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);
 hipError_t launch_rank_stats_d1_a1(int cls, int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a);
+// the experiment macros each of the four translation units was compiled with (build_info.hpp)
+const char* rank_stats_build_flags_d0_a0();
+const char* rank_stats_build_flags_d0_a1();
+const char* rank_stats_build_flags_d1_a0();
+const char* rank_stats_build_flags_d1_a1();
 
 }  // namespace nmod

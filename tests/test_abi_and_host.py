@@ -24,8 +24,48 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L._SIGNATURES), declared ^ set(L._SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.nmod_abi_version() == 2
+    assert lib.nmod_abi_version() == 3
     assert b'invalid' in lib.nmod_strerror(-1) and b'65535' in lib.nmod_strerror(-3)
+
+
+def test_shipped_binary_is_a_product_build():
+    """nmod_build_info lists the experiment macros of every translation unit: the shipped library skips no phase
+    (NMOD_SKIP / NMOD_EXP are phase-skip switches of the kernel headers) and runs the default variants."""
+    import nanomod_amd._lib as L
+    info = L.load().nmod_build_info().decode()
+    parts = info.split(' | ')
+    assert parts[0].startswith('arch=gfx950 abi=3 ')
+    names = [p.split(':')[0] for p in parts[1:]]
+    assert names == ['abi_tu', 'k1_f32_ks', 'k1_f32_all', 'k1_i16_ks', 'k1_i16_all']
+    want = {'NMOD_SKIP': '0', 'NMOD_EXP': '0', 'NMOD_HIST_WAVES': '4', 'NMOD_WIDE_PROBES': '2', 'NMOD_WIDE_I16_WORDS': '2048',
+            'NMOD_SWZ_MASK': '0', 'NMOD_PK_SELECT': '0', 'NMOD_CE_BUILTIN': '0', 'NMOD_WIDE_POW2': '0', 'NMOD_XOR4_BANKS': '0'}
+    for p in parts[1:]:
+        got = dict(kv.split('=') for kv in p.split(': ', 1)[1].split())
+        assert got == want, (p, got)
+    # every NMOD_* switch the kernel sources test is reported (a new experiment macro must be added to build_info.hpp)
+    src_dir = os.path.join(ROOT, 'nanomod_amd', 'csrc')
+    used = set()
+    for fn in os.listdir(src_dir):
+        if fn.endswith(('.hpp', '.hip')) and fn != 'build_info.hpp':
+            for ln in open(os.path.join(src_dir, fn)):
+                if ln.lstrip().startswith(('#if', '#elif')):
+                    used |= set(re.findall(r'\bNMOD_[A-Z0-9_]+\b', ln))
+    structural = {'NMOD_INST_DTYPE', 'NMOD_INST_ALL', 'NMOD_HIP', 'NMOD_CAT', 'NMOD_CAT2', 'NMOD_LAUNCH_NAME', 'NMOD_FLAGS_NAME', 'NMOD_QP',
+                  'NMOD_PK8', 'NMOD_ABI_VERSION', 'NMOD_BUILD_FLAGS'}
+    used = {u for u in used if u not in structural and not u.startswith(('NMOD_BI_', 'NMOD_STR'))}
+    assert used <= set(want), used - set(want)
+
+
+def test_host_pipeline_config_validates():
+    import nanomod_amd._lib as L
+    lib = L.load()
+    assert lib.nmod_host_pipeline_config(-1, 0, 0, 0) == -1
+    assert lib.nmod_host_pipeline_config(0, 9, 0, 0) == -1
+    assert lib.nmod_host_pipeline_config(0, 0, 0, 3) == -1
+    assert lib.nmod_host_pipeline_config(1 << 20, 4, 2, 2) == 0
+    assert lib.nmod_host_pipeline_config(0, 0, 0, 0) == 0
+    st = L.NmodHostStats()
+    assert lib.nmod_last_host_stats(C.byref(st)) == 0 and st.chunks == 0
 
 
 def test_struct_layout_matches_header():

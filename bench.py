@@ -287,9 +287,9 @@ def host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests,
 
     def run(a, b, reps):
         best, st, res = None, None, None
-        for _ in range(reps):
+        for _ in range(reps):                        # (the result arrays of the first call are written again by the next ones)
             t0 = time.perf_counter()
-            res = nm.detect_host(a, None, b, None, rid, nb=nb, weights_dif=wdif, method=method, tests=tests, stride0=n0, stride1=n1, device=dev_index)
+            res = nm.detect_host(a, None, b, None, rid, nb=nb, weights_dif=wdif, method=method, tests=tests, stride0=n0, stride1=n1, device=dev_index, out=res)
             dt = time.perf_counter() - t0
             if best is None or dt < best:
                 best = dt

@@ -160,7 +160,7 @@ int nmod_detect_batch(const nmod_params* prm, int64_t npos,
                       nmod_out* out);
 
 /* Tunables of the NMOD_MEM_HOST pipeline, process-wide; 0 keeps / restores the default.  chunk_bytes: sample bytes per
- * chunk (default min(32 MiB, batch / 8), at least 1 MiB; env NMOD_HOST_CHUNK_BYTES); slots: ring depth 2..8 (default 3; env
+ * chunk (default min(64 MiB, batch / 32), at least 1 MiB; env NMOD_HOST_CHUNK_BYTES); slots: ring depth 2..8 (default 3; env
  * NMOD_HOST_SLOTS); threads: host threads filling a bounce slot (default 4, capped by the cgroup CPU quota; env
  * NMOD_HOST_THREADS); mode: 0 = copy straight from arrays that are page-locked, bounce the rest; 2 = always bounce. */
 int nmod_host_pipeline_config(int64_t chunk_bytes, int32_t slots, int32_t threads, int32_t mode);

@@ -18,7 +18,7 @@
 // ---------------------------------------------------------------- tunables (nmod_host_pipeline_config; 0 = default)
 static std::atomic<int64_t> g_hp_chunk_bytes{0};
 static std::atomic<int> g_hp_slots{0}, g_hp_threads{0}, g_hp_mode{0};
-constexpr int64_t kHpDefaultChunk = 32ll << 20;      // 32 MiB of samples per chunk: 0.97 of the pinned H2D rate (64 MiB: 0.99, 16 MiB: 0.94)
+constexpr int64_t kHpDefaultChunk = 64ll << 20;      // 64 MiB of samples per chunk (measured at 7.4 GB, pageable input: 0.947 of the pinned H2D rate; 32 MiB: 0.933, 16 MiB: 0.898)
 constexpr int kHpMaxSlots = 8;
 
 static int64_t env_i64(const char* name, int64_t dflt) {
@@ -209,7 +209,7 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
 
   int64_t chunk_bytes = g_hp_chunk_bytes.load();
   if (chunk_bytes <= 0) chunk_bytes = env_i64("NMOD_HOST_CHUNK_BYTES", 0);
-  if (chunk_bytes <= 0) chunk_bytes = std::min<int64_t>(kHpDefaultChunk, std::max<int64_t>(1 << 20, total_bytes / 8));   // small batches: ~8 chunks, still overlapping
+  if (chunk_bytes <= 0) chunk_bytes = std::min<int64_t>(kHpDefaultChunk, std::max<int64_t>(1 << 20, total_bytes / 32));   // smaller batches: ~32 chunks, so that fill, copy and kernels still overlap
   int slots = g_hp_slots.load();
   if (slots <= 0) slots = (int)env_i64("NMOD_HOST_SLOTS", 3);
   slots = std::max(2, std::min(slots, kHpMaxSlots));

@@ -90,7 +90,7 @@ def test_chunked_equals_device_resident_csr(dtype, tests_mask, method):
         if chunk_bytes == 1:
             assert st.chunks == npos and st.chunk_positions == 1
         _same(got, ref, [k for k in names if k in got])
-    # the default configuration: a small batch is one pipeline of ~8 chunks (>= 1 MiB each -> here a single chunk)
+    # the default configuration: a small batch is cut into ~32 chunks of >= 1 MiB (here: one or two chunks)
     assert lib.nmod_host_pipeline_config(0, 0, 0, 0) == 0
     got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method=method, tests=tests_mask)
     _same(got, ref, [k for k in names if k in got])

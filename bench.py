@@ -350,6 +350,39 @@ def profile_record(lib_path, key):
     return None
 
 
+def rank_plan(args, world, rank):
+    """What this rank will hold in HBM (no GPU call, no library): its blocks of the block-cyclic partition + halos, their
+    sample bytes (ragged: from the position-keyed size generator), workspace, result tracks and the gather buffers."""
+    sys.path.insert(0, ROOT)
+    from nanomod_amd import sharding
+    preset = PRESETS[args.config]
+    csr = preset['layout'] == 'csr'
+    all_tests = bool(args.all_tests or preset['all_tests'])
+    n0, n1 = args.n0 or preset['n0'], args.n1 or preset['n1']
+    positions = args.positions or preset['positions']
+    sb = 4 if args.dtype == 'f32' else 2
+    chunks = args.chunks or (4 if world > 1 else 1)
+    total = positions if args.strong else positions * world
+    B = sharding.cyclic_block_len(total, world, chunks)
+    total = B * world * chunks
+    own, with_halo, samples = 0, 0, 0
+    for c in range(chunks):
+        lo, hi = sharding.cyclic_block(total, world, rank, chunks, c)
+        lo_h, hi_h = sharding.halo_bounds(lo, hi, NB, total)
+        own += hi - lo; with_halo += hi_h - lo_h
+        if csr:
+            samples += int(ragged_sizes(SEED, lo_h, hi_h - lo_h, 0).sum() + ragged_sizes(SEED, lo_h, hi_h - lo_h, 1).sum())
+        else:
+            samples += (hi_h - lo_h) * (n0 + n1)
+    k_tracks = 8 if all_tests else 4
+    dev_bytes = (samples * sb + (16 * with_halo if csr else 0) + 4 * with_halo          # rows, offsets, run ids
+                 + 86 * (B + 2 * NB) + 4096                                              # workspace (one block at a time; nmod_workspace_bytes)
+                 + (8 * k_tracks + 1) * with_halo                                        # result tracks + status
+                 + 2 * 8 * total)                                                        # gathered ks_p / comb_p (full length on every rank)
+    return {'positions_total': total, 'positions_own': own, 'positions_with_halo': with_halo, 'block': B, 'chunks': chunks,
+            'sample_bytes': samples * sb, 'device_bytes': dev_bytes, 'fits_288GB': bool(dev_bytes < 288e9 * 0.9)}
+
+
 def launch_ranks(args, argv):
     """N > 1 without an external launcher: one fresh child process per GPU.  This process has not imported torch.cuda
     or loaded the HIP library; it only forwards the children's output (rank 0's JSON line last) and their failure."""
@@ -413,7 +446,7 @@ def main():
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
     if args.launch_only:
-        print(json.dumps({'launch_only': True, 'rank': rank, 'local_rank': local_rank, 'world_size': world,
+        print(json.dumps({'launch_only': True, 'rank': rank, 'local_rank': local_rank, 'world_size': world, 'plan': rank_plan(args, world, rank),
                           'master': '%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'))}), flush=True)
         return
 
@@ -602,6 +635,49 @@ def main():
             same = bool(torch.equal(full['ks_p'][blocks[0]['lo_h']:blocks[0]['lo_h'] + vn], blocks[0]['out']['ks_p'][:vn]))
             verify['gathered_track_equals_local'] = same
             verify['ok'] = verify['ok'] and same
+            # ... and every OTHER rank's blocks at theirs: rank 0 regenerates (the generator is keyed by the global position) a
+            # window of +-2 nb positions around every block boundary of the cyclic partition, recomputes it with +-nb more as
+            # context, and compares with the gathered tracks bit for bit — a block landing at the wrong offset cannot pass
+            W, ctx = 4 * NB, NB
+            bounds = [k * B for k in range(1, world * chunks) if k * B < total]
+            if bounds:
+                wins = [(max(pb - W // 2 - ctx, 0), min(pb + W // 2 + ctx, total)) for pb in bounds]
+                npw = sum(hi - lo for lo, hi in wins)
+                w_rid = torch.cat([torch.full((hi - lo,), i, dtype=torch.int32) for i, (lo, hi) in enumerate(wins)]).to(dev)
+                if csr:
+                    sz = [np.concatenate([ragged_sizes(SEED, lo, hi - lo, g) for lo, hi in wins]) for g in (0, 1)]
+                    w_off = [np.zeros(npw + 1, np.int64), np.zeros(npw + 1, np.int64)]
+                    for g in (0, 1):
+                        np.cumsum(sz[g], out=w_off[g][1:])
+                    w_sig = [torch.empty(int(w_off[g][-1]), dtype=tdtype, device=dev) for g in (0, 1)]
+                    at = 0
+                    for lo, hi in wins:
+                        for g in (0, 1):
+                            o = torch.from_numpy(w_off[g][at:at + hi - lo + 1] - w_off[g][at]).to(dev)
+                            det.synth_fill_csr(w_sig[g][int(w_off[g][at]):int(w_off[g][at + hi - lo])], SEED, lo, o, g, PLANT_PERIOD, PLANT_SHIFT)
+                        at += hi - lo
+                    wr = det.run(w_sig[0], w_sig[1], w_rid, off0=torch.from_numpy(w_off[0]).to(dev), off1=torch.from_numpy(w_off[1]).to(dev),
+                                 max_n0=RAGGED_CLIP0[1], max_n1=RAGGED_CLIP1[1])
+                else:
+                    w_sig = [torch.empty(npw * (n0, n1)[g], dtype=tdtype, device=dev) for g in (0, 1)]
+                    at = 0
+                    for lo, hi in wins:
+                        for g in (0, 1):
+                            nn = (n0, n1)[g]
+                            det.synth_fill(w_sig[g][at * nn:(at + hi - lo) * nn], SEED, lo, hi - lo, g, nn, PLANT_PERIOD, PLANT_SHIFT)
+                        at += hi - lo
+                    wr = det.run(w_sig[0], w_sig[1], w_rid, stride0=n0, stride1=n1, npos=npw)
+                torch.cuda.synchronize()
+                bad, at = 0, 0
+                for (lo, hi), pb in zip(wins, bounds):
+                    a0, a1 = max(pb - W // 2, 0), min(pb + W // 2, total)         # positions whose +-nb window the recomputation holds
+                    for k in ('ks_p', 'comb_p'):
+                        g_ = full[k][a0:a1]; e_ = wr[k][at + a0 - lo: at + a1 - lo]
+                        bad += int((~((g_ == e_) | (torch.isnan(g_) & torch.isnan(e_)))).sum().item())
+                    at += hi - lo
+                verify['block_boundaries_checked'] = len(bounds)
+                verify['block_boundary_positions_differing'] = bad
+                verify['ok'] = verify['ok'] and bad == 0
         if not verify['ok']:
             print('bench.py: verification against the oracle FAILED: %r' % verify, file=sys.stderr)
 
@@ -790,6 +866,7 @@ def main():
                      'note': 'rocprofv3 SQ_INSTS_VALU / positions and SQ_ACTIVE_INST_VALU x 4 / SIMD cycles of the K1 kernel, taken '
                              'with this library binary (null: this binary has not been profiled)'},
             'verify': verify,
+            'build_info': L.load().nmod_build_info().decode(),
         }
         line.update(side)
         if host_path is not None:

@@ -28,6 +28,34 @@ def test_gpus2_spawns_two_fresh_ranks():
     assert r.stdout.rstrip().splitlines()[-1].startswith('{')            # a JSON line is the last line of stdout
 
 
+def test_chr20_on_8_ranks_plan_fits_the_gpus():
+    """BASELINE configs[3] in its stated form (64 M positions x 500 v 500 over 8 GPUs) has never run on hardware; what can be
+    checked without it: 8 fresh ranks start, each plans 8 M positions of its own (+ halos), 32 GB of samples, and the total
+    it will hold — rows, workspace, results, the gathered full-length tracks — fits one MI355X's 288 GB."""
+    r = _run(['--gpus', '8', '--launch-only', '--config', 'chr20'], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = sorted((json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')), key=lambda x: x['rank'])
+    assert [x['rank'] for x in recs] == list(range(8)) and all(x['world_size'] == 8 for x in recs)
+    plans = [x['plan'] for x in recs]
+    assert all(p['positions_total'] == 64_000_000 and p['chunks'] == 4 and p['block'] == 2_000_000 for p in plans)
+    assert sum(p['positions_own'] for p in plans) == 64_000_000 and all(p['positions_own'] == 8_000_000 for p in plans)
+    assert all(8_000_000 < p['positions_with_halo'] <= 8_000_000 + 4 * 2 * 2 for p in plans)      # +-nb per block
+    assert all(31.9e9 < p['sample_bytes'] < 32.1e9 for p in plans)
+    assert all(p['fits_288GB'] and p['device_bytes'] < 40e9 for p in plans)
+
+
+def test_ragged_plan_uses_the_position_keyed_sizes():
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    a = argparse.Namespace(config='ragged', all_tests=False, n0=0, n1=0, positions=200_000, dtype='f32', chunks=0, strong=False)
+    plans = [bench.rank_plan(a, 2, r) for r in (0, 1)]
+    assert all(p['positions_total'] == 400_000 and p['chunks'] == 4 for p in plans)
+    tot = sum(int(bench.ragged_sizes(bench.SEED, 0, 400_000, g).sum()) for g in (0, 1)) * 4
+    # the two ranks hold every row once, + the halo rows twice
+    assert tot <= sum(p['sample_bytes'] for p in plans) <= tot + 8 * 2 * 2 * (4000 + 400) * 4
+
+
 def test_under_an_external_launcher_it_is_a_rank():
     r = _run(['--gpus', '2', '--launch-only'], env={'RANK': '1', 'WORLD_SIZE': '2', 'LOCAL_RANK': '1'})
     assert r.returncode == 0, r.stderr[-2000:]

@@ -81,6 +81,74 @@ def test_sharded_equals_unsharded(npos, nb, method):
             assert np.array_equal(results[r][k], full[k], equal_nan=True), (r, k)
 
 
+def _pipe_worker(rank, world, port, npos, nb, chunk_list, q):
+    """pipelined_detect only (what bench.py --gpus N times), any world size: two consecutive steps per state object"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nanomod_amd import sharding
+    sig0, off0, sig1, off1, rid = _make(npos, 7)
+    calls = []
+
+    def compute(c, lo, hi):
+        calls.append((c, lo, hi))
+        o0 = off0[lo:hi + 1] - off0[lo]; o1 = off1[lo:hi + 1] - off1[lo]
+        r = oracle_c.detect_batch(sig0[off0[lo]:off0[hi]], o0, sig1[off1[lo]:off1[hi]], o1, rid[lo:hi], nb, 2.0, 'stouffer', threads=1)
+        return {k: torch.from_numpy(v) for k, v in r.items() if k != 'status'}
+    tracks = ('ks_p', 'comb_p')
+    res = {}
+    for chunks in chunk_list:
+        state = sharding.PipelinedGather(npos, world, chunks, tracks, 'cpu')
+        for step in range(2):
+            del calls[:]
+            sharding.pipelined_detect(compute, state, nb)
+            if step == 0:                             # poison the buffers: the second step must rewrite every element
+                first = {k: v.numpy().copy() for k, v in state.result().items()}
+                for t in tracks:
+                    state.full[t].fill_(-7.0)
+        second = {k: v.numpy().copy() for k, v in state.result().items()}
+        for k in tracks:
+            assert np.array_equal(first[k], second[k], equal_nan=True), (rank, chunks, k)
+        # this rank computed exactly its non-empty blocks (+ halo), nothing for an empty tail block
+        want = []
+        for c in range(chunks):
+            lo, hi = sharding.cyclic_block(npos, world, rank, chunks, c)
+            if hi > lo:
+                want.append((c,) + sharding.halo_bounds(lo, hi, nb, npos))
+        assert calls == want, (rank, chunks, calls, want)
+        res[chunks] = second
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,npos', [(4, 43), (8, 67), (8, 9)])
+def test_pipelined_gather_world_4_and_8_short_and_empty_tail_blocks(world, npos):
+    """block-cyclic partition at the node sizes the driver scales to: with chunks = 4 the tail holds a short block and
+    empty ones (npos = 67, world 8: B = 3, block 22 holds one position, blocks 23..31 none; npos = 9: most ranks idle)"""
+    from nanomod_amd import sharding
+    chunk_list = (1, 4)
+    B = sharding.cyclic_block_len(npos, world, 4)
+    sizes = [hi - lo for c in range(4) for r in range(world) for lo, hi in [sharding.cyclic_block(npos, world, r, 4, c)]]
+    assert 0 in sizes and any(0 < x < B for x in sizes) or npos == 9
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, npos, 2, chunk_list, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sig0, off0, sig1, off1, rid = _make(npos, 7)
+    full = oracle_c.detect_batch(sig0, off0, sig1, off1, rid, 2, 2.0, 'stouffer', threads=1)
+    for r in range(world):
+        for chunks in chunk_list:
+            for k in ('ks_p', 'comb_p'):
+                assert np.array_equal(results[r][chunks][k], full[k], equal_nan=True), (r, chunks, k)
+
+
 def test_cyclic_blocks_tile_the_genome():
     from nanomod_amd import sharding
     for npos, world, chunks in ((1000, 2, 4), (1001, 8, 3), (5, 4, 2), (4600000, 8, 4)):

@@ -106,6 +106,21 @@ __device__ __forceinline__ void ce_raw(float& lo, float& hi) {
   lo = a; hi = b;
 }
 
+// Is the float32 sample x on the milli-unit grid of real events (myRefBaseSignalAnnotation.py:1108 rounds them to 3 decimals),
+// i.e. x == RN32(k / 1000) for an integer |k| <= 32 767?  k = rint(1000 x); the quotient by Markstein's sequence with the
+// correctly rounded reciprocal (q0 = k r, rem = fma(-q0, 1000, k), q = fma(rem, r, q0)): equal to the float32 division
+// k / 1000.0f for every |k| <= 32 767 (exhaustive host test, tests/test_grid_key.py).  Equal keys <=> equal samples among
+// the samples that pass: the integer keys order and tie exactly as the floats do.
+__device__ __forceinline__ bool grid_key(float x, int& k) {
+  const float t = __builtin_rintf(__fmul_rn(x, 1000.0f));
+  const float r = 1.0e-3f;
+  const float q0 = __fmul_rn(t, r);
+  const float rem = __fmaf_rn(-q0, 1000.0f, t);
+  const float q = __fmaf_rn(rem, r, q0);
+  k = (int)t;                                          // (v_cvt_i32_f32 saturates; a value off the grid is never used as a key)
+  return q == x && __builtin_fabsf(t) <= 32767.0f;
+}
+
 // `phases` odd-even transposition phases over the R x LG keys of every group of the wave (blocked layout): enough to
 // sort a sequence whose elements are at most phases - 1 places from home
 template <int R, int LG>
@@ -319,6 +334,18 @@ void rank_hist_kernel(RankStatsArgs args) {
       }
     }
 #endif
+    // WIDE, float32: are S's samples on the milli-unit grid?  Then Q's ties are counted by value (direct-address counters, as
+    // for int16 input) instead of through the multiset hash, as long as Q's samples are on the grid too (checked as they stream)
+    bool s_grid = false;
+    if constexpr (WIDE && DTYPE == 0) {
+      bool okl = true;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { int k; const bool ok = grid_key(x[r], k); okl = okl && (ok || r * 64 + lane >= m); }
+      s_grid = __ballot(!okl) == 0ull && m > 0;
+#if defined(NMOD_NO_GRID)
+      s_grid = false;
+#endif
+    }
 #if !(NMOD_SKIP & 16)
     if constexpr (PACKED) {
       // (packed_sort_i16.hpp; the top C - m keys of the position are its pads: a sample may equal the pad value 32767,
@@ -383,46 +410,74 @@ void rank_hist_kernel(RankStatsArgs args) {
 
     unsigned ppq = 0;                              // WIDE: ties inside Q from the hash table
     double s1w = 0.0, s2w = 0.0;                   // WIDE: Q's shifted moment sums
-    if constexpr (WIDE && DTYPE == 1) {
-      // int16 samples: the ties inside Q from direct-address counts.  The wave's table holds one 8-bit counter per VALUE
-      // of a window of the milli-unit domain (four per 32-bit word: 8 192 values in 8 KB): one returning LDS add per
-      // sample gives the number of earlier copies of its value, p - 1 — no hashing, no walks, one round trip.  The
-      // window is centred on the median of S (the two groups are reads of one position: real events spread a few hundred
-      // milli-units around their level).  A position with a sample of Q outside the window, or with a value that occurs
-      // 256 times (the counter wraps into its neighbour), is counted again after the pass, see below.
+    // WIDE: the direct-address tie counters (int16 input, and float32 input on the milli-unit grid).  The wave's table holds
+    // one 8-bit counter per VALUE of a window of the milli-unit domain (four per 32-bit word): one returning LDS add per
+    // sample gives the number of earlier copies of its value, p - 1 — no hashing, no walks, one round trip.
+    unsigned long long redo = 0ull;                                          // lanes that saw a counter at 255 or a sample outside
+    [[maybe_unused]] auto count_many = [&](auto cb_tag, auto nv_tag, const int* iv, const bool* have, int base) {
+      constexpr int BITS = decltype(cb_tag)::value, NV = decltype(nv_tag)::value;
+      constexpr int PW_LOG = (BITS == 16) ? 1 : 2;
       unsigned* ht = reinterpret_cast<unsigned*>(keys) + BIN_WORDS;
+      unsigned old[NV], sh[NV];
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        const unsigned u = (unsigned)(iv[e] - base);
+        const bool in = u < ((unsigned)wslots << PW_LOG);
+        sh[e] = (u & ((1u << PW_LOG) - 1u)) * (unsigned)BITS;
+        old[e] = 0u;
+#if !(NMOD_SKIP & 128)
+        if (have[e] && in) old[e] = atomicAdd(&ht[u >> PW_LOG], 1u << sh[e]);
+#endif
+        if constexpr (BITS == 8) redo |= __ballot(have[e] && !in);
+      }
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        const unsigned c = (old[e] >> sh[e]) & ((1u << BITS) - 1u);        // earlier copies of the value: p - 1
+        ppq += __umul24(c, c) + c;                                          // p (p - 1)
+        if constexpr (BITS == 8) redo |= __ballot(c == 255u);               // the add wrapped the counter into its neighbour
+      }
+    };
+    [[maybe_unused]] auto clear_table = [&]() {
+      unsigned* ht = reinterpret_cast<unsigned*>(keys) + BIN_WORDS;
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < wslots / 4; i += 64) reinterpret_cast<uint4*>(ht)[i] = make_uint4(0u, 0u, 0u, 0u);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+    // The exceptions — a sample outside the window (a range beyond 8 units, or groups far apart), or 256 samples of one
+    // value (a constant stretch of signal): the counts are void.  The ties of the position are counted again the plain
+    // way: min and max of Q, then one pass per window of [min, max] with 16-bit counters, one sample per lane and trip.
+    // key_at(i, have): the integer key of sample i of Q.
+    [[maybe_unused]] auto recount16 = [&](auto key_at) {
+      ppq = 0u;
+      int lo = 32767, hi = -32768;
+#pragma unroll 1
+      for (int i0 = 0; i0 < q; i0 += 64) {
+        const int v = key_at(min(i0 + lane, q - 1), true);                   // (a sample read twice changes neither)
+        lo = min(lo, v); hi = max(hi, v);
+      }
+      const int vmax = (int)wave_max_u32((unsigned)(hi + 32768)) - 32768;
+      const int vmin = 32767 - (int)wave_max_u32((unsigned)(32767 - lo));
+      const int np16 = (vmax - vmin) / (2 * wslots) + 1;                      // two 16-bit counters per word
+#pragma unroll 1
+      for (int pass = 0; pass < np16; ++pass) {
+        const int base = vmin + pass * (2 * wslots);
+        clear_table();
+#pragma unroll 1
+        for (int i0 = 0; i0 < q; i0 += 64) {
+          const bool hv[1] = {i0 + lane < q};
+          const int iv1[1] = {key_at(i0 + lane, hv[0])};
+          count_many(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{}, iv1, hv, base);
+        }
+      }
+    };
+    if constexpr (WIDE && DTYPE == 1) {
+      // int16 samples.  The window is centred on the median of S (the two groups are reads of one position: real events
+      // spread a few hundred milli-units around their level).  A position with a sample of Q outside the window, or with a
+      // value that occurs 256 times (the counter wraps into its neighbour), is counted again after the pass (recount16).
       const int wb = (int)keys[Lay::word(m > 0 ? (m >> 1) : 0)] - 2 * wslots;   // four values per word (m = 0: key 0 is the +inf pad -> any window)
       const int kq = (q > 0) ? (int)rk : 0;                                 // shift of Q's moment sums
       int s1i = 0; long long s2i = 0;                                        // sum (x - kq), sum (x - kq)^2: exact integers
-      unsigned long long redo = 0ull;                                        // lanes that saw a counter at 255 or a sample outside
-      auto count_many = [&](auto cb_tag, auto nv_tag, const int* iv, const bool* have, int base) {
-        constexpr int BITS = decltype(cb_tag)::value, NV = decltype(nv_tag)::value;
-        constexpr int PW_LOG = (BITS == 16) ? 1 : 2;
-        unsigned old[NV], sh[NV];
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          const unsigned u = (unsigned)(iv[e] - base);
-          const bool in = u < ((unsigned)wslots << PW_LOG);
-          sh[e] = (u & ((1u << PW_LOG) - 1u)) * (unsigned)BITS;
-          old[e] = 0u;
-#if !(NMOD_SKIP & 128)
-          if (have[e] && in) old[e] = atomicAdd(&ht[u >> PW_LOG], 1u << sh[e]);
-#endif
-          if constexpr (BITS == 8) redo |= __ballot(have[e] && !in);
-        }
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          const unsigned c = (old[e] >> sh[e]) & ((1u << BITS) - 1u);      // earlier copies of the value: p - 1
-          ppq += __umul24(c, c) + c;                                        // p (p - 1)
-          if constexpr (BITS == 8) redo |= __ballot(c == 255u);             // the add wrapped the counter into its neighbour
-        }
-      };
-      auto clear_table = [&]() {
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < wslots / 4; i += 64) reinterpret_cast<uint4*>(ht)[i] = make_uint4(0u, 0u, 0u, 0u);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      };
       clear_table();
       __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll 1
@@ -459,33 +514,7 @@ void rank_hist_kernel(RankStatsArgs args) {
         s1i += d; s2i += (long long)d * (long long)d;
         count_many(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, iv1, hv, wb);
       }
-      // The exceptions — a sample outside the window (a range beyond 8 units, or groups far apart), or 256 samples of
-      // one value (a constant stretch of signal): the counts are void.  The ties of the position are counted again the
-      // plain way: min and max of Q, then one pass per window of [min, max] with 16-bit counters, one sample per lane
-      // and trip.
-      if (redo != 0ull) {
-        ppq = 0u;
-        int lo = 32767, hi = -32768;
-#pragma unroll 1
-        for (int i0 = 0; i0 < q; i0 += 64) {
-          const int v = (int)load_q1(sig_q, off_q, min(i0 + lane, q - 1), true);   // (a sample read twice changes neither)
-          lo = min(lo, v); hi = max(hi, v);
-        }
-        const int vmax = (int)wave_max_u32((unsigned)(hi + 32768)) - 32768;
-        const int vmin = 32767 - (int)wave_max_u32((unsigned)(32767 - lo));
-        const int np16 = (vmax - vmin) / (2 * wslots) + 1;                    // two 16-bit counters per word
-#pragma unroll 1
-        for (int pass = 0; pass < np16; ++pass) {
-          const int base = vmin + pass * (2 * wslots);
-          clear_table();
-#pragma unroll 1
-          for (int i0 = 0; i0 < q; i0 += 64) {
-            const bool hv[1] = {i0 + lane < q};
-            const int iv1[1] = {(int)load_q1(sig_q, off_q, i0 + lane, hv[0])};
-            count_many(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{}, iv1, hv, base);
-          }
-        }
-      }
+      if (redo != 0ull) recount16([&](int i, bool have) { return (int)load_q1(sig_q, off_q, i, have); });
       // exact sums to doubles (|s1| < 2^23 and s2 < 2^39 per lane): the common moments code below reduces them
       s1w = (double)s1i; s2w = (double)s2i;
     } else if constexpr (WIDE) {
@@ -567,15 +596,18 @@ void rank_hist_kernel(RankStatsArgs args) {
           }
         }
       };
+      // the hash passes over Q; rank_first: the first pass also ranks the samples and sums their moments (false when the grid
+      // mode below has done that already and only the ties are counted again)
+      auto hash_passes = [&](bool rank_first) {
 #pragma unroll 1
       for (int pass = 0; pass < wide_passes; ++pass) {
-        const bool first = pass == 0;                // the pass that also ranks the samples and sums their moments
+        const bool first = rank_first && pass == 0;
         __builtin_amdgcn_wave_barrier();
 #if !(NMOD_SKIP & 256)
         for (int i = lane; i < wslots / 4; i += 64)
           reinterpret_cast<uint4*>(ht)[i] = make_uint4(kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty);
 #endif
-        if (!first) {
+        if (!(rank_first && pass == 0)) {             // (Q streams again: the requests of the item's head have been consumed)
           ra = load_q4(sig_q, off_q, 4 * gl, 0 < full);
           rt = load_q1(sig_q, off_q, full * (4 * LG) + gl, full * (4 * LG) + gl < q);
         }
@@ -618,6 +650,61 @@ void rank_hist_kernel(RankStatsArgs args) {
           insert_many(std::integral_constant<int, 1>{}, xq1, hv, pass);
         }
         if (lcnt > 0) drain(lcnt);                   // what is still deferred belongs to this pass's half of the values
+      }
+      };
+      if (!s_grid) {
+        hash_passes(true);
+      } else {
+        // ---- S is on the milli-unit grid: rank and sum the moments as above, count Q's ties by VALUE with the direct-address
+        // counters of the int16 form (window of 4 x wslots >= 8 192 values centred on the median of S) — as long as every
+        // sample of Q is on the grid too
+        const int wb = (int)__builtin_rintf(__fmul_rn(keys[Lay::word(m >> 1)], 1000.0f)) - 2 * wslots;
+        bool offl = false;                            // this lane saw a sample of Q off the grid
+        clear_table();
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll 1
+        for (int c = 0; c < full_w; ++c) {
+          const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
+          const float xa[4] = {ra.x, ra.y, ra.z, ra.w};
+          unsigned ad[4];
+#if !(NMOD_SKIP & 512)
+          rank_many(std::integral_constant<int, 4>{}, xa, true, ad);
+#endif
+          int iv[4]; bool hv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const double d = (double)xa[e] - KQ; s1w += d; s2w = __fma_rn(d, d, s2w);
+            hv[e] = grid_key(xa[e], iv[e]);
+            offl = offl || !hv[e];
+          }
+          count_many(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{}, iv, hv, wb);
+          ra = rb;
+        }
+#pragma unroll 1
+        for (int c = 0; c < tail_w; ++c) {
+          const int idx_now = full * (4 * LG) + c * LG + gl;
+          const bool have = idx_now < q;
+          const float xq1[1] = {have ? (float)rt : big};
+          const int idx = full * (4 * LG) + (c + 1) * LG + gl;
+          rt = load_q1(sig_q, off_q, idx, idx < q);
+          unsigned a1[1];
+#if !(NMOD_SKIP & 512)
+          rank_many(std::integral_constant<int, 1>{}, xq1, have, a1);
+#endif
+          const double d = (double)(have ? xq1[0] : kqf) - KQ;
+          s1w += d; s2w = __fma_rn(d, d, s2w);
+          int iv1[1];
+          const bool ok = grid_key(xq1[0], iv1[0]);
+          offl = offl || (have && !ok);
+          const bool hv[1] = {have && ok};
+          count_many(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, iv1, hv, wb);
+        }
+        if (__ballot(offl) != 0ull) {                 // Q has samples off the grid: its ties through the hash after all
+          ppq = 0u;
+          hash_passes(false);
+        } else if (redo != 0ull) {
+          recount16([&](int i, bool have) { int k; grid_key((float)load_q1(sig_q, off_q, i, have), k); return k; });
+        }
       }
     } else {
     __builtin_amdgcn_s_waitcnt(0x0F70);            // everything requested before the sort has arrived

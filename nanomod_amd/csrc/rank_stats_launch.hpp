@@ -48,7 +48,7 @@ inline bool wide_class(int cls) {
 // 32-bit words of a wave's tie table in the WIDE form (rank_hist.hpp).  int16: direct-address counters over a window of the
 // value domain, NMOD_WIDE_I16_WORDS words for every class.  float32: the multiset hash table; its slots in use are the
 // largest prime below the words (double hashing with any step then visits every slot), sized by the class of the larger
-// group: Q <= 512: 1 024 words (1 021 slots); Q <= 1 024: 2 048 (2 039; four blocks per CU — 1 600 words = five blocks
+// group: Q <= 1 024: 2 048 (2 039; four blocks per CU — 1 600 words = five blocks
 // measured no faster); Q <= 2 048: 3 068 (3 067, load <= 0.67: THREE blocks per CU instead of the two of 4 096 words,
 // +5 % on configs[4]); the two-pass classes (Q <= 4 096, split by a hash bit): 4 100 (4 099: a pass may receive every sample).
 #ifndef NMOD_WIDE_I16_WORDS
@@ -63,7 +63,7 @@ __host__ __device__ constexpr int wide_table_words(int cls, int dtype) {
   if (cls >= kWideBigBase) return 4100;            // (one pass may receive all 4 096 samples: every sample one value)
   const int c0 = cls / kNumSizeClasses, c1 = cls % kNumSizeClasses;
   const int cq = c0 < c1 ? c1 : c0;
-  return cq <= 3 ? 1024 : (cq == 4 ? 2048 : 3068);
+  return cq <= 4 ? 2048 : 3068;                  // (Q <= 512 took 1 024 words: the grid mode's window is four values per word, 8 192 at least)
 }
 __host__ __device__ constexpr int wide_table_slots(int words) {
   switch (words) {
@@ -80,7 +80,7 @@ __host__ __device__ constexpr int wide_table_slots(int words) {
   }
 }
 // (a table never fills: a class's slots hold every sample the larger group can have, even when all are one value)
-static_assert(wide_table_slots(wide_table_words(0 * kNumSizeClasses + 3, 0)) >= 512 && wide_table_slots(wide_table_words(0 * kNumSizeClasses + 4, 0)) >= 1024 &&
+static_assert(wide_table_slots(wide_table_words(0 * kNumSizeClasses + 3, 0)) >= 512 && wide_table_words(0, 0) * 4 >= 8192 && wide_table_slots(wide_table_words(0 * kNumSizeClasses + 4, 0)) >= 1024 &&
               wide_table_slots(wide_table_words(0 * kNumSizeClasses + 5, 0)) >= 2048 && wide_table_slots(wide_table_words(kWideBigBase, 0)) >= kWideBigMaxQ, "tie table sizes");
 inline int wide_class_of_s(int cls) {              // capacity class of the smaller group of a WIDE class
   if (cls >= kWideBigBase) return cls - kWideBigBase;

@@ -384,7 +384,8 @@ def test_ks_only_large_ranked_group(nm):
         assert abs(got['ks_d'][i] - d) <= 0.0 and abs(got['ks_p'][i] - max(p, orc.DBL_MIN)) <= 1e-9 * max(p, orc.DBL_MIN), i
 
 
-@pytest.mark.parametrize('mode', ['cont', 'grid1', 'const', 'i16', 'i16const', 'i16span', 'i16heavy', 'f64', 'f64ties'])
+@pytest.mark.parametrize('mode', ['cont', 'grid1', 'const', 'i16', 'i16const', 'i16span', 'i16heavy', 'f64', 'f64ties',
+                                  'g32', 'g32span', 'g32heavy', 'g32mixed'])
 def test_unequal_classes_streamed_larger_group(nm, mode):
     """positions whose groups fall in different capacity classes with the smaller one <= 256 samples: the WIDE form of
     rank_hist_kernel (smaller group sorted, larger one streamed and counted in a per-wave hash table), the larger group up
@@ -393,7 +394,10 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
     and the sum of t^3 - t pass 2^32).  int16 input counts the ties of the larger group in direct-address 8-bit counters
     over a window of the value domain: `i16const` (hundreds of equal samples: the counters overflow and the position is
     recounted with 16-bit ones), `i16span` (values over the whole int16 range: one pass per window), `i16heavy` (a
-    heavy value of 255 / 256 / 257 copies among spread ones: the edge of the overflow test)"""
+    heavy value of 255 / 256 / 257 copies among spread ones: the edge of the overflow test).  float32 input whose smaller
+    group is on the milli-unit grid of real events takes the same counters (rank_hist.hpp: grid_key) while the larger
+    group's samples are on the grid too: `g32` (3-decimal values), `g32span` / `g32heavy` (the recount paths), `g32mixed`
+    (samples off the grid, one ulp beside it, or beyond +-32.767 in either group: back to the hash, mid-position)"""
     import nanomod_oracle as orc
     rng = np.random.default_rng(zlib.crc32(mode.encode()))
     sizes = [(50, 1000), (1000, 50), (3, 130), (64, 65), (65, 2048), (130, 700), (256, 2048), (256, 4096), (4096, 256),
@@ -403,12 +407,14 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
         x = rng.normal(0, 1, a); y = rng.normal(0.3 if i % 2 else 0.0, 1.2, b)
         if mode == 'grid1':
             x, y = np.round(x, 1), np.round(y, 1)
-        elif mode == 'i16span':
+        elif mode in ('g32', 'g32mixed'):
+            x, y = np.round(x, 3), np.round(y, 3)
+        elif mode in ('i16span', 'g32span'):
             x = rng.integers(-32768, 32768, a) / 1000.0; y = rng.integers(-32768, 32768, b) / 1000.0
             y[::5] = y[0]; x[::4] = y[1 % b]
             if i % 4 == 0:
                 y[:] = np.where(rng.random(b) < 0.5, -32.768, 32.767)   # the two ends of the domain only
-        elif mode == 'i16heavy':
+        elif mode in ('i16heavy', 'g32heavy'):
             big, small = (x, y) if a > b else (y, x)
             k = (255, 256, 257)[i % 3]
             if len(big) > k:
@@ -436,7 +442,21 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
             sig1[k:2 * k:7] = sig0[k:2 * k:7]
         r0, r1 = sig0, sig1
     else:
-        sig0 = np.concatenate(ca).astype(np.float32); sig1 = np.concatenate(cb).astype(np.float32); r0, r1 = sig0, sig1
+        sig0 = np.concatenate(ca).astype(np.float32); sig1 = np.concatenate(cb).astype(np.float32)
+        if mode == 'g32mixed':
+            for i, (a, b) in enumerate(sizes):
+                big_, ob = (sig0, off0) if a > b else (sig1, off1)          # the streamed group of position i
+                sm_, os_ = (sig1, off1) if a > b else (sig0, off0)
+                j = int(ob[i]) + (7 * i) % max(a, b)
+                if i % 4 == 0:
+                    big_[j] = np.nextafter(big_[j], np.float32(9))          # one ulp beside a grid value: ties with nothing
+                    if j + 1 < ob[i + 1]:
+                        big_[j + 1] = big_[j]                               # ... except its own copy
+                elif i % 4 == 1:
+                    big_[j] = np.float32(40.0)                              # on the 3-decimal grid but beyond int16 milli-units
+                elif i % 4 == 2:
+                    sm_[int(os_[i])] = np.float32(0.1234567)                # the sorted group off the grid: the hash from the start
+        r0, r1 = sig0, sig1
     got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=1, weights_dif=2.0, method='fisher')
     exp = orc.detect_batch(r0, off0, r1, off1, rid, 1, 2.0, orc.METHOD_FISHER)
     ident = (exp['status'] & 1) != 0                  # all samples identical: U / p NaN on both sides

@@ -510,9 +510,12 @@ def main():
             else:
                 det.synth_fill(tgt, SEED, b['lo_h'], b['n'], g, (n0, n1)[g], PLANT_PERIOD, PLANT_SHIFT)
             if grid:
-                step = 1 << 28
+                # k / 1000 as a 3-decimal event value is stored: the float64 quotient (a tensor divisor: torch multiplies by the
+                # reciprocal of a Python scalar, which is not the correctly rounded quotient), then rounded to float32
+                step = 1 << 27
+                thousand = torch.full((), 1000.0, dtype=torch.float64, device=dev)
                 for lo in range(0, dst.numel(), step):
-                    dst[lo:lo + step] = tgt[lo:lo + step].to(torch.float32) / 1000.0
+                    dst[lo:lo + step] = torch.div(tgt[lo:lo + step].to(torch.float64), thousand).to(torch.float32)
                 del tgt
 
     # this rank's blocks (+ halo)

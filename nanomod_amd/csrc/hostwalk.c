@@ -8,6 +8,8 @@
  *   flatten(rows, out) -> number of values written
  *     rows: list or tuple of per-position sequences (ndarray, list, tuple, ...)
  *     out:  writable C-contiguous float64 buffer with room for all of them (ValueError otherwise)
+ *   filter_coverage(norm, base, min_cov), join_strand(norm0, norm1, base0, base1): mfilter_coverage's inner loop and
+ *     mtest2's loop header for one (chrom, strand), one C pass over the dicts each (see below)
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
@@ -79,8 +81,166 @@ fail:
   return NULL;
 }
 
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The reference's per-strand structure: dict[pos] -> row for each dataset, dict[pos] -> base beside it
+ * (myDetect.py:569-572).  Both functions below read the dicts in STORAGE order with PyDict_Next — sequential memory, no
+ * hashing; the reference fills them position by position, so storage order is ascending position for any real input
+ * (checked; anything else is sorted first).
+ */
+static Py_ssize_t row_len(PyObject* row) {
+  if (PyList_CheckExact(row)) return PyList_GET_SIZE(row);
+  if (PyTuple_CheckExact(row)) return PyTuple_GET_SIZE(row);
+  if (PyArray_Check(row)) {
+    PyArrayObject* a = (PyArrayObject*)row;
+    if (PyArray_NDIM(a) != 1) { PyErr_SetString(PyExc_ValueError, "every per-position row must be one-dimensional"); return -1; }
+    return (Py_ssize_t)PyArray_DIM(a, 0);
+  }
+  return PyObject_Length(row);
+}
+
+/* filter_coverage(norm, base, min_cov) -> number of positions deleted.  mfilter_coverage's inner loop
+ * (myDetect.py:304-309) for one (chrom, strand): positions with fewer than min_cov samples leave both dicts. */
+static PyObject* filter_coverage(PyObject* self, PyObject* args) {
+  PyObject *norm, *base; long long min_cov;
+  (void)self;
+  if (!PyArg_ParseTuple(args, "O!O!L", &PyDict_Type, &norm, &PyDict_Type, &base, &min_cov)) return NULL;
+  Py_ssize_t it = 0, ndel = 0, cap = 0;
+  PyObject *k, *v, **dead = NULL;
+  while (PyDict_Next(norm, &it, &k, &v)) {
+    const Py_ssize_t n = row_len(v);
+    if (n < 0) { free(dead); return NULL; }
+    if (n < min_cov) {
+      if (ndel == cap) { cap = cap ? 2 * cap : 1024; PyObject** nd = (PyObject**)realloc(dead, (size_t)cap * sizeof(*dead)); if (!nd) { free(dead); return PyErr_NoMemory(); } dead = nd; }
+      Py_INCREF(k); dead[ndel++] = k;
+    }
+  }
+  int failed = 0;
+  for (Py_ssize_t i = 0; i < ndel; ++i) {
+    if (!failed && (PyDict_DelItem(norm, dead[i]) < 0 || PyDict_DelItem(base, dead[i]) < 0)) failed = 1;    /* KeyError on base: as the reference's del */
+    Py_DECREF(dead[i]);
+  }
+  free(dead);
+  if (failed) return NULL;
+  return PyLong_FromSsize_t(ndel);
+}
+
+typedef struct { long long pos; PyObject* row; } ent_t;
+static int ent_cmp(const void* a, const void* b) {
+  const long long x = ((const ent_t*)a)->pos, y = ((const ent_t*)b)->pos;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+/* the (position, value) pairs of a dict, ascending by position; NULL + exception on a key that is not an integer */
+static ent_t* dict_entries(PyObject* d, Py_ssize_t* n_out) {
+  const Py_ssize_t n = PyDict_Size(d);
+  ent_t* e = (ent_t*)malloc((size_t)(n ? n : 1) * sizeof(ent_t));
+  if (!e) { PyErr_NoMemory(); return NULL; }
+  Py_ssize_t it = 0, i = 0;
+  PyObject *k, *v;
+  int sorted = 1;
+  while (PyDict_Next(d, &it, &k, &v)) {
+    long long p;
+    if (PyLong_CheckExact(k)) p = PyLong_AsLongLong(k);
+    else { PyObject* ix = PyNumber_Index(k); if (!ix) { free(e); return NULL; } p = PyLong_AsLongLong(ix); Py_DECREF(ix); }
+    if (p == -1 && PyErr_Occurred()) { free(e); return NULL; }
+    if (i > 0 && p <= e[i - 1].pos) sorted = 0;
+    e[i].pos = p; e[i].row = v; ++i;
+  }
+  if (!sorted) qsort(e, (size_t)i, sizeof(ent_t), ent_cmp);
+  *n_out = i;
+  return e;
+}
+
+static int copy_row(PyObject* row, double* dst, Py_ssize_t n) {
+  if (PyArray_Check(row) && PyArray_TYPE((PyArrayObject*)row) == NPY_DOUBLE && PyArray_IS_C_CONTIGUOUS((PyArrayObject*)row)) {
+    memcpy(dst, PyArray_DATA((PyArrayObject*)row), (size_t)n * 8);
+    return 0;
+  }
+  Py_ssize_t wrote = 0;
+  if (put_generic(row, dst, n, &wrote) < 0) return -1;
+  if (wrote != n) { PyErr_SetString(PyExc_ValueError, "a position changed its number of samples while it was read"); return -1; }
+  return 0;
+}
+
+/* join_strand(norm0, norm1, base0, base1) -> (pos int64[n], n0 int32[n], n1 int32[n], sig0 float64[sum n0], sig1 float64[sum n1],
+ *                                             bases list[n] (group 2's, as mtest2 records them), mismatch list of indices)
+ * The loop header of mtest2 for one (chrom, strand) (myDetect.py:427-436): the positions both datasets hold, ascending, their
+ * rows flattened into two CSR sample arrays, and the indices where the two datasets disagree about the base (:432-434). */
+static PyObject* join_strand(PyObject* self, PyObject* args) {
+  PyObject *d0, *d1, *b0, *b1;
+  (void)self;
+  if (!PyArg_ParseTuple(args, "O!O!O!O!", &PyDict_Type, &d0, &PyDict_Type, &d1, &PyDict_Type, &b0, &PyDict_Type, &b1)) return NULL;
+  Py_ssize_t m0 = 0, m1 = 0, mb0 = 0, mb1 = 0;
+  ent_t *e0 = NULL, *e1 = NULL, *eb0 = NULL, *eb1 = NULL;
+  PyObject *pos_a = NULL, *n0_a = NULL, *n1_a = NULL, *s0_a = NULL, *s1_a = NULL, *bases = NULL, *mism = NULL, *ret = NULL;
+  Py_ssize_t *i0 = NULL, *i1 = NULL;
+  if (!(e0 = dict_entries(d0, &m0)) || !(e1 = dict_entries(d1, &m1)) || !(eb0 = dict_entries(b0, &mb0)) || !(eb1 = dict_entries(b1, &mb1))) goto done;
+  /* merge join of the two ascending position lists */
+  const Py_ssize_t cap = m0 < m1 ? m0 : m1;
+  i0 = (Py_ssize_t*)malloc((size_t)(cap ? cap : 1) * sizeof(Py_ssize_t)); i1 = (Py_ssize_t*)malloc((size_t)(cap ? cap : 1) * sizeof(Py_ssize_t));
+  if (!i0 || !i1) { PyErr_NoMemory(); goto done; }
+  Py_ssize_t n = 0;
+  for (Py_ssize_t a = 0, b = 0; a < m0 && b < m1;) {
+    if (e0[a].pos < e1[b].pos) ++a;
+    else if (e0[a].pos > e1[b].pos) ++b;
+    else { i0[n] = a; i1[n] = b; ++n; ++a; ++b; }
+  }
+  npy_intp dn = (npy_intp)n;
+  pos_a = PyArray_SimpleNew(1, &dn, NPY_INT64); n0_a = PyArray_SimpleNew(1, &dn, NPY_INT32); n1_a = PyArray_SimpleNew(1, &dn, NPY_INT32);
+  bases = PyList_New(n); mism = PyList_New(0);
+  if (!pos_a || !n0_a || !n1_a || !bases || !mism) goto done;
+  long long* pos = (long long*)PyArray_DATA((PyArrayObject*)pos_a);
+  int* n0 = (int*)PyArray_DATA((PyArrayObject*)n0_a); int* n1 = (int*)PyArray_DATA((PyArrayObject*)n1_a);
+  long long t0 = 0, t1 = 0;
+  Py_ssize_t jb0 = 0, jb1 = 0;                           /* cursors into the base dicts (the same ascending positions in any real input) */
+  for (Py_ssize_t j = 0; j < n; ++j) {
+    if (j + 8 < n) { __builtin_prefetch(e0[i0[j + 8]].row); __builtin_prefetch(e1[i1[j + 8]].row); }
+    const long long p = e0[i0[j]].pos;
+    const Py_ssize_t l0 = row_len(e0[i0[j]].row), l1 = row_len(e1[i1[j]].row);
+    if (l0 < 0 || l1 < 0) goto done;
+    if (l0 > 2147483647 || l1 > 2147483647) { PyErr_SetString(PyExc_OverflowError, "a position holds more than 2^31 samples"); goto done; }
+    pos[j] = p; n0[j] = (int)l0; n1[j] = (int)l1; t0 += l0; t1 += l1;
+    while (jb0 < mb0 && eb0[jb0].pos < p) ++jb0;
+    while (jb1 < mb1 && eb1[jb1].pos < p) ++jb1;
+    if (jb0 >= mb0 || eb0[jb0].pos != p || jb1 >= mb1 || eb1[jb1].pos != p) { PyObject* kp = PyLong_FromLongLong(p); if (kp) { PyErr_SetObject(PyExc_KeyError, kp); Py_DECREF(kp); } goto done; }   /* as base[sk][pk] would */
+    PyObject *x0 = eb0[jb0].row, *x1 = eb1[jb1].row;
+    Py_INCREF(x1); PyList_SET_ITEM(bases, j, x1);
+    if (x0 != x1) {
+      const int eq = PyObject_RichCompareBool(x1, x0, Py_EQ);
+      if (eq < 0) goto done;
+      if (!eq) { PyObject* ix = PyLong_FromSsize_t(j); if (!ix || PyList_Append(mism, ix) < 0) { Py_XDECREF(ix); goto done; } Py_DECREF(ix); }
+    }
+  }
+  npy_intp d0n = (npy_intp)t0, d1n = (npy_intp)t1;
+  s0_a = PyArray_SimpleNew(1, &d0n, NPY_DOUBLE); s1_a = PyArray_SimpleNew(1, &d1n, NPY_DOUBLE);
+  if (!s0_a || !s1_a) goto done;
+  double* s0 = (double*)PyArray_DATA((PyArrayObject*)s0_a); double* s1 = (double*)PyArray_DATA((PyArrayObject*)s1_a);
+  for (int g = 0; g < 2; ++g) {                          /* one group after the other: each pass streams its own rows */
+    double* dst = g ? s1 : s0;
+    const ent_t* e = g ? e1 : e0; const Py_ssize_t* ix = g ? i1 : i0; const int* nn = g ? n1 : n0;
+    long long at = 0;
+    for (Py_ssize_t j = 0; j < n; ++j) {
+      if (j + 16 < n) __builtin_prefetch(e[ix[j + 16]].row);
+      if (j + 8 < n) {
+        PyObject* o = e[ix[j + 8]].row;
+        if (PyList_CheckExact(o)) __builtin_prefetch(((PyListObject*)o)->ob_item);
+        else if (PyArray_Check(o)) __builtin_prefetch(PyArray_DATA((PyArrayObject*)o));
+      }
+      if (copy_row(e[ix[j]].row, dst + at, nn[j]) < 0) goto done;
+      at += nn[j];
+    }
+  }
+  ret = PyTuple_Pack(7, pos_a, n0_a, n1_a, s0_a, s1_a, bases, mism);
+done:
+  free(e0); free(e1); free(eb0); free(eb1); free(i0); free(i1);
+  Py_XDECREF(pos_a); Py_XDECREF(n0_a); Py_XDECREF(n1_a); Py_XDECREF(s0_a); Py_XDECREF(s1_a); Py_XDECREF(bases); Py_XDECREF(mism);
+  return ret;
+}
+
 static PyMethodDef methods[] = {
   {"flatten", flatten, METH_VARARGS, "flatten(rows, out): copy the values of every row into the float64 buffer `out`, in order"},
+  {"filter_coverage", filter_coverage, METH_VARARGS, "filter_coverage(norm, base, min_cov): delete the positions with fewer than min_cov samples from both dicts"},
+  {"join_strand", join_strand, METH_VARARGS, "join_strand(norm0, norm1, base0, base1): positions of both datasets, ascending, as CSR arrays"},
   {NULL, NULL, 0, NULL}
 };
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_hostwalk", "host-side row flattening for detect.build_csr", -1, methods,

@@ -38,7 +38,7 @@ def test_shipped_binary_is_a_product_build():
     names = [p.split(':')[0] for p in parts[1:]]
     assert names == ['abi_tu', 'k1_f32_ks', 'k1_f32_all', 'k1_i16_ks', 'k1_i16_all']
     want = {'NMOD_SKIP': '0', 'NMOD_EXP': '0', 'NMOD_HIST_WAVES': '4', 'NMOD_WIDE_PROBES': '2', 'NMOD_WIDE_I16_WORDS': '2048',
-            'NMOD_SWZ_MASK': '0', 'NMOD_PK_SELECT': '0', 'NMOD_CE_BUILTIN': '0', 'NMOD_WIDE_POW2': '0', 'NMOD_XOR4_BANKS': '0'}
+            'NMOD_SWZ_MASK': '0', 'NMOD_PK_SELECT': '0', 'NMOD_CE_BUILTIN': '0', 'NMOD_WIDE_POW2': '0', 'NMOD_XOR4_BANKS': '0', 'NMOD_NO_GRID': '0'}
     for p in parts[1:]:
         got = dict(kv.split('=') for kv in p.split(': ', 1)[1].split())
         assert got == want, (p, got)
@@ -395,6 +395,74 @@ def test_hostwalk_flatten_equals_numpy():
         got.append((s0.copy(), o0.copy()))
         assert len(meta['pos']) == 300 and o0[-1] == 2700
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+
+
+def test_hostwalk_dict_walks_equal_the_python_loops(capsys, monkeypatch):
+    """csrc/hostwalk.c filter_coverage / join_strand (mfilter_coverage's inner loop, mtest2's loop header — myDetect.py:301-314,
+    427-436) against the plain-Python statements of the same loops: dicts filled in scrambled order, positions missing on
+    either side, rows as lists of numpy.float64 / arrays / tuples, base mismatches (printed like the reference), positions
+    below MinCoverage, a strand that only one dataset holds, numpy-integer position keys (the general path)."""
+    hw = pytest.importorskip('nanomod_amd._hostwalk', reason='make -C nanomod_amd/csrc')
+    import copy
+    import nanomod_amd.detect as D
+    rng = np.random.default_rng(12)
+
+    def dataset(seed, scramble, np_keys=False):
+        r = np.random.default_rng(seed)
+        ds = {'norm_mean': {}, 'base': {}, 'basedict': {}}
+        for sk in (('chr2', '-'), ('chr1', '+'), ('chr1', '-'), ('chrX', '+') if seed % 2 else ('chrY', '+')):
+            poss = np.unique(r.integers(0, 400, 250))
+            if scramble:
+                poss = r.permutation(poss)
+            nm_, bs = {}, {}
+            for p_ in poss.tolist():
+                n = int(r.integers(1, 12))
+                v = np.round(r.normal(0, 1, n), 3)
+                row = [np.float64(x) for x in v] if p_ % 3 == 0 else (tuple(v.tolist()) if p_ % 3 == 1 else v)
+                key = np.int64(p_) if np_keys else p_
+                nm_[key] = row
+                bs[key] = 'ACGT'[(p_ + (1 if (seed == 2 and p_ % 37 == 0) else 0)) % 4]
+            ds['norm_mean'][sk] = nm_; ds['base'][sk] = bs
+        return ds
+
+    def reference_way(mo):
+        mo = copy.deepcopy(mo)
+        monkeypatch.setattr(D, '_hostwalk_module', lambda: None)
+        D.mfilter_coverage(mo)
+        out = D.build_csr(mo)
+        monkeypatch.undo()
+        return mo, out
+
+    for scramble in (False, True):
+        for np_keys in (False, True):
+            mo = {'ds2': ['a', 'b'], 'a': dataset(1, scramble, np_keys), 'b': dataset(2, scramble, np_keys), 'MinCoverage': 4, 'outLevel': 3}
+            ref_mo, ref = reference_way(mo)
+            ref_print = capsys.readouterr().out
+            got_mo = copy.deepcopy(mo)
+            D.mfilter_coverage(got_mo)
+            for dsn in ('a', 'b'):                           # the same positions left, the same strands left
+                assert {sk: sorted(int(k) for k in d) for sk, d in got_mo[dsn]['norm_mean'].items()} == \
+                       {sk: sorted(int(k) for k in d) for sk, d in ref_mo[dsn]['norm_mean'].items()}
+                assert {sk: sorted(int(k) for k in d) for sk, d in got_mo[dsn]['base'].items()} == \
+                       {sk: sorted(int(k) for k in d) for sk, d in ref_mo[dsn]['base'].items()}
+            got = D.build_csr(got_mo)
+            assert capsys.readouterr().out == ref_print and 'Error not equal' in ref_print
+            for k in ('chrom', 'strand', 'pos', 'base', 'n0', 'n1', 'chrom_id'):
+                assert list(got[0][k]) == list(ref[0][k]), k
+            assert got[0]['names'] == ref[0]['names'] and len(got[0]['pos']) > 100
+            for a, b in zip(got[1:], ref[1:]):
+                assert a.dtype == b.dtype and np.array_equal(a, b)
+    # the C functions themselves: errors
+    with pytest.raises(TypeError):
+        hw.join_strand({'x': [1.0]}, {'x': [1.0]}, {'x': 'A'}, {'x': 'A'})
+    with pytest.raises(KeyError):
+        hw.join_strand({5: [1.0]}, {5: [1.0]}, {}, {5: 'A'})
+    with pytest.raises(ValueError):
+        hw.join_strand({5: np.zeros((2, 2))}, {5: [1.0]}, {5: 'A'}, {5: 'A'})
+    d, b = {1: [1.0, 2.0], 2: [1.0], 3: np.zeros(5)}, {1: 'A', 2: 'C', 3: 'G'}
+    assert hw.filter_coverage(d, b, 2) == 1 and sorted(d) == [1, 3] and sorted(b) == [1, 3]
+    p_, n0, n1, s0, s1, bases, mism = hw.join_strand({}, {}, {}, {})
+    assert len(p_) == 0 and len(s0) == 0 and bases == [] and mism == []
 
 
 def test_dispatch_forms_keep_16_keys_per_lane():

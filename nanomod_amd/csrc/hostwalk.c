@@ -163,7 +163,8 @@ static int copy_row(PyObject* row, double* dst, Py_ssize_t n) {
 }
 
 /* join_strand(norm0, norm1, base0, base1) -> (pos int64[n], n0 int32[n], n1 int32[n], sig0 float64[sum n0], sig1 float64[sum n1],
- *                                             bases list[n] (group 2's, as mtest2 records them), mismatch list of indices)
+ *                                             bases list[n] (group 2's, as mtest2 records them), mismatch list of indices,
+ *                                             base_codes uint32[n]: the code point of a one-character base, else 0)
  * The loop header of mtest2 for one (chrom, strand) (myDetect.py:427-436): the positions both datasets hold, ascending, their
  * rows flattened into two CSR sample arrays, and the indices where the two datasets disagree about the base (:432-434). */
 static PyObject* join_strand(PyObject* self, PyObject* args) {
@@ -172,7 +173,7 @@ static PyObject* join_strand(PyObject* self, PyObject* args) {
   if (!PyArg_ParseTuple(args, "O!O!O!O!", &PyDict_Type, &d0, &PyDict_Type, &d1, &PyDict_Type, &b0, &PyDict_Type, &b1)) return NULL;
   Py_ssize_t m0 = 0, m1 = 0, mb0 = 0, mb1 = 0;
   ent_t *e0 = NULL, *e1 = NULL, *eb0 = NULL, *eb1 = NULL;
-  PyObject *pos_a = NULL, *n0_a = NULL, *n1_a = NULL, *s0_a = NULL, *s1_a = NULL, *bases = NULL, *mism = NULL, *ret = NULL;
+  PyObject *pos_a = NULL, *n0_a = NULL, *n1_a = NULL, *s0_a = NULL, *s1_a = NULL, *bases = NULL, *mism = NULL, *ret = NULL, *codes_a = NULL;
   Py_ssize_t *i0 = NULL, *i1 = NULL;
   if (!(e0 = dict_entries(d0, &m0)) || !(e1 = dict_entries(d1, &m1)) || !(eb0 = dict_entries(b0, &mb0)) || !(eb1 = dict_entries(b1, &mb1))) goto done;
   /* merge join of the two ascending position lists */
@@ -187,8 +188,9 @@ static PyObject* join_strand(PyObject* self, PyObject* args) {
   }
   npy_intp dn = (npy_intp)n;
   pos_a = PyArray_SimpleNew(1, &dn, NPY_INT64); n0_a = PyArray_SimpleNew(1, &dn, NPY_INT32); n1_a = PyArray_SimpleNew(1, &dn, NPY_INT32);
-  bases = PyList_New(n); mism = PyList_New(0);
-  if (!pos_a || !n0_a || !n1_a || !bases || !mism) goto done;
+  bases = PyList_New(n); mism = PyList_New(0); codes_a = PyArray_SimpleNew(1, &dn, NPY_UINT32);
+  if (!pos_a || !n0_a || !n1_a || !bases || !mism || !codes_a) goto done;
+  npy_uint32* codes = (npy_uint32*)PyArray_DATA((PyArrayObject*)codes_a);
   long long* pos = (long long*)PyArray_DATA((PyArrayObject*)pos_a);
   int* n0 = (int*)PyArray_DATA((PyArrayObject*)n0_a); int* n1 = (int*)PyArray_DATA((PyArrayObject*)n1_a);
   long long t0 = 0, t1 = 0;
@@ -205,6 +207,7 @@ static PyObject* join_strand(PyObject* self, PyObject* args) {
     if (jb0 >= mb0 || eb0[jb0].pos != p || jb1 >= mb1 || eb1[jb1].pos != p) { PyObject* kp = PyLong_FromLongLong(p); if (kp) { PyErr_SetObject(PyExc_KeyError, kp); Py_DECREF(kp); } goto done; }   /* as base[sk][pk] would */
     PyObject *x0 = eb0[jb0].row, *x1 = eb1[jb1].row;
     Py_INCREF(x1); PyList_SET_ITEM(bases, j, x1);
+    codes[j] = (PyUnicode_CheckExact(x1) && PyUnicode_GET_LENGTH(x1) == 1) ? (npy_uint32)PyUnicode_READ_CHAR(x1, 0) : 0u;
     if (x0 != x1) {
       const int eq = PyObject_RichCompareBool(x1, x0, Py_EQ);
       if (eq < 0) goto done;
@@ -230,10 +233,10 @@ static PyObject* join_strand(PyObject* self, PyObject* args) {
       at += nn[j];
     }
   }
-  ret = PyTuple_Pack(7, pos_a, n0_a, n1_a, s0_a, s1_a, bases, mism);
+  ret = PyTuple_Pack(8, pos_a, n0_a, n1_a, s0_a, s1_a, bases, mism, codes_a);
 done:
   free(e0); free(e1); free(eb0); free(eb1); free(i0); free(i1);
-  Py_XDECREF(pos_a); Py_XDECREF(n0_a); Py_XDECREF(n1_a); Py_XDECREF(s0_a); Py_XDECREF(s1_a); Py_XDECREF(bases); Py_XDECREF(mism);
+  Py_XDECREF(pos_a); Py_XDECREF(n0_a); Py_XDECREF(n1_a); Py_XDECREF(s0_a); Py_XDECREF(s1_a); Py_XDECREF(bases); Py_XDECREF(mism); Py_XDECREF(codes_a);
   return ret;
 }
 

@@ -360,12 +360,12 @@ def build_csr(moptions):
             try:
                 # the loop header of mtest2 for this strand in one C pass: merge join of the two dicts read in storage
                 # order, rows flattened straight into the CSR arrays (csrc/hostwalk.c: join_strand)
-                p_, n0_, n1_, s0_, s1_, bases_, mism = hw.join_strand(d0, d1, b0, b1)
+                p_, n0_, n1_, s0_, s1_, bases_, mism, codes_ = hw.join_strand(d0, d1, b0, b1)
                 if mism and not quiet:
                     b0l = [b0[int(p_[j])] for j in mism]
                     for j, x0 in zip(mism, b0l):
                         print('Error not equal', sk, int(p_[j]), bases_[j], x0)
-                part = (p_, n0_, n1_, s0_, s1_, bases_)
+                part = (p_, n0_, n1_, s0_, s1_, bases_, codes_)
             except TypeError:                             # position keys that are not integers: the general way below
                 part = None
         if part is None:
@@ -389,9 +389,15 @@ def build_csr(moptions):
     names = sorted(set(chrom))
     ids = {c: i for i, c in enumerate(names)}
     counts = np.asarray(counts, dtype=np.int64)
-    base_arr = np.empty(npos, dtype=object)
-    base_arr[:] = base
-    meta = dict(chrom=np.repeat(np.array(chrom, dtype=object), counts), strand=np.repeat(np.array(strand, dtype=object), counts),
+    codes = [p[6] if len(p) > 6 else None for p in parts]
+    if parts and all(c is not None and (len(c) == 0 or int(c.min()) > 0) for c in codes):
+        # every base is a one-character string (what the reference stores): the code points ARE a '<U1' array, no copy
+        base_arr = (np.concatenate(codes) if len(codes) > 1 else codes[0]).view('<U1')
+    else:
+        base_arr = np.empty(npos, dtype=object)
+        base_arr[:] = base
+    as_text = lambda names_: np.array(names_) if all(isinstance(x, str) for x in names_) else np.array(names_, dtype=object)
+    meta = dict(chrom=np.repeat(as_text(chrom), counts), strand=np.repeat(as_text(strand), counts),
                 pos=np.asarray(pos, dtype=np.int64), base=base_arr, n0=np.asarray(n0, dtype=np.int32),
                 n1=np.asarray(n1, dtype=np.int32), names=names,
                 chrom_id=np.repeat(np.array([ids[c] for c in chrom], dtype=np.int32), counts))

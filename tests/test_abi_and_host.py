@@ -461,7 +461,7 @@ def test_hostwalk_dict_walks_equal_the_python_loops(capsys, monkeypatch):
         hw.join_strand({5: np.zeros((2, 2))}, {5: [1.0]}, {5: 'A'}, {5: 'A'})
     d, b = {1: [1.0, 2.0], 2: [1.0], 3: np.zeros(5)}, {1: 'A', 2: 'C', 3: 'G'}
     assert hw.filter_coverage(d, b, 2) == 1 and sorted(d) == [1, 3] and sorted(b) == [1, 3]
-    p_, n0, n1, s0, s1, bases, mism = hw.join_strand({}, {}, {}, {})
+    p_, n0, n1, s0, s1, bases, mism, codes = hw.join_strand({}, {}, {}, {})
     assert len(p_) == 0 and len(s0) == 0 and bases == [] and mism == []
 
 

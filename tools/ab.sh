@@ -7,7 +7,7 @@ cd /tmp; export TMPDIR=/tmp
 for lib in "$@"; do
   export NMOD_HIP_LIB=$R/$lib
   D=/tmp/ab_$(basename $lib .so); rm -rf $D
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --output-format csv -d $D -- python3 $R/bench.py $ARGS --steps 2 --warmup 1 --no-cpu --no-real-ties > /dev/null 2> $D.err
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --output-format csv -d $D -- python3 $R/bench.py $ARGS --steps 2 --warmup 1 --no-cpu --no-side --no-host-path > /dev/null 2> $D.err
   python3 - "$D" "$lib" <<'PY'
 import csv,glob,collections,sys
 d=collections.defaultdict(float); n=collections.defaultdict(int)
@@ -19,5 +19,5 @@ p=4.0   # passes of the hot path under the profiler: verify + 1 warm-up + 2 time
 if d: print('%-28s VALU/pass %.4g  busy-cycles/pass %.4g  issue-util %.3f  LDS insts %.4g' % (sys.argv[2], d['SQ_INSTS_VALU']/p, d['GRBM_GUI_ACTIVE']/p, d['SQ_ACTIVE_INST_VALU']*4/(1024*d['GRBM_GUI_ACTIVE']/8), d['SQ_INSTS_LDS']/p))
 else: print(sys.argv[2], 'no counters', open(sys.argv[1]+'.err').read()[-300:])
 PY
-  python3 $R/bench.py $ARGS --steps 20 --warmup 5 --no-cpu --no-real-ties 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-28s %.4g pos/s  K1 %.3f ms  verify %s'%('', d['value'], d['roofline']['kernel_avg_ms'], d['verify']['ok']))"
+  python3 $R/bench.py $ARGS --steps 20 --warmup 5 --no-cpu --no-side --no-host-path 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-28s %.4g pos/s  K1 %.3f ms  verify %s'%('', d['value'], d['roofline']['kernel_avg_ms'], d['verify']['ok']))"
 done

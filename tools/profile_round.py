@@ -31,9 +31,11 @@ LIB = os.path.join(ROOT, 'nanomod_amd', 'libnanomod_hip.so')
 SHA = hashlib.sha256(open(LIB, 'rb').read()).hexdigest()[:16]
 
 CONFIGS = [('ks_f32', []), ('all_f32', ['--config', 'alltests']), ('ks_i16', ['--dtype', 'i16']),
-           ('all_i16', ['--config', 'alltests', '--dtype', 'i16']), ('ks_f32_realties', ['--ties', 'real'])]
+           ('all_i16', ['--config', 'alltests', '--dtype', 'i16']), ('ks_f32_realties', ['--ties', 'real']),
+           ('ks_f32_rationald', ['--rational-d'])]
 if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minutes per pass): only on request
     CONFIGS += [('ragged_all_f32', ['--config', 'ragged', '--all-tests', '--steps', '3', '--warmup', '1']),
+                ('ragged_all_f32_realties', ['--config', 'ragged', '--all-tests', '--ties', 'real', '--steps', '3', '--warmup', '1']),
                 ('ragged_all_i16', ['--config', 'ragged', '--all-tests', '--dtype', 'i16', '--steps', '3', '--warmup', '1']),
                 ('ragged_ks_f32', ['--config', 'ragged', '--steps', '3', '--warmup', '1']),
                 ('chr20_ks_f32', ['--config', 'chr20', '--steps', '3', '--warmup', '1'])]
@@ -70,12 +72,12 @@ def k1_rows(pattern, col):
 
 traffic = {}
 for cfg, extra in CONFIGS:
-    line = bench_line(extra + (['--no-cpu'] if cfg != 'ks_f32' else []))
+    line = bench_line(extra + (['--no-cpu', '--no-side', '--no-host-path'] if cfg != 'ks_f32' else []))   # the headline: the full default line
     json.dump(line, open(os.path.join(OUT, '%s_bench_%s.json' % (TAG, cfg)), 'w'))
     # kernel trace + stats
     d = '/tmp/prof_%s_trace' % cfg
     shutil.rmtree(d, ignore_errors=True)
-    r = run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', 'python3', BENCH, '--steps', '10', '--warmup', '3', '--no-cpu', '--no-real-ties'] + extra)
+    r = run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', 'python3', BENCH, '--steps', '10', '--warmup', '3', '--no-cpu', '--no-side', '--no-host-path'] + extra)
     under = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     for f in glob.glob(d + '/*/*kernel_stats.csv'):
         shutil.copy(f, os.path.join(OUT, '%s_%s_kernel_stats.csv' % (TAG, cfg)))
@@ -88,7 +90,7 @@ for cfg, extra in CONFIGS:
     for gi, group in enumerate(PMC_GROUPS):
         d = '/tmp/prof_%s_pmc%d' % (cfg, gi)
         shutil.rmtree(d, ignore_errors=True)
-        run(['rocprofv3', '--pmc'] + group + ['--output-format', 'csv', '-d', d, '--', 'python3', BENCH] + extra + ['--steps', '2', '--warmup', '1', '--no-cpu', '--no-real-ties'])
+        run(['rocprofv3', '--pmc'] + group + ['--output-format', 'csv', '-d', d, '--', 'python3', BENCH] + extra + ['--steps', '2', '--warmup', '1', '--no-cpu', '--no-side', '--no-host-path'])
         vals, meta = k1_rows(d + '/*/*counter_collection.csv', 'Counter_Name')
         # per bench step: 4 passes of the hot path run under the profiler (verify, warm-up, 2 timed); a ragged pass is
         # many size-class launches, so the counters are summed over the K1 kernels and divided by the passes

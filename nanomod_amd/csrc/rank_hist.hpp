@@ -531,9 +531,10 @@ void rank_hist_kernel(RankStatsArgs args) {
       int lcnt = 0;                                  // how many (the same in every lane)
       // (the table size is a prime, not a power of two — 1 597 slots for Q <= 1 024, 3 067 for Q <= 2 048: five and three
       // blocks per CU instead of four and two; any step in 1 .. nslots - 1 visits every slot: here 1 .. 512)
+      unsigned tslots = nslots;                      // slots of the table the deferred walks use (the bitmap mode's is smaller)
       auto walk_to_end = [&](unsigned bits, bool act) {
         const unsigned hsh = bits * 2654435761u;
-        unsigned hh = ((hsh >> 13) * nslots) >> 19;         // 19 hash bits x at most 4 099 slots: (2^19 - 1) * 4 099 < 2^32, no wrap
+        unsigned hh = ((hsh >> 13) * tslots) >> 19;         // 19 hash bits x at most 4 099 slots: (2^19 - 1) * 4 099 < 2^32, no wrap
         const unsigned st = 1u + (hsh & 511u);
         unsigned dup = 0u;
         while (__ballot(act) != 0ull) {
@@ -541,7 +542,7 @@ void rank_hist_kernel(RankStatsArgs args) {
           dup += (act && old == bits) ? 1u : 0u;
           act = act && old != kWideEmpty;
           hh += st;
-          hh = min(hh, hh - nslots);                          // (below nslots the difference wraps to a huge value)
+          hh = min(hh, hh - tslots);                          // (below tslots the difference wraps to a huge value)
         }
         ppq += dup * (dup + 1u);                     // the p-th of its value, p = dup + 1: p (p - 1)
       };
@@ -652,8 +653,115 @@ void rank_hist_kernel(RankStatsArgs args) {
         if (lcnt > 0) drain(lcnt);                   // what is still deferred belongs to this pass's half of the values
       }
       };
+      // ---- Samples off the grid (continuous signals): ties inside Q are rare, and the hash above pays two dependent
+      // compare-and-swaps per sample to find none.  Two cheap passes instead.  Pass 1 (with the ranking and the moments): every
+      // sample sets one bit of a bitmap B1 by a returning OR; a sample that finds its bit set marks the same bit in a second
+      // bitmap B2 — the bits that two or more samples share.  Equal samples share a bit, so every tied sample of Q sits on a
+      // B2 bit.  Pass 2 streams Q again (from L2), reads each sample's B2 bit, and only the samples on marked bits (~n^2 / bits:
+      // a few per cent) go through the exact multiset walk — into a table in B1's words, 64 at a time, one per lane.  No B2 bit:
+      // no ties inside Q at all.  Too many marked samples for that table (heavy ties off the grid): the hash passes above.
+      auto bitmap_passes = [&]() {
+        const int W1 = (wslots >= 4096) ? 2048 : 1024;             // words of B1 (and of B2 behind it): 32 768 or 65 536 bits
+        const unsigned SH = (W1 == 2048) ? 16u : 17u;              // bit index = the top bits of the multiplicative hash
+        unsigned* B2 = ht + W1;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < (2 * W1) / 4; i += 64) reinterpret_cast<uint4*>(ht)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        unsigned hits = 0u;                                        // samples of this lane that found their bit set
+        auto mark = [&](float xv, bool have) {
+          const unsigned hsh = __float_as_uint(xv + 0.0f) * 2654435761u;      // (-0.0 -> +0.0: one key per value)
+          const unsigned idx = hsh >> SH;
+          const unsigned bit = 1u << (idx & 31u);
+          unsigned old = 0u;
+          if (have) old = atomicOr(&ht[idx >> 5], bit);
+          const bool hit = (old & bit) != 0u;
+          if (hit) atomicOr(&B2[idx >> 5], bit);
+          hits += hit ? 1u : 0u;
+        };
+#pragma unroll 1
+        for (int c = 0; c < full_w; ++c) {
+          const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
+          const float xa[4] = {ra.x, ra.y, ra.z, ra.w};
+          unsigned ad[4];
+#if !(NMOD_SKIP & 512)
+          rank_many(std::integral_constant<int, 4>{}, xa, true, ad);
+#endif
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const double d = (double)xa[e] - KQ; s1w += d; s2w = __fma_rn(d, d, s2w); }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mark(xa[e], true);
+          ra = rb;
+        }
+#pragma unroll 1
+        for (int c = 0; c < tail_w; ++c) {
+          const int idx_now = full * (4 * LG) + c * LG + gl;
+          const bool have = idx_now < q;
+          const float xq1[1] = {have ? (float)rt : big};
+          const int idx = full * (4 * LG) + (c + 1) * LG + gl;
+          rt = load_q1(sig_q, off_q, idx, idx < q);
+          unsigned a1[1];
+#if !(NMOD_SKIP & 512)
+          rank_many(std::integral_constant<int, 1>{}, xq1, have, a1);
+#endif
+          const double d = (double)(have ? xq1[0] : kqf) - KQ;
+          s1w += d; s2w = __fma_rn(d, d, s2w);
+          mark(xq1[0], have);
+        }
+        const unsigned total_hits = pos_allsum_u32<64>(hits);
+        if (total_hits == 0u) return;                              // no two samples on one bit: no ties inside Q
+        tslots = (unsigned)wide_table_slots(W1);
+        if (2u * total_hits + 64u > tslots / 2u) {                 // (a bit shared by c samples: c - 1 hits, c <= 2 (c - 1) samples to walk)
+          tslots = nslots;
+          hash_passes(false);
+          return;
+        }
+        // pass 2: B1's words become the exact table; B2 stays
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < W1 / 4; i += 64) reinterpret_cast<uint4*>(ht)[i] = make_uint4(kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty);
+        ra = load_q4(sig_q, off_q, 4 * gl, 0 < full);
+        rt = load_q1(sig_q, off_q, full * (4 * LG) + gl, full * (4 * LG) + gl < q);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        auto collect = [&](float xv, bool have) {
+          const unsigned bits = __float_as_uint(xv + 0.0f);
+          const unsigned idx = (bits * 2654435761u) >> SH;
+          const unsigned w = B2[idx >> 5];
+          const bool sus = have && ((w >> (idx & 31u)) & 1u) != 0u;
+          const unsigned long long mk = __ballot(sus);
+          if (mk != 0ull) {
+            const int at = lcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            if (sus) lst[at] = bits;
+            lcnt += __popcll(mk);
+            if (lcnt >= 64) drain(64);
+          }
+        };
+#pragma unroll 1
+        for (int c = 0; c < full_w; ++c) {
+          const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
+          collect(ra.x, true); collect(ra.y, true); collect(ra.z, true); collect(ra.w, true);
+          ra = rb;
+        }
+#pragma unroll 1
+        for (int c = 0; c < tail_w; ++c) {
+          const bool have = full * (4 * LG) + c * LG + gl < q;
+          const float xv = have ? (float)rt : big;
+          const int idx = full * (4 * LG) + (c + 1) * LG + gl;
+          rt = load_q1(sig_q, off_q, idx, idx < q);
+          collect(xv, have);
+        }
+        if (lcnt > 0) drain(lcnt);
+        tslots = nslots;
+      };
       if (!s_grid) {
+#if defined(NMOD_NO_BITMAP)
         hash_passes(true);
+#else
+        bitmap_passes();
+#endif
       } else {
         // ---- S is on the milli-unit grid: rank and sum the moments as above, count Q's ties by VALUE with the direct-address
         // counters of the int16 form (window of 4 x wslots >= 8 192 values centred on the median of S) — as long as every

@@ -784,6 +784,72 @@ def main():
             fill(b, args.ties)
         step(False); state.wait(); torch.cuda.synchronize()     # the headline rows and outputs are back for what follows
 
+    # ---- the other BASELINE configurations at their per-GPU size, a few timed steps each (configs[3]: one GPU's share of chr20;
+    # configs[4]: the ragged stress, KS + Stouffer and all three tests): every BASELINE config gets a number in the default run
+    def preset_leg(name, leg_all, steps):
+        pz = PRESETS[name]
+        csr_ = pz['layout'] == 'csr'
+        P, m0, m1 = pz['positions'], pz['n0'], pz['n1']
+        leg_method = 'fisher' if leg_all else 'stouffer'
+        det_x = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=leg_method, tests=L.TEST_ALL if leg_all else L.TEST_KS)
+        rid_x = torch.zeros(P, dtype=torch.int32, device=dev)
+        sig, hoff, doff = [None, None], [None, None], [None, None]
+        for g in (0, 1):
+            if csr_:
+                sz = ragged_sizes(SEED, 0, P, g)
+                hoff[g] = np.zeros(P + 1, np.int64)
+                np.cumsum(sz, out=hoff[g][1:])
+                doff[g] = torch.from_numpy(hoff[g]).to(dev)
+                sig[g] = torch.empty(int(hoff[g][-1]), dtype=torch.float32, device=dev)
+                det_x.synth_fill_csr(sig[g], SEED, 0, doff[g], g, PLANT_PERIOD, PLANT_SHIFT)
+            else:
+                sig[g] = torch.empty(P * (m0, m1)[g], dtype=torch.float32, device=dev)
+                det_x.synth_fill(sig[g], SEED, 0, P, g, (m0, m1)[g], PLANT_PERIOD, PLANT_SHIFT)
+        outs = det_x.alloc_outputs(P)
+
+        def run_once():
+            if csr_:
+                det_x.run(sig[0], sig[1], rid_x, off0=doff[0], off1=doff[1], max_n0=RAGGED_CLIP0[1], max_n1=RAGGED_CLIP1[1], out=outs)
+            else:
+                det_x.run(sig[0], sig[1], rid_x, stride0=m0, stride1=m1, npos=P, out=outs)
+        run_once(); torch.cuda.synchronize()
+        vn = 5_000 if csr_ else 20_000
+        if csr_:
+            o0, o1 = hoff[0][:vn + 1], hoff[1][:vn + 1]
+        else:
+            o0 = np.arange(0, (vn + 1) * m0, m0, dtype=np.int64); o1 = np.arange(0, (vn + 1) * m1, m1, dtype=np.int64)
+        rows = (sig[0][:int(o0[-1])].cpu().numpy(), o0, sig[1][:int(o1[-1])].cpu().numpy(), o1)
+        v = verify_against_oracle(rows, vn, outs, leg_all, leg_method, 0.0)
+        run_once()
+        tm = nm.EventTimer(256)
+        det_x.timer = tm
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run_once()
+        barrier()
+        el = time.perf_counter() - t0
+        det_x.timer = None
+        k1, kn = tm.read(L.KERNEL_RANK_STATS); k2, _ = tm.read(L.KERNEL_FINALIZE); k3, _ = tm.read(L.KERNEL_COMBINE)
+        mean0_, mean1_ = sig[0].numel() / P, sig[1].numel() / P
+        algo_leg = algorithmic_bytes(mean0_, mean1_, 4, 4 if leg_all else 2, csr_)
+        gbs = algo_leg * P / ((k1 + k2 + k3) / steps * 1e-3) / 1e9
+        if not v['ok']:
+            verify['ok'] = False
+            print('bench.py: verification of the %s leg FAILED: %r' % (name, v), file=sys.stderr)
+        return {'value': P * steps / el, 'unit': 'positions/s', 'steps': steps, 'ms_per_step': el / steps * 1e3, 'positions': P,
+                'workload': '%s, %s, float32' % (pz['name'], 'KS + MWU + Welch-t + Fisher' if leg_all else 'KS + weighted Stouffer'),
+                'mean_reads': [mean0_, mean1_], 'k1_ms_per_step': k1 / steps, 'algorithmic_bytes_per_position': algo_leg,
+                'achieved_GBps': gbs, 'roofline_frac': gbs / HBM_PEAK_GBS, 'verify': v}
+
+    if simple and args.config == 'ecoli' and args.dtype == 'f32' and args.ties == 'few' and not all_tests and not args.positions:
+        side['chr20_share'] = preset_leg('chr20', False, 5)
+        torch.cuda.empty_cache()
+        side['ragged'] = preset_leg('ragged', False, 3)
+        torch.cuda.empty_cache()
+        side['ragged_all_tests'] = preset_leg('ragged', True, 3)
+        torch.cuda.empty_cache()
+
     # ---- the host-resident entry on the same rows (NMOD_MEM_HOST): PCIe-bound, its own roofline
     host_path = None
     if world == 1 and not csr and not args.no_host_path and chunks == 1 and not args.force_collective:

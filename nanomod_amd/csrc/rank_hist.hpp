@@ -670,15 +670,30 @@ void rank_hist_kernel(RankStatsArgs args) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0x0F70);
         unsigned hits = 0u;                                        // samples of this lane that found their bit set
-        auto mark = [&](float xv, bool have) {
-          const unsigned hsh = __float_as_uint(xv + 0.0f) * 2654435761u;      // (-0.0 -> +0.0: one key per value)
-          const unsigned idx = hsh >> SH;
-          const unsigned bit = 1u << (idx & 31u);
-          unsigned old = 0u;
-          if (have) old = atomicOr(&ht[idx >> 5], bit);
-          const bool hit = (old & bit) != 0u;
-          if (hit) atomicOr(&B2[idx >> 5], bit);
-          hits += hit ? 1u : 0u;
+        // (the NV returning ORs of a round are issued together, then the marks: one LDS round trip per round, not one per sample)
+        auto mark_many = [&](auto nv_tag, const float* xv, const bool* have) {
+          constexpr int NV = decltype(nv_tag)::value;
+          unsigned idx[NV], bit[NV], old[NV];
+#pragma unroll
+          for (int e = 0; e < NV; ++e) {
+            const unsigned hsh = __float_as_uint(xv[e] + 0.0f) * 2654435761u;   // (-0.0 -> +0.0: one key per value)
+            idx[e] = hsh >> SH;
+            bit[e] = 1u << (idx[e] & 31u);
+          }
+#if !(NMOD_SKIP & 4096)
+#pragma unroll
+          for (int e = 0; e < NV; ++e) { old[e] = 0u; if (have[e]) old[e] = atomicOr(&ht[idx[e] >> 5], bit[e]); }
+#else
+#pragma unroll
+          for (int e = 0; e < NV; ++e) old[e] = 0u;               // (timing experiment: no bitmap atomics)
+#endif
+          bool hit[NV], any = false;
+#pragma unroll
+          for (int e = 0; e < NV; ++e) { hit[e] = (old[e] & bit[e]) != 0u; any = any || hit[e]; hits += hit[e] ? 1u : 0u; }
+          if (__ballot(any) != 0ull) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) if (hit[e]) atomicOr(&B2[idx[e] >> 5], bit[e]);
+          }
         };
 #pragma unroll 1
         for (int c = 0; c < full_w; ++c) {
@@ -690,10 +705,16 @@ void rank_hist_kernel(RankStatsArgs args) {
 #endif
 #pragma unroll
           for (int e = 0; e < 4; ++e) { const double d = (double)xa[e] - KQ; s1w += d; s2w = __fma_rn(d, d, s2w); }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) mark(xa[e], true);
+          { const bool hv[4] = {true, true, true, true}; mark_many(std::integral_constant<int, 4>{}, xa, hv); }
           ra = rb;
         }
+        // the first rounds of pass 2 are requested HERE, before the tail rounds of pass 1: a position is only ~4 full rounds
+        // long, so a request at the head of pass 2 exposes one L2 round trip per position (6.6 of 46.6 ms on configs[4])
+        constexpr int PF = 4;
+        Q4Raw buf[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) buf[i] = load_q4(sig_q, off_q, i * (4 * LG) + 4 * gl, i < full);
+        Q1Raw rt2 = load_q1(sig_q, off_q, full * (4 * LG) + gl, full * (4 * LG) + gl < q);
 #pragma unroll 1
         for (int c = 0; c < tail_w; ++c) {
           const int idx_now = full * (4 * LG) + c * LG + gl;
@@ -707,9 +728,12 @@ void rank_hist_kernel(RankStatsArgs args) {
 #endif
           const double d = (double)(have ? xq1[0] : kqf) - KQ;
           s1w += d; s2w = __fma_rn(d, d, s2w);
-          mark(xq1[0], have);
+          { const bool hv[1] = {have}; mark_many(std::integral_constant<int, 1>{}, xq1, hv); }
         }
         const unsigned total_hits = pos_allsum_u32<64>(hits);
+#if (NMOD_SKIP & 2048)
+        return;                                                    // (timing experiment: no second pass)
+#endif
         if (total_hits == 0u) return;                              // no two samples on one bit: no ties inside Q
         tslots = (unsigned)wide_table_slots(W1);
         if (2u * total_hits + 64u > tslots / 2u) {                 // (a bit shared by c samples: c - 1 hits, c <= 2 (c - 1) samples to walk)
@@ -721,37 +745,65 @@ void rank_hist_kernel(RankStatsArgs args) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < W1 / 4; i += 64) reinterpret_cast<uint4*>(ht)[i] = make_uint4(kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty);
-        ra = load_q4(sig_q, off_q, 4 * gl, 0 < full);
-        rt = load_q1(sig_q, off_q, full * (4 * LG) + gl, full * (4 * LG) + gl < q);
+        rt = rt2;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        auto collect = [&](float xv, bool have) {
-          const unsigned bits = __float_as_uint(xv + 0.0f);
-          const unsigned idx = (bits * 2654435761u) >> SH;
-          const unsigned w = B2[idx >> 5];
-          const bool sus = have && ((w >> (idx & 31u)) & 1u) != 0u;
-          const unsigned long long mk = __ballot(sus);
-          if (mk != 0ull) {
-            const int at = lcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-            if (sus) lst[at] = bits;
-            lcnt += __popcll(mk);
-            if (lcnt >= 64) drain(64);
+        auto collect_many = [&](auto nv_tag, const float* xv, const bool* have) {
+          constexpr int NV = decltype(nv_tag)::value;
+          unsigned bits[NV], idx[NV], w[NV];
+#pragma unroll
+          for (int e = 0; e < NV; ++e) { bits[e] = __float_as_uint(xv[e] + 0.0f); idx[e] = (bits[e] * 2654435761u) >> SH; }
+#if (NMOD_SKIP & 16384)
+#pragma unroll
+          for (int e = 0; e < NV; ++e) w[e] = idx[e];                // (timing experiment: no bitmap reads)
+#else
+#pragma unroll
+          for (int e = 0; e < NV; ++e) w[e] = B2[idx[e] >> 5];
+#endif
+          bool sus[NV], any = false;
+#pragma unroll
+          for (int e = 0; e < NV; ++e) { sus[e] = have[e] && ((w[e] >> (idx[e] & 31u)) & 1u) != 0u; any = any || sus[e]; }
+#if (NMOD_SKIP & 8192)
+          ppq += any ? 1u : 0u;                                      // (timing experiment: no list, no walks)
+          any = false;
+#endif
+          if (__ballot(any) != 0ull) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+              const unsigned long long mk = __ballot(sus[e]);
+              if (mk != 0ull) {
+                const int at = lcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                if (sus[e]) lst[at] = bits[e];
+                lcnt += __popcll(mk);
+                if (lcnt >= 64) drain(64);
+              }
+            }
           }
         };
 #pragma unroll 1
-        for (int c = 0; c < full_w; ++c) {
-          const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
-          collect(ra.x, true); collect(ra.y, true); collect(ra.z, true); collect(ra.w, true);
-          ra = rb;
+        for (int c = 0; c < full_w; c += PF) {
+          Q4Raw nxt[PF];
+#pragma unroll
+          for (int i = 0; i < PF; ++i) nxt[i] = load_q4(sig_q, off_q, (c + PF + i) * (4 * LG) + 4 * gl, c + PF + i < full);
+#pragma unroll
+          for (int i = 0; i < PF; ++i) {
+            if (c + i < full_w) {
+              const float xa[4] = {buf[i].x, buf[i].y, buf[i].z, buf[i].w};
+              const bool hv[4] = {true, true, true, true};
+              collect_many(std::integral_constant<int, 4>{}, xa, hv);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < PF; ++i) buf[i] = nxt[i];
         }
 #pragma unroll 1
         for (int c = 0; c < tail_w; ++c) {
           const bool have = full * (4 * LG) + c * LG + gl < q;
-          const float xv = have ? (float)rt : big;
+          const float xv[1] = {have ? (float)rt : big};
           const int idx = full * (4 * LG) + (c + 1) * LG + gl;
           rt = load_q1(sig_q, off_q, idx, idx < q);
-          collect(xv, have);
+          const bool hv[1] = {have};
+          collect_many(std::integral_constant<int, 1>{}, xv, hv);
         }
         if (lcnt > 0) drain(lcnt);
         tslots = nslots;

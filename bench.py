@@ -255,11 +255,49 @@ def cpu_baseline(rows, what, method, tests, threads, target_seconds=12.0, refpy=
             'reference_shaped_python': ref_shaped}
 
 
+def gpu_local_cpus(torch, dev_index):
+    """CPUs of the NUMA node the GPU hangs off (sysfs), or None.  A two-socket host copies from the far socket's memory at
+    ~0.8 of the near rate; where the caller's arrays live is the caller's business, the measurement keeps its own near."""
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bdf = '%04x:%02x:%02x.0' % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open('/sys/bus/pci/devices/%s/numa_node' % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        return cpus or None
+    except Exception:
+        return None
+
+
 def host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out):
     """The host-resident entry (NMOD_MEM_HOST; what a drop-in mtest2 hands over — everything on this path is host memory in
     the reference, myDetect.py:416-445) on the SAME rows as the headline: pageable numpy arrays, the same arrays page-locked
     in place, and int16 milli-unit arrays.  The path is PCIe-bound, so its roofline is the pinned hipMemcpy rate, measured
     here in the same run.  Results are compared bit for bit with the device-resident pass."""
+    import ctypes
+    import numpy as np
+    L = nm._lib
+    lib = L.load()
+    dev = 'cuda:%d' % dev_index
+    b0 = blocks[0]
+    npos = b0['n']
+    # the host arrays of this leg are first touched by this thread: keep it (and the library's copy threads, which inherit the
+    # mask) on the GPU's own socket while the leg runs
+    near = gpu_local_cpus(torch, dev_index)
+    old_aff = os.sched_getaffinity(0)
+    if near and (near & old_aff):
+        os.sched_setaffinity(0, near & old_aff)
+    try:
+        return _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out, near)
+    finally:
+        os.sched_setaffinity(0, old_aff)
+
+
+def _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out, near):
     import ctypes
     import numpy as np
     L = nm._lib
@@ -307,7 +345,7 @@ def host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests,
             rec['equals_device_resident_pass'] = bool(all(np.array_equal(res[k], check[k].cpu().numpy(), equal_nan=True) for k in res if k in check))
         return rec, res
 
-    out = {'pinned_h2d_GBps': h2d_gbs, 'pinned_d2h_GBps': d2h_gbs, 'positions': npos,
+    out = {'pinned_h2d_GBps': h2d_gbs, 'pinned_d2h_GBps': d2h_gbs, 'positions': npos, 'host_arrays_on_gpu_socket': bool(near),
            'note': 'nmod_detect_batch(NMOD_MEM_HOST) on the headline rows held in host memory: chunks of positions through pinned bounce '
                    'slots, H2D of chunk k+1 / K1+K2 of chunk k / D2H of chunk k-1 on three streams, one K3 over the whole KS track; '
                    'best of the runs listed; roofline = the pinned H2D rate measured above'}
@@ -431,6 +469,7 @@ def main():
     ap.add_argument('--refpy-seconds', type=float, default=6.0, help='reference-shaped Python CPU leg: at least this many seconds per process')
     ap.add_argument('--no-side', '--no-real-ties', dest='no_side', action='store_true',
                     help='skip the side measurements of the default run (all tests, int16, rational D, tie-heavy input)')
+    ap.add_argument('--side-legs', default='all', help='comma list of side measurements to run (all_tests,int16,rational_d,real_ties,presets); default all')
     ap.add_argument('--no-host-path', action='store_true', help='skip the host-resident (NMOD_MEM_HOST, PCIe-bound) measurement')
     ap.add_argument('--rational-d', action='store_true', help='KS-only configurations: time NMOD_FLAG_KS_RATIONAL_D (D as the exact rational, <= 2 ulp '
                     'from ks_2samp\'s float form) instead of the library default (D bit for bit); the default run reports this rate as a side figure')
@@ -749,14 +788,17 @@ def main():
                 'roofline_frac': gbs / HBM_PEAK_GBS, 'achieved_GBps': gbs, 'note': note, 'verify': v}
 
     side = {}
+    legs = set(args.side_legs.split(',')) if args.side_legs != 'all' else {'all_tests', 'int16', 'rational_d', 'real_ties', 'presets'}
     simple = world == 1 and not csr and not args.force_collective and not args.no_side and chunks == 1
-    if simple and args.config == 'ecoli' and args.dtype == 'f32' and args.ties == 'few' and not all_tests:
+    headline_default = simple and args.config == 'ecoli' and args.dtype == 'f32' and args.ties == 'few' and not all_tests
+    if headline_default and 'all_tests' in legs:
         # (a) all three tests + Fisher on the same buffers: what every real getKStest call computes (myDetect.py:331-343), BASELINE configs[2]
         det_all = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method='fisher', tests=L.TEST_ALL)
         outs_all = det_all.alloc_outputs(blocks[0]['n'])
         side['all_tests'] = side_leg(det_all, ('sig0', 'sig1'), outs_all, True, 'fisher', 0.0,
                                      'BASELINE configs[2] on the same buffers: KS + MWU + Welch-t per position + Fisher window=5 (rank_hist_kernel)')
         del outs_all
+    if headline_default and 'int16' in legs:
         # (b) the same rows as int16 milli-units, the format of real events (myRefBaseSignalAnnotation.py:1108): 844 B / position
         for b in blocks:
             b['q0'] = torch.empty(b['n'] * n0, dtype=torch.int16, device=dev); b['q1'] = torch.empty(b['n'] * n1, dtype=torch.int16, device=dev)
@@ -767,13 +809,13 @@ def main():
                                  'the same generator as int16 milli-units (844 algorithmic bytes per position): ks_rank_kernel<16,16,i16>, packed v_pk_min/max_i16 sort')
         for b in blocks:
             del b['q0'], b['q1']
+    if headline_default and 'rational_d' in legs and not rational_d:
         # (c) NMOD_FLAG_KS_RATIONAL_D: D as the correctly rounded rational (<= 2 ulp from ks_2samp's float form) — an opt-out no
         # reference-shaped entry point uses; rounds 1-3 quoted this rate as the headline
-        if not rational_d:
-            det_r = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests, flags=L.FLAG_KS_RATIONAL_D)
-            side['rational_d'] = side_leg(det_r, ('sig0', 'sig1'), blocks[0]['out'], False, method, KS_D_RATIONAL_ABS,
-                                          'flags = NMOD_FLAG_KS_RATIONAL_D (skips the float-form pass of D; gate 4.5e-16); the headline of BENCH_r01..r03')
-    if simple and args.ties == 'few' and args.dtype == 'f32' and args.config in ('ecoli', 'alltests'):
+        det_r = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests, flags=L.FLAG_KS_RATIONAL_D)
+        side['rational_d'] = side_leg(det_r, ('sig0', 'sig1'), blocks[0]['out'], False, method, KS_D_RATIONAL_ABS,
+                                      'flags = NMOD_FLAG_KS_RATIONAL_D (skips the float-form pass of D; gate 4.5e-16); the headline of BENCH_r01..r03')
+    if simple and args.ties == 'few' and args.dtype == 'f32' and args.config in ('ecoli', 'alltests') and 'real_ties' in legs:
         # (d) tie-heavy input (real NanoMod events are 3-decimal values): the buffers are refilled in place — last, nothing
         # after this leg sees the headline's rows
         for b in blocks:
@@ -782,7 +824,8 @@ def main():
                                      'the same generator on the 3-decimal grid (round(1000 x) / 1000 as float32): ties between and inside the groups as in real events')
         for b in blocks:
             fill(b, args.ties)
-        step(False); state.wait(); torch.cuda.synchronize()     # the headline rows and outputs are back for what follows
+    if side:
+        step(False); state.wait(); torch.cuda.synchronize()     # the headline's outputs are back for what follows
 
     # ---- the other BASELINE configurations at their per-GPU size, a few timed steps each (configs[3]: one GPU's share of chr20;
     # configs[4]: the ragged stress, KS + Stouffer and all three tests): every BASELINE config gets a number in the default run
@@ -842,14 +885,6 @@ def main():
                 'mean_reads': [mean0_, mean1_], 'k1_ms_per_step': k1 / steps, 'algorithmic_bytes_per_position': algo_leg,
                 'achieved_GBps': gbs, 'roofline_frac': gbs / HBM_PEAK_GBS, 'verify': v}
 
-    if simple and args.config == 'ecoli' and args.dtype == 'f32' and args.ties == 'few' and not all_tests and not args.positions:
-        side['chr20_share'] = preset_leg('chr20', False, 5)
-        torch.cuda.empty_cache()
-        side['ragged'] = preset_leg('ragged', False, 3)
-        torch.cuda.empty_cache()
-        side['ragged_all_tests'] = preset_leg('ragged', True, 3)
-        torch.cuda.empty_cache()
-
     # ---- the host-resident entry on the same rows (NMOD_MEM_HOST): PCIe-bound, its own roofline
     host_path = None
     if world == 1 and not csr and not args.no_host_path and chunks == 1 and not args.force_collective:
@@ -859,6 +894,16 @@ def main():
         if bad:
             verify['ok'] = False
             print('bench.py: the host-resident entry differs from the device-resident pass: %r' % bad, file=sys.stderr)
+
+    # (after the host-resident leg: freeing the presets' 79 GB of device memory slows the PCIe copies that follow for a while —
+    # 0.77 instead of 0.95 of the pinned rate when the order is reversed)
+    if headline_default and not args.positions and 'presets' in legs:
+        side['chr20_share'] = preset_leg('chr20', False, 5)
+        torch.cuda.empty_cache()
+        side['ragged'] = preset_leg('ragged', False, 3)
+        torch.cuda.empty_cache()
+        side['ragged_all_tests'] = preset_leg('ragged', True, 3)
+        torch.cuda.empty_cache()
 
     line = None
     if rank == 0:

@@ -748,6 +748,21 @@ void rank_hist_kernel(RankStatsArgs args) {
         rt = rt2;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // a sample on a marked bit waits in a register of its lane (`pend`); the waiting samples of all lanes go to the deferred
+        // list together when some lane gets a second one (a ballot + branch per sample slot instead of a compaction per slot:
+        // 3 % of the samples are on marked bits, but nearly every slot of 64 lanes holds one)
+        unsigned pend = 0u;
+        bool full_l = false;
+        auto flush = [&]() {
+          const unsigned long long mk = __ballot(full_l);
+          if (mk != 0ull) {
+            const int at = lcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            if (full_l) lst[at] = pend;
+            lcnt += __popcll(mk);
+            full_l = false;
+            while (lcnt >= 64) drain(64);
+          }
+        };
         auto collect_many = [&](auto nv_tag, const float* xv, const bool* have) {
           constexpr int NV = decltype(nv_tag)::value;
           unsigned bits[NV], idx[NV], w[NV];
@@ -760,24 +775,15 @@ void rank_hist_kernel(RankStatsArgs args) {
 #pragma unroll
           for (int e = 0; e < NV; ++e) w[e] = B2[idx[e] >> 5];
 #endif
-          bool sus[NV], any = false;
 #pragma unroll
-          for (int e = 0; e < NV; ++e) { sus[e] = have[e] && ((w[e] >> (idx[e] & 31u)) & 1u) != 0u; any = any || sus[e]; }
+          for (int e = 0; e < NV; ++e) {
+            bool sus = have[e] && ((w[e] >> (idx[e] & 31u)) & 1u) != 0u;
 #if (NMOD_SKIP & 8192)
-          ppq += any ? 1u : 0u;                                      // (timing experiment: no list, no walks)
-          any = false;
+            ppq += sus ? 1u : 0u; sus = false;                        // (timing experiment: no list, no walks)
 #endif
-          if (__ballot(any) != 0ull) {
-#pragma unroll
-            for (int e = 0; e < NV; ++e) {
-              const unsigned long long mk = __ballot(sus[e]);
-              if (mk != 0ull) {
-                const int at = lcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                if (sus[e]) lst[at] = bits[e];
-                lcnt += __popcll(mk);
-                if (lcnt >= 64) drain(64);
-              }
-            }
+            if (__ballot(sus && full_l) != 0ull) flush();
+            pend = sus ? bits[e] : pend;
+            full_l = full_l || sus;
           }
         };
 #pragma unroll 1
@@ -805,6 +811,7 @@ void rank_hist_kernel(RankStatsArgs args) {
           const bool hv[1] = {have};
           collect_many(std::integral_constant<int, 1>{}, xv, hv);
         }
+        flush();
         if (lcnt > 0) drain(lcnt);
         tslots = nslots;
       };

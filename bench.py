@@ -23,7 +23,12 @@ and runs on RCCL's stream beside the kernels of round c+1.  Two figures are time
 
 Before the warm-up one untimed pass is checked against the CPU oracle (the C restatement) on a bounded sample of the
 same input; the result goes into `verify`, and a failed verification makes the exit code non-zero.  The oracle is
-also the `cpu_baseline`.  Prints ONE JSON line (the last line of stdout) on rank 0.
+also the `cpu_baseline` (C port on all usable cores and on one; the reference-shaped Python loop on all cores, one spawn
+child per core started before this process touches a GPU).  `value` is the library default (D bit for bit).  The default
+N = 1 run also times — each checked against the oracle first — all three tests + Fisher and int16 rows on the same buffers,
+the rational-D flag, 3-decimal input, one GPU's share of chr20, the ragged preset with KS and with all tests, and the
+host-resident entry (NMOD_MEM_HOST) on the same rows against the pinned-copy rate measured in the same run (`host_path`).
+Prints ONE JSON line (the last line of stdout) on rank 0.
 """
 import argparse
 import hashlib

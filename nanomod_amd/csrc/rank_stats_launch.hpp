@@ -49,8 +49,7 @@ inline bool wide_class(int cls) {
 // value domain, NMOD_WIDE_I16_WORDS words for every class.  float32: the multiset hash table; its slots in use are the
 // largest prime below the words (double hashing with any step then visits every slot), sized by the class of the larger
 // group: Q <= 1 024: 2 048 (2 039; four blocks per CU — 1 600 words = five blocks
-// measured no faster); Q <= 2 048: 3 068 (3 067, load <= 0.67: THREE blocks per CU instead of the two of 4 096 words,
-// +5 % on configs[4]); the two-pass classes (Q <= 4 096, split by a hash bit): 4 100 (4 099: a pass may receive every sample).
+// measured no faster); Q <= 2 048: 2 056 (2 053: see wide_table_words; until round 4 3 068 words, three blocks per CU); the two-pass classes (Q <= 4 096, split by a hash bit): 4 100 (4 099: a pass may receive every sample).
 #ifndef NMOD_WIDE_I16_WORDS
 #define NMOD_WIDE_I16_WORDS 2048                   // 8 192 values, four blocks per CU (1 912 words = five blocks: measured 10 % slower)
 #endif
@@ -63,13 +62,17 @@ __host__ __device__ constexpr int wide_table_words(int cls, int dtype) {
   if (cls >= kWideBigBase) return 4100;            // (one pass may receive all 4 096 samples: every sample one value)
   const int c0 = cls / kNumSizeClasses, c1 = cls % kNumSizeClasses;
   const int cq = c0 < c1 ? c1 : c0;
-  return cq <= 4 ? 2048 : 3068;                  // (Q <= 512 took 1 024 words: the grid mode's window is four values per word, 8 192 at least)
+  // Q <= 1 024: 2 048 words; Q <= 2 048: 2 056 (2 053 slots: the hash passes — since round 4 only the fall-back for heavy ties off the
+  // milli-unit grid — run at load <= 1 there, and the class fits FOUR blocks per CU instead of the three of 3 068 words: +10 % on
+  // configs[4], where it holds 43 % of the positions; the bitmaps need 2 048 words, the counters' window is four values per word)
+  return cq <= 4 ? 2048 : 2056;
 }
 __host__ __device__ constexpr int wide_table_slots(int words) {
   switch (words) {
     case 1024: return 1021;
     case 1600: return 1597;
     case 3068: return 3067;
+    case 2056: return 2053;
     case 4100: return 4099;
     case 2048: return 2039;
     case 4096: return 4093;

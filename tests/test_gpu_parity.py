@@ -385,7 +385,7 @@ def test_ks_only_large_ranked_group(nm):
 
 
 @pytest.mark.parametrize('mode', ['cont', 'grid1', 'const', 'i16', 'i16const', 'i16span', 'i16heavy', 'f64', 'f64ties',
-                                  'g32', 'g32span', 'g32heavy', 'g32mixed'])
+                                  'g32', 'g32span', 'g32heavy', 'g32mixed', 'offconst'])
 def test_unequal_classes_streamed_larger_group(nm, mode):
     """positions whose groups fall in different capacity classes with the smaller one <= 256 samples: the WIDE form of
     rank_hist_kernel (smaller group sorted, larger one streamed and counted in a per-wave hash table), the larger group up
@@ -397,7 +397,8 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
     heavy value of 255 / 256 / 257 copies among spread ones: the edge of the overflow test).  float32 input whose smaller
     group is on the milli-unit grid of real events takes the same counters (rank_hist.hpp: grid_key) while the larger
     group's samples are on the grid too: `g32` (3-decimal values), `g32span` / `g32heavy` (the recount paths), `g32mixed`
-    (samples off the grid, one ulp beside it, or beyond +-32.767 in either group: back to the hash, mid-position)"""
+    (samples off the grid, one ulp beside it, or beyond +-32.767 in either group: back to the hash, mid-position); `offconst`:
+    hundreds to thousands of equal samples off the grid — the bitmap form's fall-back, the hash passes with the table full"""
     import nanomod_oracle as orc
     rng = np.random.default_rng(zlib.crc32(mode.encode()))
     sizes = [(50, 1000), (1000, 50), (3, 130), (64, 65), (65, 2048), (130, 700), (256, 2048), (256, 4096), (4096, 256),
@@ -420,6 +421,12 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
             if len(big) > k:
                 big[rng.permutation(len(big))[:k]] = 0.123
             small[: len(small) // 2] = 0.123
+        elif mode == 'offconst':                      # heavy ties OFF the milli-unit grid: bitmaps -> the hash passes at full load
+            x[:] = 0.1234567; y[:] = 0.1234567
+            if i % 3 == 0:
+                y[: b // 2] = -1.7654321
+            elif i % 3 == 1:
+                y[::3] = rng.normal(0, 1, len(y[::3]))
         elif mode in ('const', 'i16const'):
             x[:] = 0.25; y[:] = 0.25
             if i % 3 == 0:

@@ -247,9 +247,36 @@ class SignTestRecords(collections.abc.Sequence):
             raise IndexError('list index out of range')
         return self._get(int(self._order[k]) if self._order is not None else k)
 
+    def _build_block(self, idx):
+        """records for the position indices `idx` (an int array), built column-wise: one `tolist()` per column instead of
+        fourteen scalar conversions per record (0.5 us against 4 us a record when a consumer walks the whole list)"""
+        root = self._parent if self._parent is not None else self
+        m, r = self._meta, self._res
+        cols = [np.asarray(m[k])[idx].tolist() for k in ('chrom', 'strand', 'pos', 'base', 'n0', 'n1')]
+        cols[0] = [str(x) for x in cols[0]]; cols[1] = [str(x) for x in cols[1]]; cols[3] = [str(x) for x in cols[3]]
+        nums = [np.asarray(r[k], dtype=np.float64)[idx].tolist() for k in ('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p')]
+        comb = [np.asarray(r[k], dtype=np.float64)[idx].tolist() for k in ('comb_st', 'comb_p')] if self._with_comb else None
+        out = []
+        for j, i in enumerate(idx.tolist()):
+            rec = root._cache.get(i)
+            if rec is None:
+                tests = [(nums[0][j], nums[1][j]), (nums[2][j], nums[3][j]), (nums[4][j], nums[5][j])]
+                if comb is not None:
+                    tests.append((comb[0][j], comb[1][j]))
+                rec = ((cols[0][j], cols[1][j], cols[2][j], cols[3][j], cols[4][j], cols[5][j]), tests)
+                root._cache[i] = rec
+                root._where[id(rec)] = i
+            out.append(rec)
+        return out
+
     def __iter__(self):
-        for k in range(len(self)):
-            yield self[k]
+        n = len(self)
+        block = 4096
+        for lo in range(0, n, block):
+            hi = min(lo + block, n)
+            idx = np.asarray(self._order[lo:hi], dtype=np.int64) if self._order is not None else np.arange(lo, hi, dtype=np.int64)
+            for rec in self._build_block(idx):
+                yield rec
 
     def index(self, value, start=0, stop=None):
         """list.index: first k with self[k] == value.  A record handed out by this object (or by the view that shares its

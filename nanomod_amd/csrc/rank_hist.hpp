@@ -111,6 +111,10 @@ __device__ __forceinline__ void ce_raw(float& lo, float& hi) {
 // correctly rounded reciprocal (q0 = k r, rem = fma(-q0, 1000, k), q = fma(rem, r, q0)): equal to the float32 division
 // k / 1000.0f for every |k| <= 32 767 (exhaustive host test, tests/test_grid_key.py).  Equal keys <=> equal samples among
 // the samples that pass: the integer keys order and tie exactly as the floats do.
+// RANGE = false leaves the |k| <= 32 767 test out (one compare per sample of the streamed group): an accepted sample is a function
+// of its key whatever the range (x == q(t)), so equal keys still mean equal samples; keys outside the counters' window send the
+// position to the recount, which checks the range once per position (a key beyond +-2^31 saturates there and fails it).
+template <bool RANGE = true>
 __device__ __forceinline__ bool grid_key(float x, int& k) {
   const float t = __builtin_rintf(__fmul_rn(x, 1000.0f));
   const float r = 1.0e-3f;
@@ -118,7 +122,8 @@ __device__ __forceinline__ bool grid_key(float x, int& k) {
   const float rem = __fmaf_rn(-q0, 1000.0f, t);
   const float q = __fmaf_rn(rem, r, q0);
   k = (int)t;                                          // (v_cvt_i32_f32 saturates; a value off the grid is never used as a key)
-  return q == x && __builtin_fabsf(t) <= 32767.0f;
+  if constexpr (RANGE) return q == x && __builtin_fabsf(t) <= 32767.0f;
+  else return q == x;
 }
 
 // `phases` odd-even transposition phases over the R x LG keys of every group of the wave (blocked layout): enough to
@@ -448,16 +453,18 @@ void rank_hist_kernel(RankStatsArgs args) {
     // value (a constant stretch of signal): the counts are void.  The ties of the position are counted again the plain
     // way: min and max of Q, then one pass per window of [min, max] with 16-bit counters, one sample per lane and trip.
     // key_at(i, have): the integer key of sample i of Q.
-    [[maybe_unused]] auto recount16 = [&](auto key_at) {
+    [[maybe_unused]] auto recount16 = [&](auto key_at) -> bool {
       ppq = 0u;
-      int lo = 32767, hi = -32768;
+      int lo = 0x7fffffff, hi = (int)0x80000000;
 #pragma unroll 1
       for (int i0 = 0; i0 < q; i0 += 64) {
         const int v = key_at(min(i0 + lane, q - 1), true);                   // (a sample read twice changes neither)
         lo = min(lo, v); hi = max(hi, v);
       }
-      const int vmax = (int)wave_max_u32((unsigned)(hi + 32768)) - 32768;
-      const int vmin = 32767 - (int)wave_max_u32((unsigned)(32767 - lo));
+      // (int16 input: keys within +-32 768.  float32 on the grid: any int, saturated beyond — such a range is refused)
+      const unsigned bmax = wave_max_u32((unsigned)hi ^ 0x80000000u), bmin = ~wave_max_u32(~((unsigned)lo ^ 0x80000000u));
+      if (bmax - bmin > 65535u) return false;
+      const int vmax = (int)(bmax ^ 0x80000000u), vmin = (int)(bmin ^ 0x80000000u);
       const int np16 = (vmax - vmin) / (2 * wslots) + 1;                      // two 16-bit counters per word
 #pragma unroll 1
       for (int pass = 0; pass < np16; ++pass) {
@@ -470,6 +477,7 @@ void rank_hist_kernel(RankStatsArgs args) {
           count_many(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{}, iv1, hv, base);
         }
       }
+      return true;
     };
     if constexpr (WIDE && DTYPE == 1) {
       // int16 samples.  The window is centred on the median of S (the two groups are reads of one position: real events
@@ -841,7 +849,7 @@ void rank_hist_kernel(RankStatsArgs args) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const double d = (double)xa[e] - KQ; s1w += d; s2w = __fma_rn(d, d, s2w);
-            hv[e] = grid_key(xa[e], iv[e]);
+            hv[e] = grid_key<false>(xa[e], iv[e]);
             offl = offl || !hv[e];
           }
           count_many(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{}, iv, hv, wb);
@@ -861,7 +869,7 @@ void rank_hist_kernel(RankStatsArgs args) {
           const double d = (double)(have ? xq1[0] : kqf) - KQ;
           s1w += d; s2w = __fma_rn(d, d, s2w);
           int iv1[1];
-          const bool ok = grid_key(xq1[0], iv1[0]);
+          const bool ok = grid_key<false>(xq1[0], iv1[0]);
           offl = offl || (have && !ok);
           const bool hv[1] = {have && ok};
           count_many(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, iv1, hv, wb);
@@ -870,7 +878,10 @@ void rank_hist_kernel(RankStatsArgs args) {
           ppq = 0u;
           hash_passes(false);
         } else if (redo != 0ull) {
-          recount16([&](int i, bool have) { int k; grid_key((float)load_q1(sig_q, off_q, i, have), k); return k; });
+          if (!recount16([&](int i, bool have) { int k; grid_key<false>((float)load_q1(sig_q, off_q, i, have), k); return k; })) {
+            ppq = 0u;                                 // keys over more than 65 535 milli-units: the hash
+            hash_passes(false);
+          }
         }
       }
     } else {

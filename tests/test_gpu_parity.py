@@ -463,6 +463,10 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
                     big_[j] = np.float32(40.0)                              # on the 3-decimal grid but beyond int16 milli-units
                 elif i % 4 == 2:
                     sm_[int(os_[i])] = np.float32(0.1234567)                # the sorted group off the grid: the hash from the start
+                else:                                                       # grid values far outside the counters' reach: the recount
+                    big_[j] = np.float32(200.0) if i % 8 == 3 else np.float32(1.0e10)   # refuses the range -> the hash passes
+                    if j + 2 < ob[i + 1]:
+                        big_[j + 2] = big_[j]
         r0, r1 = sig0, sig1
     got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=1, weights_dif=2.0, method='fisher')
     exp = orc.detect_batch(r0, off0, r1, off1, rid, 1, 2.0, orc.METHOD_FISHER)

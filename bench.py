@@ -293,13 +293,23 @@ def host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests,
     # the host arrays of this leg are first touched by this thread: keep it (and the library's copy threads, which inherit the
     # mask) on the GPU's own socket while the leg runs
     near = gpu_local_cpus(torch, dev_index)
-    old_aff = os.sched_getaffinity(0)
-    if near and (near & old_aff):
-        os.sched_setaffinity(0, near & old_aff)
+    old_aff = None
+    try:
+        old_aff = os.sched_getaffinity(0)
+        if near and (near & old_aff):
+            os.sched_setaffinity(0, near & old_aff)
+        else:
+            near = None
+    except (AttributeError, OSError):
+        near = None
     try:
         return _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out, near)
     finally:
-        os.sched_setaffinity(0, old_aff)
+        if old_aff is not None:
+            try:
+                os.sched_setaffinity(0, old_aff)
+            except OSError:
+                pass
 
 
 def _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out, near):

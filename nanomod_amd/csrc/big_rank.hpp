@@ -420,4 +420,60 @@ void big_hist_kernel(BigArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// wide_redo_kernel — the ties INSIDE the streamed group of the positions that rank_hist_kernel's WIDE float32 form put on
+// its redo list (more samples on shared bitmap bits than its exact table takes: hundreds to thousands of equal samples off
+// the milli-unit grid).  One workgroup per listed position: the larger group (<= 4 096 samples) is sorted in LDS and
+// 3 x sum over its elements of p (p - 1), p = place of the element in its run of equal keys, is ADDED to tie[pos] — the
+// WIDE kernel has stored everything else of the position (the ties of the sorted group and between the groups included).
+// The list length is read on the device: the launch needs no host round trip and returns at once when the list is empty.
+struct WideRedoArgs {
+  const void* sig0; const void* sig1; const int64_t* off0; const int64_t* off1; int64_t stride0, stride1;
+  const int32_t* list; const int32_t* count; uint64_t* tie;
+};
+constexpr int kWideRedoMaxQ = 4096;
+
+__global__ __launch_bounds__(kBigThreads)
+void wide_redo_kernel(WideRedoArgs a) {
+  __shared__ float keys[kWideRedoMaxQ];
+  __shared__ int carry[kBigThreads];
+  __shared__ double red[kBigThreads / 64];
+  const int n_items = *a.count;
+  const int tid = threadIdx.x;
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const int64_t pos = a.list[it];
+    int64_t o0, o1; int n0, n1;
+    if (a.stride0 > 0) { o0 = pos * a.stride0; n0 = (int)a.stride0; } else { o0 = a.off0[pos]; n0 = (int)(a.off0[pos + 1] - o0); }
+    if (a.stride1 > 0) { o1 = pos * a.stride1; n1 = (int)a.stride1; } else { o1 = a.off1[pos]; n1 = (int)(a.off1[pos + 1] - o1); }
+    const bool swap = n1 < n0;                       // rank_hist_kernel: S = the smaller group (ties: group 1), Q = the other
+    const float* src = reinterpret_cast<const float*>(swap ? a.sig0 : a.sig1) + (swap ? o0 : o1);
+    const int q = swap ? n0 : n1;
+    int P = 64;
+    while (P < q) P <<= 1;
+    if (q > kWideRedoMaxQ) continue;                 // (not reached: the WIDE classes end at 4 096 samples)
+    __syncthreads();
+    for (int i = tid; i < P; i += kBigThreads) keys[i] = (i < q) ? src[i] + 0.0f : __builtin_inff();   // (-0.0 -> +0.0)
+    __syncthreads();
+    big_bitonic(keys, P);
+    // place of every element in its run: chunks of P / 256 consecutive keys per thread, the start of the run open at a chunk's
+    // first key from a max-scan of the chunks' last run starts
+    const int per = P / kBigThreads > 0 ? P / kBigThreads : 1;
+    const int lo = tid * per, hi = min(lo + per, q);
+    int last = -1;                                   // start of the last run that begins inside this chunk
+    for (int i = lo; i < hi; ++i) if (i == 0 || keys[i] != keys[i - 1]) last = i;
+    carry[tid] = last;
+    __syncthreads();
+    int start = -1;
+    for (int t = tid - 1; t >= 0 && start < 0; --t) start = carry[t];     // (short: most chunks begin a run)
+    double sum = 0.0;
+    for (int i = lo; i < hi; ++i) {
+      if (i == 0 || keys[i] != keys[i - 1]) start = i;
+      const double d = (double)(i - start);          // p - 1
+      sum += d * (d + 1.0);                          // p (p - 1): exact in fp64 (< 2^53 for 4 096 samples)
+    }
+    const double tot = big_block_sum(sum, red);
+    if (tid == 0) a.tie[pos] += 3ull * (unsigned long long)tot;
+  }
+}
+
 }  // namespace nmod

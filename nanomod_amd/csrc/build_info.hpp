@@ -19,11 +19,6 @@
 #else
 #define NMOD_BI_HIST_WAVES "4"
 #endif
-#ifdef NMOD_WIDE_PROBES
-#define NMOD_BI_WIDE_PROBES NMOD_STR(NMOD_WIDE_PROBES)
-#else
-#define NMOD_BI_WIDE_PROBES "2"
-#endif
 #ifdef NMOD_WIDE_I16_WORDS
 #define NMOD_BI_WIDE_I16_WORDS NMOD_STR(NMOD_WIDE_I16_WORDS)
 #else
@@ -44,11 +39,6 @@
 #else
 #define NMOD_BI_CE_BUILTIN "0"
 #endif
-#ifdef NMOD_WIDE_POW2
-#define NMOD_BI_WIDE_POW2 "1"
-#else
-#define NMOD_BI_WIDE_POW2 "0"
-#endif
 #ifdef NMOD_XOR4_BANKS
 #define NMOD_BI_XOR4_BANKS "1"
 #else
@@ -59,13 +49,8 @@
 #else
 #define NMOD_BI_NO_GRID "0"
 #endif
-#ifdef NMOD_NO_BITMAP
-#define NMOD_BI_NO_BITMAP "1"
-#else
-#define NMOD_BI_NO_BITMAP "0"
-#endif
 #define NMOD_BUILD_FLAGS                                                                                              \
   "NMOD_SKIP=" NMOD_BI_SKIP " NMOD_EXP=" NMOD_BI_EXP " NMOD_HIST_WAVES=" NMOD_BI_HIST_WAVES                            \
-  " NMOD_WIDE_PROBES=" NMOD_BI_WIDE_PROBES " NMOD_WIDE_I16_WORDS=" NMOD_BI_WIDE_I16_WORDS " NMOD_SWZ_MASK=" NMOD_BI_SWZ_MASK \
-  " NMOD_PK_SELECT=" NMOD_BI_PK_SELECT " NMOD_CE_BUILTIN=" NMOD_BI_CE_BUILTIN " NMOD_WIDE_POW2=" NMOD_BI_WIDE_POW2     \
-  " NMOD_XOR4_BANKS=" NMOD_BI_XOR4_BANKS " NMOD_NO_GRID=" NMOD_BI_NO_GRID " NMOD_NO_BITMAP=" NMOD_BI_NO_BITMAP
+  " NMOD_WIDE_I16_WORDS=" NMOD_BI_WIDE_I16_WORDS " NMOD_SWZ_MASK=" NMOD_BI_SWZ_MASK \
+  " NMOD_PK_SELECT=" NMOD_BI_PK_SELECT " NMOD_CE_BUILTIN=" NMOD_BI_CE_BUILTIN     \
+  " NMOD_XOR4_BANKS=" NMOD_BI_XOR4_BANKS " NMOD_NO_GRID=" NMOD_BI_NO_GRID

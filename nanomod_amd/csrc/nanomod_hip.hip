@@ -63,17 +63,18 @@ struct ScopedKernelTimer {
 struct Workspace {
   uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments;
   double* tmp_ks_d; double* tmp_ks_p; double* ks_d_ref;
-  int32_t* order; uint8_t* cls; uint8_t* tied; int32_t* meta;   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
+  int32_t* order; int32_t* redo; uint8_t* cls; uint8_t* tied; int32_t* meta;   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
   int64_t bytes;
 };
 constexpr int kMetaInts = 256;
 constexpr int kMetaMax = 3 * kClassStride;      // [168..169] max n0 / n1
 constexpr int kMetaBigTotal = kMetaMax + 2;     // [170..171] u64: scratch floats the large positions need
 constexpr int kMetaBigCursor = kMetaMax + 4;    // [172..173] u64: bump allocator of big_rank_kernel
+constexpr int kMetaWideRedo = kMetaMax + 8;     // [176] positions on the WIDE form's redo list (wide_redo_kernel)
 constexpr int kMetaRedo = 184;                  // float64 front end: [184] count of positions to redo, [184 + kClassStride] = 0 (their
                                                 // offset in the list), [242..243] u64 scratch keys they need, [244..245] u64 bump allocator
 constexpr int kMetaRedoTotal = 242, kMetaRedoCursor = 244;
-static_assert(kMetaRedo + kClassStride < kMetaRedoTotal && kMetaRedoCursor + 2 <= kMetaInts && kMetaBigCursor + 2 <= kMetaRedo, "meta layout");
+static_assert(kMetaRedo + kClassStride < kMetaRedoTotal && kMetaRedoCursor + 2 <= kMetaInts && kMetaBigCursor + 2 <= kMetaWideRedo && kMetaWideRedo < kMetaRedo, "meta layout");
 // (kBigClass, kBigHistClass, kWideBigBase .., kNumPairs: rank_stats_launch.hpp)
 static_assert(kNumPairs <= kClassStride, "class tables");
 
@@ -92,6 +93,7 @@ static Workspace carve(void* base, int64_t npos) {
   w.tmp_ks_p = (double*)take(8 * npos);
   w.ks_d_ref = (double*)take(8 * npos);
   w.order = (int32_t*)take(4 * npos);
+  w.redo = (int32_t*)take(4 * npos);
   w.cls = (uint8_t*)take(npos);
   w.tied = (uint8_t*)take(npos);
   w.meta = (int32_t*)take(kMetaInts * 4);
@@ -472,6 +474,17 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   ra.npos = npos; ra.ks_num = ws.ks_num; ra.mwu_s = ws.mwu_s; ra.tie = ws.tie; ra.moments = ws.moments; ra.ks_d_ref = ws.ks_d_ref;
   ra.ks_rational_d = (!all && (prm->flags & NMOD_FLAG_KS_RATIONAL_D)) ? 1 : 0;
   ra.tied = f64 ? ws.tied : nullptr;            // float32 keys of float64 samples: K1 reports the positions whose keys tie
+  ra.redo_list = ws.redo; ra.redo_count = ws.meta + kMetaWideRedo;
+  // the WIDE float32 form may put positions on its redo list: wide_redo_kernel finishes them (count read on the device)
+  auto launch_wide_redo = [&]() -> int {
+    WideRedoArgs wr;
+    wr.sig0 = sig0; wr.sig1 = sig1; wr.off0 = off0; wr.off1 = off1; wr.stride0 = ra.stride0; wr.stride1 = ra.stride1;
+    wr.list = ws.redo; wr.count = ws.meta + kMetaWideRedo; wr.tie = ws.tie;
+    hipLaunchKernelGGL(wide_redo_kernel, dim3((unsigned)std::min<int64_t>(npos, (int64_t)num_cus * 2)), dim3(kBigThreads), 0, stream, wr);
+    NMOD_HIP(hipGetLastError());
+    return NMOD_OK;
+  };
+  const bool wide_f32 = all && prm->dtype == NMOD_DTYPE_F32;
 
   auto launch = [&](int cls, int64_t work) -> hipError_t {
     ra.class_id = cls;
@@ -484,8 +497,12 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
 
   DevScratch big_scratch;
   if (uniform && !big_possible) {
+    const int ucls = all ? launch_class_of(cmax0, cmax1) : kKsClassBase + std::min(cmax0, cmax1);
+    const bool uwide = wide_f32 && wide_class(ucls);
+    if (uwide && !meta_cleared && !f64) NMOD_HIP(hipMemsetAsync(ws.meta + kMetaWideRedo, 0, 4, stream));   // (the meta block is not cleared for uniform batches)
     ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
-    NMOD_HIP(launch(all ? launch_class_of(cmax0, cmax1) : kKsClassBase + std::min(cmax0, cmax1), npos));
+    NMOD_HIP(launch(ucls, npos));
+    if (uwide) { const int rr = launch_wide_redo(); if (rr != NMOD_OK) return rr; }
   } else {
     BinArgs ba;
     ba.npos = npos; ba.off0 = off0; ba.off1 = off1; ba.stride0 = ra.stride0; ba.stride1 = ra.stride1;
@@ -506,11 +523,16 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
       NMOD_HIP(launch(cls, npos));
     }
     if (big_possible && all) {
-      // larger group of 2 049 .. 4 096 samples against at most 256: the two-pass form of rank_hist_kernel WIDE
+      // larger group of 2 049 .. 4 096 samples against at most 256: rank_hist_kernel WIDE as well
       for (int cs = 0; cs < kNumWideBig; ++cs) {
         ra.pos_list = ws.order; ra.class_meta = ws.meta;
         NMOD_HIP(launch(kWideBigBase + cs, npos));
       }
+    }
+    if (wide_f32) {
+      bool any_wide = big_possible;
+      for (int cls = 0; cls < kNumClasses && !any_wide; ++cls) any_wide = wanted[cls] && wide_class(cls);
+      if (any_wide) { const int rr = launch_wide_redo(); if (rr != NMOD_OK) return rr; }
     }
     if (big_possible) {
       // the only host round trip of this path: how many large positions, how much scratch

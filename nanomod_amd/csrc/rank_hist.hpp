@@ -182,10 +182,6 @@ __device__ __forceinline__ unsigned pos_allsum_u32(unsigned v) {     // sum over
 // twice: the values are split by one more hash bit and Q is streamed once per half.  int16: no hash — one 8-bit counter
 // per VALUE of a window of the milli-unit domain (see the streaming section below).
 constexpr unsigned kWideEmpty = 0xffffffffu;
-#ifndef NMOD_WIDE_PROBES
-#define NMOD_WIDE_PROBES 2
-#endif
-constexpr int kWideProbes = NMOD_WIDE_PROBES;      // steps of a walk before the sample is deferred
 constexpr int kWideList = 128;                     // words of the deferred list: < 64 waiting + <= 64 of one sample slot
 
 template <int R, int LG, int DTYPE, bool WIDE = false>
@@ -200,13 +196,7 @@ void rank_hist_kernel(RankStatsArgs args) {
   using Lay = KsLayout<R, LG>;
   constexpr int ROW = Lay::ROW;
   constexpr int BIN_WORDS = WIDE ? ((ks_rank_pos_words(R, LG) + 3) & ~3) : ks_rank_pos_words(R, LG);   // keys + bins of a position
-  int wide_passes = 1;                                                             // WIDE: hash passes over Q
-  if constexpr (WIDE) {
-    // (float32) Q of 2 049 .. 4 096 samples: two passes, half of the values each
-    if (DTYPE == 0 && args.class_id >= kWideBigBase) wide_passes = 2;
-  }
   const int wslots = WIDE ? wide_table_words(args.class_id, DTYPE) : 0;           // words of the wave's tie table
-  const unsigned nslots = (unsigned)wide_table_slots(wslots);                      // float32: hash slots in use (a prime)
   const int POS_WORDS = BIN_WORDS + wslots + ((WIDE && DTYPE == 0) ? kWideList : 0);   // WIDE: the table (float32: and the deferred list) behind them, 16-byte aligned
   constexpr int HIST_OFF = Lay::REGION;        // words from key 0 to bin 0
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
@@ -413,7 +403,8 @@ void rank_hist_kernel(RankStatsArgs args) {
       }
     };
 
-    unsigned ppq = 0;                              // WIDE: ties inside Q from the hash table
+    unsigned ppq = 0;                              // WIDE: ties inside Q (counters / exact table of the bitmap form)
+    bool redo_flag = false;                        // WIDE float32: the position went on the redo list (wide_redo_kernel adds Q's ties)
     double s1w = 0.0, s2w = 0.0;                   // WIDE: Q's shifted moment sums
     // WIDE: the direct-address tie counters (int16 input, and float32 input on the milli-unit grid).  The wave's table holds
     // one 8-bit counter per VALUE of a window of the milli-unit domain (four per 32-bit word): one returning LDS add per
@@ -529,20 +520,21 @@ void rank_hist_kernel(RankStatsArgs args) {
       unsigned* ht = reinterpret_cast<unsigned*>(keys) + BIN_WORDS;
       const float kqf = (q > 0) ? (float)rk : 0.0f;
       const double KQ = (double)kqf;
-      // The multiset table: an arrival walks its value's double-hashing sequence (start and odd step from the value
-      // alone, so every copy of a value walks the same slots) past all earlier copies to the first empty slot; `dup` =
-      // the copies it passed, it is the (dup + 1)-th of its value.  A wave pays for the LONGEST walk of its lanes, so the
-      // walks are cut after kWideProbes steps: a sample that has not found its slot by then is put on a list in LDS and
-      // starts again later, 64 deferred samples at a time, one per lane, to the end of their walks.  (Each copy of a
-      // value still gets its own place p in 1..b whatever the order of arrival, so the sum of p (p - 1) is the same.)
-      unsigned* lst = ht + wslots;                   // the deferred samples (kWideList words)
+      // The exact multiset table of the bitmap form (below): a sample walks its value's double-hashing sequence (start and odd
+      // step from the value alone, so every copy of a value walks the same slots) past all earlier copies to the first empty
+      // slot; `dup` = the copies it passed, it is the (dup + 1)-th of its value: p (p - 1) = dup (dup + 1).  Only the few samples
+      // on shared bitmap bits come here, from a list in LDS, 64 at a time, one per lane.  (Until round 4 EVERY sample of Q went
+      // through such a table, two compare-and-swaps each: half of this form's time.)
+      constexpr int W1 = 1024;                       // words of B1 (the table's words in pass 2) and of B2 behind it: 32 768 bits each
+      constexpr unsigned SH = 17u;                   // bit index = the top 15 bits of the multiplicative hash
+      constexpr unsigned tslots = (unsigned)wide_table_slots(W1);     // 1 021, a prime: any step visits every slot
+      static_assert(2 * W1 <= wide_table_words(0, 0) && wide_table_words(0, 0) * 4 >= 8192, "two bitmaps; a counter window of 8 192 values");
+      unsigned* B2 = ht + W1;
+      unsigned* lst = ht + wslots;                   // the samples on shared bits that wait for their walk (kWideList words)
       int lcnt = 0;                                  // how many (the same in every lane)
-      // (the table size is a prime, not a power of two — 1 597 slots for Q <= 1 024, 3 067 for Q <= 2 048: five and three
-      // blocks per CU instead of four and two; any step in 1 .. nslots - 1 visits every slot: here 1 .. 512)
-      unsigned tslots = nslots;                      // slots of the table the deferred walks use (the bitmap mode's is smaller)
       auto walk_to_end = [&](unsigned bits, bool act) {
         const unsigned hsh = bits * 2654435761u;
-        unsigned hh = ((hsh >> 13) * tslots) >> 19;         // 19 hash bits x at most 4 099 slots: (2^19 - 1) * 4 099 < 2^32, no wrap
+        unsigned hh = ((hsh >> 13) * tslots) >> 19;         // 19 hash bits x 1 021 slots: below 2^32
         const unsigned st = 1u + (hsh & 511u);
         unsigned dup = 0u;
         while (__ballot(act) != 0ull) {
@@ -552,7 +544,7 @@ void rank_hist_kernel(RankStatsArgs args) {
           hh += st;
           hh = min(hh, hh - tslots);                          // (below tslots the difference wraps to a huge value)
         }
-        ppq += dup * (dup + 1u);                     // the p-th of its value, p = dup + 1: p (p - 1)
+        ppq += dup * (dup + 1u);
       };
       auto drain = [&](int n) {                      // the last n <= 64 entries of the list
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -562,118 +554,20 @@ void rank_hist_kernel(RankStatsArgs args) {
         const unsigned bits = lst[lcnt + (act ? lane : 0)];
         walk_to_end(bits, act);
       };
-      auto insert_many = [&](auto nv_tag, const float* xq, const bool* have, int pass) {
-        constexpr int NV = decltype(nv_tag)::value;
-        unsigned hh[NV], st[NV], bits[NV], dup[NV]; bool act[NV];
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          bits[e] = __float_as_uint(xq[e] + 0.0f);                             // (-0.0 -> +0.0: one key per value)
-          const unsigned hsh = bits[e] * 2654435761u;
-          hh[e] = ((hsh >> 13) * nslots) >> 19;                               // (19 bits: the product stays below 2^32 for every table size)
-          st[e] = 1u + (hsh & 511u);
-          // (two passes: the values are split by one more hash bit; each pass holds one half in the table)
-          const bool mine = wide_passes == 1 || ((hsh >> 9) & 1u) == (unsigned)pass;
-          dup[e] = 0u; act[e] = have[e] && mine;
-        }
-#if (NMOD_SKIP & (128 | 256))
-#pragma unroll
-        for (int e = 0; e < NV; ++e) act[e] = false;
-#endif
-        // kWideProbes steps for every sample, the NV compare-and-swaps of a step in flight together
-#pragma unroll
-        for (int t = 0; t < kWideProbes; ++t) {
-          unsigned old[NV];
-#pragma unroll
-          for (int e = 0; e < NV; ++e) old[e] = atomicCAS(&ht[hh[e]], kWideEmpty, act[e] ? bits[e] : kWideEmpty);
-#pragma unroll
-          for (int e = 0; e < NV; ++e) {
-            dup[e] += (act[e] && old[e] == bits[e]) ? 1u : 0u;
-            act[e] = act[e] && old[e] != kWideEmpty;
-            hh[e] += st[e];
-            hh[e] = min(hh[e], hh[e] - nslots);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          ppq += act[e] ? 0u : dup[e] * (dup[e] + 1u);                          // placed: p (p - 1); deferred: counted when it is
-          const unsigned long long m = __ballot(act[e]);
-          if (m != 0ull) {
-            const int at = lcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            if (act[e]) lst[at] = bits[e];
-            lcnt += __popcll(m);
-            if (lcnt >= 64) drain(64);
-          }
-        }
-      };
-      // the hash passes over Q; rank_first: the first pass also ranks the samples and sums their moments (false when the grid
-      // mode below has done that already and only the ties are counted again)
-      auto hash_passes = [&](bool rank_first) {
-#pragma unroll 1
-      for (int pass = 0; pass < wide_passes; ++pass) {
-        const bool first = rank_first && pass == 0;
+      // ---- Samples off the milli-unit grid (continuous signals): ties inside Q are rare.  Pass 1 (with the ranking and the
+      // moments when `rank` is set): every sample sets one bit of a bitmap B1 by a returning OR; a sample that finds its bit set
+      // marks the same bit in a second bitmap B2 — the bits that two or more samples share.  Equal samples share a bit, so every
+      // tied sample of Q sits on a B2 bit.  Pass 2 streams Q again (from L2), reads each sample's B2 bit, and only the samples on
+      // marked bits (~n^2 / bits: a few per cent) walk the exact table, which takes B1's words.  No B2 bit: no ties inside Q.
+      // More marked samples than that table takes at load 0.75 (thousands of equal samples off the grid): the position goes on
+      // the redo list and wide_redo_kernel counts its ties by sorting Q; the kernel here adds nothing for them.
+      auto bitmap_passes = [&](bool rank) {
         __builtin_amdgcn_wave_barrier();
-#if !(NMOD_SKIP & 256)
-        for (int i = lane; i < wslots / 4; i += 64)
-          reinterpret_cast<uint4*>(ht)[i] = make_uint4(kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty);
-#endif
-        if (!(rank_first && pass == 0)) {             // (Q streams again: the requests of the item's head have been consumed)
+        for (int i = lane; i < (2 * W1) / 4; i += 64) reinterpret_cast<uint4*>(ht)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (!rank) {                                 // (Q streams again: the requests of the item's head have been consumed)
           ra = load_q4(sig_q, off_q, 4 * gl, 0 < full);
           rt = load_q1(sig_q, off_q, full * (4 * LG) + gl, full * (4 * LG) + gl < q);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-#pragma unroll 1
-        for (int c = 0; c < full_w; ++c) {
-          const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
-          float xa[4];
-          xa[0] = (float)ra.x; xa[1] = (float)ra.y; xa[2] = (float)ra.z; xa[3] = (float)ra.w;
-          const bool hv[4] = {true, true, true, true};
-          if (first) {
-            unsigned ad[4];
-#if !(NMOD_SKIP & 512)
-            rank_many(std::integral_constant<int, 4>{}, xa, true, ad);
-#endif
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const double d = (double)xa[e] - KQ; s1w += d; s2w = __fma_rn(d, d, s2w); }
-          }
-          insert_many(std::integral_constant<int, 4>{}, xa, hv, pass);
-          ra = rb;
-        }
-#pragma unroll 1
-        for (int c = 0; c < tail_w; ++c) {
-          const int idx_now = full * (4 * LG) + c * LG + gl;
-          const bool have = idx_now < q;
-          const float xq1[1] = {have ? (float)rt : big};
-          const int idx = full * (4 * LG) + (c + 1) * LG + gl;
-          rt = load_q1(sig_q, off_q, idx, idx < q);
-          const bool hv[1] = {have};
-          if (first) {
-            unsigned a1[1];
-#if !(NMOD_SKIP & 512)
-            rank_many(std::integral_constant<int, 1>{}, xq1, have, a1);
-#endif
-            const double d = (double)(have ? xq1[0] : kqf) - KQ;
-            s1w += d; s2w = __fma_rn(d, d, s2w);
-          }
-          insert_many(std::integral_constant<int, 1>{}, xq1, hv, pass);
-        }
-        if (lcnt > 0) drain(lcnt);                   // what is still deferred belongs to this pass's half of the values
-      }
-      };
-      // ---- Samples off the grid (continuous signals): ties inside Q are rare, and the hash above pays two dependent
-      // compare-and-swaps per sample to find none.  Two cheap passes instead.  Pass 1 (with the ranking and the moments): every
-      // sample sets one bit of a bitmap B1 by a returning OR; a sample that finds its bit set marks the same bit in a second
-      // bitmap B2 — the bits that two or more samples share.  Equal samples share a bit, so every tied sample of Q sits on a
-      // B2 bit.  Pass 2 streams Q again (from L2), reads each sample's B2 bit, and only the samples on marked bits (~n^2 / bits:
-      // a few per cent) go through the exact multiset walk — into a table in B1's words, 64 at a time, one per lane.  No B2 bit:
-      // no ties inside Q at all.  Too many marked samples for that table (heavy ties off the grid): the hash passes above.
-      auto bitmap_passes = [&]() {
-        const int W1 = (wslots >= 4096) ? 2048 : 1024;             // words of B1 (and of B2 behind it): 32 768 or 65 536 bits
-        const unsigned SH = (W1 == 2048) ? 16u : 17u;              // bit index = the top bits of the multiplicative hash
-        unsigned* B2 = ht + W1;
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < (2 * W1) / 4; i += 64) reinterpret_cast<uint4*>(ht)[i] = make_uint4(0u, 0u, 0u, 0u);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -707,17 +601,18 @@ void rank_hist_kernel(RankStatsArgs args) {
         for (int c = 0; c < full_w; ++c) {
           const Q4Raw rb = load_q4(sig_q, off_q, (c + 1) * (4 * LG) + 4 * gl, c + 1 < full);
           const float xa[4] = {ra.x, ra.y, ra.z, ra.w};
-          unsigned ad[4];
+          if (rank) {
+            unsigned ad[4];
 #if !(NMOD_SKIP & 512)
-          rank_many(std::integral_constant<int, 4>{}, xa, true, ad);
+            rank_many(std::integral_constant<int, 4>{}, xa, true, ad);
 #endif
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const double d = (double)xa[e] - KQ; s1w += d; s2w = __fma_rn(d, d, s2w); }
+            for (int e = 0; e < 4; ++e) { const double d = (double)xa[e] - KQ; s1w += d; s2w = __fma_rn(d, d, s2w); }
+          }
           { const bool hv[4] = {true, true, true, true}; mark_many(std::integral_constant<int, 4>{}, xa, hv); }
           ra = rb;
         }
-        // the first rounds of pass 2 are requested HERE, before the tail rounds of pass 1: a position is only ~4 full rounds
-        // long, so a request at the head of pass 2 exposes one L2 round trip per position (6.6 of 46.6 ms on configs[4])
+        // the first rounds of pass 2 are requested HERE, before the tail rounds of pass 1 (a position is only ~4 full rounds long)
         constexpr int PF = 4;
         Q4Raw buf[PF];
 #pragma unroll
@@ -730,12 +625,14 @@ void rank_hist_kernel(RankStatsArgs args) {
           const float xq1[1] = {have ? (float)rt : big};
           const int idx = full * (4 * LG) + (c + 1) * LG + gl;
           rt = load_q1(sig_q, off_q, idx, idx < q);
-          unsigned a1[1];
+          if (rank) {
+            unsigned a1[1];
 #if !(NMOD_SKIP & 512)
-          rank_many(std::integral_constant<int, 1>{}, xq1, have, a1);
+            rank_many(std::integral_constant<int, 1>{}, xq1, have, a1);
 #endif
-          const double d = (double)(have ? xq1[0] : kqf) - KQ;
-          s1w += d; s2w = __fma_rn(d, d, s2w);
+            const double d = (double)(have ? xq1[0] : kqf) - KQ;
+            s1w += d; s2w = __fma_rn(d, d, s2w);
+          }
           { const bool hv[1] = {have}; mark_many(std::integral_constant<int, 1>{}, xq1, hv); }
         }
         const unsigned total_hits = pos_allsum_u32<64>(hits);
@@ -743,10 +640,9 @@ void rank_hist_kernel(RankStatsArgs args) {
         return;                                                    // (timing experiment: no second pass)
 #endif
         if (total_hits == 0u) return;                              // no two samples on one bit: no ties inside Q
-        tslots = (unsigned)wide_table_slots(W1);
-        if (2u * total_hits + 64u > tslots / 2u) {                 // (a bit shared by c samples: c - 1 hits, c <= 2 (c - 1) samples to walk)
-          tslots = nslots;
-          hash_passes(false);
+        if (2u * total_hits + 64u > (3u * tslots) / 4u) {          // (a bit shared by c samples: c - 1 hits, c <= 2 (c - 1) samples to walk)
+          if (valid && lane == 0) args.redo_list[atomicAdd(args.redo_count, 1)] = (int32_t)pos;
+          redo_flag = true;
           return;
         }
         // pass 2: B1's words become the exact table; B2 stays
@@ -756,9 +652,8 @@ void rank_hist_kernel(RankStatsArgs args) {
         rt = rt2;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // a sample on a marked bit waits in a register of its lane (`pend`); the waiting samples of all lanes go to the deferred
-        // list together when some lane gets a second one (a ballot + branch per sample slot instead of a compaction per slot:
-        // 3 % of the samples are on marked bits, but nearly every slot of 64 lanes holds one)
+        // a sample on a marked bit waits in a register of its lane (`pend`); the waiting samples of all lanes go to the list
+        // together when some lane gets a second one (a ballot + branch per sample slot instead of a compaction per slot)
         unsigned pend = 0u;
         bool full_l = false;
         auto flush = [&]() {
@@ -821,17 +716,12 @@ void rank_hist_kernel(RankStatsArgs args) {
         }
         flush();
         if (lcnt > 0) drain(lcnt);
-        tslots = nslots;
       };
       if (!s_grid) {
-#if defined(NMOD_NO_BITMAP)
-        hash_passes(true);
-#else
-        bitmap_passes();
-#endif
+        bitmap_passes(true);
       } else {
         // ---- S is on the milli-unit grid: rank and sum the moments as above, count Q's ties by VALUE with the direct-address
-        // counters of the int16 form (window of 4 x wslots >= 8 192 values centred on the median of S) — as long as every
+        // counters of the int16 form (window of 4 x wslots = 8 192 values centred on the median of S) — as long as every
         // sample of Q is on the grid too
         const int wb = (int)__builtin_rintf(__fmul_rn(keys[Lay::word(m >> 1)], 1000.0f)) - 2 * wslots;
         bool offl = false;                            // this lane saw a sample of Q off the grid
@@ -874,13 +764,13 @@ void rank_hist_kernel(RankStatsArgs args) {
           const bool hv[1] = {have && ok};
           count_many(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, iv1, hv, wb);
         }
-        if (__ballot(offl) != 0ull) {                 // Q has samples off the grid: its ties through the hash after all
+        if (__ballot(offl) != 0ull) {                 // Q has samples off the grid: its ties through the bitmaps after all
           ppq = 0u;
-          hash_passes(false);
+          bitmap_passes(false);
         } else if (redo != 0ull) {
           if (!recount16([&](int i, bool have) { int k; grid_key<false>((float)load_q1(sig_q, off_q, i, have), k); return k; })) {
-            ppq = 0u;                                 // keys over more than 65 535 milli-units: the hash
-            hash_passes(false);
+            ppq = 0u;                                 // keys over more than 65 535 milli-units: the bitmaps
+            bitmap_passes(false);
           }
         }
       }
@@ -1216,7 +1106,7 @@ void rank_hist_kernel(RankStatsArgs args) {
       args.tie[pos] = 3ull * PP + 3ull * AB;
       args.ks_d_ref[pos] = (m > 0 && q > 0) ? dmax : 0.0;
       args.ks_num[pos] = (m > 0 && q > 0) ? best : 0u;
-      if (args.tied) args.tied[pos] = (PP != 0ull || AB != 0ull) ? 1 : 0;   // any two samples of the position compare equal
+      if (args.tied) args.tied[pos] = (PP != 0ull || AB != 0ull || redo_flag) ? 1 : 0;   // any two samples of the position compare equal (a position on the redo list: not known here)
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0x0F70);

@@ -42,6 +42,7 @@ struct RankStatsArgs {
   int32_t ks_rational_d;                       // KS-only mode: skip the float form of D (NMOD_FLAG_KS_RATIONAL_D)
   double* ks_d_ref;                            // [npos] max |fl(c0/n0) - fl(c1/n1)| exactly as ks_2samp forms it (all-tests mode)
   uint8_t* tied;                               // [npos] or null: 1 where the position's keys tie (see ks_rank_kernel FLAGS; all-tests: any tie)
+  int32_t* redo_list; int32_t* redo_count;     // WIDE float32 form: positions whose streamed group's ties are counted by wide_redo_kernel
 };
 
 // compare-exchange of two registers.  (fminf / fmaxf put a canonicalising v_max x, x in front of every value of unknown

@@ -45,27 +45,18 @@ inline bool wide_class(int cls) {
   if (cls >= kWideBigBase) return cls < kWideBigBase + kNumWideBig;
   return cls < kNumGeneralClasses && (cls / kNumSizeClasses <= 2 || cls % kNumSizeClasses <= 2);
 }
-// 32-bit words of a wave's tie table in the WIDE form (rank_hist.hpp).  int16: direct-address counters over a window of the
-// value domain, NMOD_WIDE_I16_WORDS words for every class.  float32: the multiset hash table; its slots in use are the
-// largest prime below the words (double hashing with any step then visits every slot), sized by the class of the larger
-// group: Q <= 1 024: 2 048 (2 039; four blocks per CU — 1 600 words = five blocks
-// measured no faster); Q <= 2 048: 2 056 (2 053: see wide_table_words; until round 4 3 068 words, three blocks per CU); the two-pass classes (Q <= 4 096, split by a hash bit): 4 100 (4 099: a pass may receive every sample).
+// 32-bit words of a wave's tie table in the WIDE form (rank_hist.hpp): see wide_table_words.
 #ifndef NMOD_WIDE_I16_WORDS
 #define NMOD_WIDE_I16_WORDS 2048                   // 8 192 values, four blocks per CU (1 912 words = five blocks: measured 10 % slower)
 #endif
 __host__ __device__ constexpr int wide_table_words(int cls, int dtype) {
-  if (dtype == 1) return NMOD_WIDE_I16_WORDS;
-#if defined(NMOD_WIDE_POW2)
-  if (cls >= kWideBigBase) return 4096;
-  { const int a = cls / kNumSizeClasses, b = cls % kNumSizeClasses; return 128 << (a < b ? b : a); }
-#endif
-  if (cls >= kWideBigBase) return 4100;            // (one pass may receive all 4 096 samples: every sample one value)
-  const int c0 = cls / kNumSizeClasses, c1 = cls % kNumSizeClasses;
-  const int cq = c0 < c1 ? c1 : c0;
-  // Q <= 1 024: 2 048 words; Q <= 2 048: 2 056 (2 053 slots: the hash passes — since round 4 only the fall-back for heavy ties off the
-  // milli-unit grid — run at load <= 1 there, and the class fits FOUR blocks per CU instead of the three of 3 068 words: +10 % on
-  // configs[4], where it holds 43 % of the positions; the bitmaps need 2 048 words, the counters' window is four values per word)
-  return cq <= 4 ? 2048 : 2056;
+  // int16: NMOD_WIDE_I16_WORDS (counters over 8 192 values).  float32 (round 4): 2 048 words for every class — the two bitmaps of
+  // the bitmap form (B1's words double as the exact table of the few samples on shared bits), the counters of the grid form
+  // (8 192 values); the multiset hash that sized the table by the class of the larger group (up to 4 100 words: two blocks per
+  // CU for groups beyond 2 048 samples) is gone — a position with more shared bits than the exact table takes is finished by
+  // wide_redo_kernel.  Every class of R = 1, 2 fits four blocks per CU (+6.5 % on configs[4] over 3 068 / 4 100 words).
+  (void)cls;
+  return dtype == 1 ? NMOD_WIDE_I16_WORDS : 2048;
 }
 __host__ __device__ constexpr int wide_table_slots(int words) {
   switch (words) {
@@ -82,9 +73,6 @@ __host__ __device__ constexpr int wide_table_slots(int words) {
     default: return words > 8 ? (words - 1) | 1 : 7;     // (not reached: every size above has its prime)
   }
 }
-// (a table never fills: a class's slots hold every sample the larger group can have, even when all are one value)
-static_assert(wide_table_slots(wide_table_words(0 * kNumSizeClasses + 3, 0)) >= 512 && wide_table_words(0, 0) * 4 >= 8192 && wide_table_slots(wide_table_words(0 * kNumSizeClasses + 4, 0)) >= 1024 &&
-              wide_table_slots(wide_table_words(0 * kNumSizeClasses + 5, 0)) >= 2048 && wide_table_slots(wide_table_words(kWideBigBase, 0)) >= kWideBigMaxQ, "tie table sizes");
 inline int wide_class_of_s(int cls) {              // capacity class of the smaller group of a WIDE class
   if (cls >= kWideBigBase) return cls - kWideBigBase;
   return cls / kNumSizeClasses < cls % kNumSizeClasses ? cls / kNumSizeClasses : cls % kNumSizeClasses;

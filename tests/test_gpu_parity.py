@@ -486,6 +486,46 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
         assert buf.value == want, (a, b, buf.value)
 
 
+def test_wide_redo_list_random_heavy_ties(nm):
+    """the WIDE float32 form's redo list (wide_redo_kernel): streamed groups of 300 .. 4 096 samples drawn from a handful to a
+    few hundred distinct values OFF the milli-unit grid — more samples on shared bitmap bits than the exact table takes — mixed
+    with continuous positions and positions on the grid in one batch, either group the larger one, CSR and fixed stride"""
+    import nanomod_oracle as orc
+    rng = np.random.default_rng(2024)
+    ca, cb = [], []
+    for i in range(48):
+        small = int(rng.integers(3, 257)); large = int(rng.integers(300, 4097))
+        kind = i % 4
+        if kind == 0:                                             # continuous
+            x = rng.normal(0, 1, small); y = rng.normal(0.1, 1.1, large)
+        elif kind == 1:                                           # on the grid
+            x = np.round(rng.normal(0, 1, small), 3); y = np.round(rng.normal(0.1, 1.1, large), 3)
+        else:                                                     # few distinct values off the grid (multiples of an odd step)
+            nvals = int(rng.choice([2, 7, 40, 300]))
+            vals = (rng.permutation(4 * nvals)[:nvals] - 2 * nvals) * 0.013700001
+            y = rng.choice(vals, large); x = rng.choice(np.r_[vals[: max(1, nvals // 2)], rng.normal(0, 1, 5)], small)
+        if i % 3 == 0:
+            x, y = y, x
+        ca.append(x.astype(np.float32)); cb.append(y.astype(np.float32))
+    off0 = np.zeros(len(ca) + 1, np.int64); off0[1:] = np.cumsum([len(c) for c in ca])
+    off1 = np.zeros(len(cb) + 1, np.int64); off1[1:] = np.cumsum([len(c) for c in cb])
+    sig0, sig1 = np.concatenate(ca), np.concatenate(cb)
+    rid = np.zeros(len(ca), np.int32)
+    got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=1, weights_dif=2.0, method='fisher')
+    exp = orc.detect_batch(sig0, off0, sig1, off1, rid, 1, 2.0, orc.METHOD_FISHER)
+    H.compare_outputs(got, exp, True)
+    assert np.array_equal(got['status'], exp['status'])
+    # fixed stride (no class lists, no cleared counters between batches): 40 v 3 000, every position heavy; twice in a row
+    P, n0, n1 = 64, 40, 3000
+    vals = np.arange(-6, 7) * np.float32(0.0771)
+    a = rng.choice(vals, P * n0).astype(np.float32); b = rng.choice(vals, P * n1).astype(np.float32)
+    o0 = np.arange(0, (P + 1) * n0, n0, dtype=np.int64); o1 = np.arange(0, (P + 1) * n1, n1, dtype=np.int64)
+    exp = orc.detect_batch(a, o0, b, o1, np.zeros(P, np.int32), 1, 2.0, orc.METHOD_FISHER)
+    for _ in range(2):
+        got = nm.detect_host(a, None, b, None, np.zeros(P, np.int32), nb=1, weights_dif=2.0, method='fisher', stride0=n0, stride1=n1)
+        H.compare_outputs(got, exp, True)
+
+
 @pytest.mark.parametrize('grid', [False, True])
 def test_large_positions_all_tests_and_ks_only(nm, grid):
     """positions beyond the wave-resident kernels (> 2048 samples in a sorted group) take big_rank_kernel: LDS sort

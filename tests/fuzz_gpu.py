@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz of the HIP path against the C oracle (run on the GPU box: python tests/fuzz_gpu.py [rounds]).
 Random ragged batches: group sizes from 1 to ~9000 with random size ranges per batch, continuous / gridded /
-heavily tied values, optional int16 input (also heavily tied and spread over the whole domain), both test masks.  Test infrastructure, like everything under oracle/."""
+heavily tied values on and off the milli-unit grid, float32 values beside / beyond the grid, optional int16 input (also heavily tied and spread over the whole domain), both test masks.  Test infrastructure, like everything under oracle/."""
 import os
 import sys
 
@@ -23,7 +23,7 @@ def run_round(rng):
     hi1 = int(rng.choice([3, 8, 40, 64, 65, 130, 260, 600, 1100, 2048, 2500, 9000]))
     lo0 = int(rng.integers(1, hi0 + 1)) if rng.random() < 0.5 else 1
     lo1 = int(rng.integers(1, hi1 + 1)) if rng.random() < 0.5 else 1
-    mode = rng.choice(['cont', 'grid2', 'grid0', 'i16', 'i16t', 'i16w', 'f64', 'f64near'])
+    mode = rng.choice(['cont', 'grid2', 'grid0', 'grid3', 'offt', 'gmix', 'i16', 'i16t', 'i16w', 'f64', 'f64near'])
     npos = int(rng.integers(1, (400 if max(hi0, hi1) <= 600 else 40) // (4 if mode.startswith('f64') else 1) + 1))
     n0 = rng.integers(lo0, hi0 + 1, npos); n1 = rng.integers(lo1, hi1 + 1, npos)
     off0 = np.zeros(npos + 1, np.int64); off0[1:] = np.cumsum(n0)
@@ -33,6 +33,16 @@ def run_round(rng):
         a, b = np.round(a, 2), np.round(b, 2)
     elif mode == 'grid0':
         a, b = np.round(a, 0), np.round(b, 0)
+    elif mode == 'grid3':                     # float32 on the milli-unit grid of real events (the counters of the WIDE form)
+        a, b = np.round(a, 3), np.round(b, 3)
+    elif mode == 'offt':                      # heavy ties OFF the milli-unit grid: the bitmap form's exact table or its redo list
+        step = float(rng.choice([0.0137, 0.25001, 0.7003]))
+        a, b = np.round(a / step) * step, np.round(b / step) * step
+    elif mode == 'gmix':                      # on the grid, except some samples: off it by chance, by one float32 ulp, or far away
+        a, b = np.round(a, 3), np.round(b, 3)
+        for v in (a, b):
+            k = rng.random(len(v)) < rng.choice([0.0005, 0.01, 0.3])
+            v[k] = rng.choice([1.0, 7.0, 33.0, 4e4]) * rng.normal(0, 1, int(k.sum()))
     if mode == 'i16t':                        # int16 with heavy ties: up to hundreds of copies of a value (8-bit counters wrap)
         a, b = np.round(a, 1), np.round(b, int(rng.integers(0, 3)))
     elif mode == 'i16w':                      # int16 over most of the domain: many count windows
@@ -49,7 +59,10 @@ def run_round(rng):
             s1[:k] = s0[idx] * (1.0 + rng.choice([0.0, 2.0 ** -30, -2.0 ** -40], k))
         r0, r1 = s0, s1
     else:
-        s0 = a.astype(np.float32); s1 = b.astype(np.float32); r0, r1 = s0, s1
+        s0 = a.astype(np.float32); s1 = b.astype(np.float32)
+        if mode == 'gmix' and len(s0) > 3 and len(s1) > 3:
+            s0[::97] = np.nextafter(s0[::97], np.float32(1e9)); s1[1::53] = np.nextafter(s1[1::53], np.float32(-1e9))
+        r0, r1 = s0, s1
     rid = np.cumsum(rng.random(npos) < 0.1).astype(np.int32)
     nb = int(rng.integers(0, 4)); method = str(rng.choice(['stouffer', 'fisher']))
     if s0.dtype == np.float64:                # the C oracle takes float32 / int16: the numpy restatement on the doubles

@@ -174,15 +174,14 @@ __device__ __forceinline__ unsigned pos_allsum_u32(unsigned v) {     // sum over
 // smaller one S of at most 256 samples, the other Q of up to 4 096 (config 5: ~1000 v ~50 reads).  S is sorted and
 // ranked into exactly as above; Q streams through the ranking rounds in a loop (nothing of it is kept), and the ties
 // inside Q — the scatter + clean-up needs Q to fit the words of S — are counted in a per-wave table in LDS behind the
-// bins.  float32: a hash table, open addressing that inserts EVERY sample (a multiset): an arrival passes all earlier
-// copies of its key on the way along the key's probe sequence to the first empty slot, so it knows its place p in its
-// run and adds p (p - 1).  The table's size follows the capacity class of Q (the larger of the launch's two classes,
-// args.class_id; rank_stats_launch.hpp: wide_table_words / wide_table_slots — a prime number of slots, never fewer than
-// the samples a pass can receive).  A Q of 2 049 .. 4 096 samples (classes kWideBigBase + class of S) takes its table
-// twice: the values are split by one more hash bit and Q is streamed once per half.  int16: no hash — one 8-bit counter
-// per VALUE of a window of the milli-unit domain (see the streaming section below).
+// bins (wide_table_words: 2 048 words = 8 KB per wave for every class, four blocks per CU).  int16, and float32 positions on
+// the milli-unit grid of real events (grid_key): one 8-bit counter per VALUE of a window of 8 192 milli-units, a returning add per
+// sample gives its place p in its run.  float32 otherwise: two bitmaps — a sample sets its bit in the first and, when the bit was
+// already set, marks it in the second; a second pass over Q sends only the samples on marked bits through an exact multiset
+// table (open addressing: an arrival passes all earlier copies of its key and adds p (p - 1)); a position with more of them than
+// that table takes goes on a redo list for wide_redo_kernel (big_rank.hpp).  See the streaming section below.
 constexpr unsigned kWideEmpty = 0xffffffffu;
-constexpr int kWideList = 128;                     // words of the deferred list: < 64 waiting + <= 64 of one sample slot
+constexpr int kWideList = 128;                     // words of the list in front of the exact table: < 64 waiting + <= 64 of one flush
 
 template <int R, int LG, int DTYPE, bool WIDE = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (WIDE ? 2 : (R <= 16 ? NMOD_HIST_WAVES : 2)))

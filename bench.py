@@ -278,7 +278,7 @@ def gpu_local_cpus(torch, dev_index):
         return None
 
 
-def host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out):
+def host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out, flags=0):
     """The host-resident entry (NMOD_MEM_HOST; what a drop-in mtest2 hands over — everything on this path is host memory in
     the reference, myDetect.py:416-445) on the SAME rows as the headline: pageable numpy arrays, the same arrays page-locked
     in place, and int16 milli-unit arrays.  The path is PCIe-bound, so its roofline is the pinned hipMemcpy rate, measured
@@ -303,7 +303,7 @@ def host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests,
     except (AttributeError, OSError):
         near = None
     try:
-        return _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out, near)
+        return _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out, near, flags)
     finally:
         if old_aff is not None:
             try:
@@ -312,7 +312,7 @@ def host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests,
                 pass
 
 
-def _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out, near):
+def _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests, want_i16, ref_out, near, flags):
     import ctypes
     import numpy as np
     L = nm._lib
@@ -342,7 +342,8 @@ def _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests
         best, st, res = None, None, None
         for _ in range(reps):                        # (the result arrays of the first call are written again by the next ones)
             t0 = time.perf_counter()
-            res = nm.detect_host(a, None, b, None, rid, nb=nb, weights_dif=wdif, method=method, tests=tests, stride0=n0, stride1=n1, device=dev_index, out=res)
+            res = nm.detect_host(a, None, b, None, rid, nb=nb, weights_dif=wdif, method=method, tests=tests, stride0=n0, stride1=n1, device=dev_index, out=res,
+                                 flags=flags)
             dt = time.perf_counter() - t0
             if best is None or dt < best:
                 best = dt
@@ -376,7 +377,7 @@ def _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests
             cudart.cudaHostUnregister(x.ctypes.data)
     if want_i16 and a.dtype == np.float32:
         # the same rows as int16 milli-units (the format of real events): device pass for the check, then the host entry
-        det16 = nm.DeviceDetector(dev_index, nb=nb, weights_dif=wdif, method=method, tests=tests)
+        det16 = nm.DeviceDetector(dev_index, nb=nb, weights_dif=wdif, method=method, tests=tests, flags=flags)
         q0 = torch.empty(npos * n0, dtype=torch.int16, device=dev); q1 = torch.empty(npos * n1, dtype=torch.int16, device=dev)
         det16.synth_fill(q0, SEED, b0['lo_h'], npos, 0, n0, PLANT_PERIOD, PLANT_SHIFT)
         det16.synth_fill(q1, SEED, b0['lo_h'], npos, 1, n1, PLANT_PERIOD, PLANT_SHIFT)
@@ -904,7 +905,7 @@ def main():
     host_path = None
     if world == 1 and not csr and not args.no_host_path and chunks == 1 and not args.force_collective:
         host_path = host_path_leg(nm, torch, local_rank, blocks, n0, n1, NB, WDIF, method, tests,
-                                  want_i16=(args.dtype == 'f32'), ref_out=blocks[0]['out'])
+                                  want_i16=(args.dtype == 'f32'), ref_out=blocks[0]['out'], flags=det.flags)
         bad = [k for k, v in host_path.items() if isinstance(v, dict) and v.get('equals_device_resident_pass') is False]
         if bad:
             verify['ok'] = False

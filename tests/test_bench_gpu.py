@@ -1,0 +1,47 @@
+"""-m gpu: bench.py end to end at small sizes — flag combinations whose legs interact (the rational-D flag through the side legs
+and the host-resident leg, the ragged preset with all tests on 3-decimal input, the forced collective with the boundary check):
+the line parses, every verification in it holds, the exit code is 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args):
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args + ['--steps', '2', '--warmup', '1', '--no-cpu'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_rational_d_flag_through_side_and_host_legs():
+    d = _bench(['--positions', '150000', '--rational-d'])
+    assert d['verify']['ok'] and 'NMOD_FLAG_KS_RATIONAL_D' in d['config']['ks_d']
+    assert all(d[k]['verify']['ok'] for k in ('all_tests', 'int16', 'real_ties'))
+    hp = d['host_path']
+    assert all(v['equals_device_resident_pass'] for v in hp.values() if isinstance(v, dict))
+    assert d['roofline']['bound'] == 'valu-issue' and d['build_info'].startswith('arch=gfx950')
+
+
+def test_default_line_carries_every_leg():
+    d = _bench(['--positions', '120000', '--side-legs', 'all_tests,int16,rational_d,real_ties'])
+    assert d['verify']['ok'] and 'library default' in d['config']['ks_d']
+    for k in ('all_tests', 'int16', 'rational_d', 'real_ties'):
+        assert d[k]['verify']['ok'] and d[k]['value'] > 0 and 0 < d[k]['roofline_frac'] < 1, k
+    assert d['host_path']['pageable_float32']['chunks'] >= 1 and d['host_path']['pinned_h2d_GBps'] > 1
+
+
+def test_ragged_all_tests_grid_input_and_forced_collective():
+    d = _bench(['--config', 'ragged', '--positions', '60000', '--all-tests', '--ties', 'real'])
+    assert d['verify']['ok'] and d['config']['layout'] == 'csr'
+    d = _bench(['--force-collective', '--config', 'ragged', '--positions', '60000', '--all-tests', '--chunks', '3'])
+    v = d['verify']
+    assert v['ok'] and v['gathered_track_equals_local'] and v['block_boundaries_checked'] == 2 and v['block_boundary_positions_differing'] == 0

@@ -203,6 +203,18 @@ int nmod_combine_track(const nmod_params* prm, int64_t npos,
                        const double* ks_d, const double* ks_p, const int32_t* run_id,
                        double* comb_st, double* comb_p);
 
+/* Replaces the down-sampling branch of getKStest (myDetect.py:345-361; taken when --coverages > 0 and a group exceeds the
+ * threshold) for `nflag` positions of a HOST-resident CSR batch (prm->memspace == NMOD_MEM_HOST): `iters` (--downsampling, 100)
+ * times, a group of position positions[i] with more than cov[i] samples is resampled WITH replacement to cov[i] samples
+ * (np.random.choice(x, cov)), KS runs on each resample, and the (D, p) pair at index int(iters * quantile)
+ * (--downsampling_quantile, 0.25) of the p-sorted resamples is written to ks_d[i] / ks_p[i].  The reference draws from numpy's
+ * unseeded global generator; here the draws are a counter-based function of (seed, i, iteration, group, draw) on the device —
+ * reproducible, statistically equivalent, not bit-comparable (SURVEY.md 8a row A3').  The resampled rows are materialised in
+ * HBM chunk by chunk (2^27 samples) and go through the same KS kernel as everything else.  Synchronises. */
+int nmod_downsample_ks(const nmod_params* prm, int64_t nflag, const void* sig0, const int64_t* off0, const void* sig1, const int64_t* off1,
+                       const int64_t* positions, const int64_t* cov, int32_t iters, double quantile, uint64_t seed,
+                       double* ks_d, double* ks_p);
+
 /* Benchmark input generator (no reference counterpart).
  * Counter-based and integer-only, so tests restate it bit-exactly on the CPU:
  *   h = mix64(seed, group, pos, read);  s = sum of the four 16-bit fields of h;

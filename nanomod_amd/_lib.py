@@ -77,6 +77,8 @@ _SIGNATURES = {
     'nmod_host_pipeline_config': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     'nmod_last_host_stats': (C.c_int, [C.POINTER(NmodHostStats)]),
     'nmod_build_info': (C.c_char_p, []),
+    'nmod_downsample_ks': (C.c_int, [C.POINTER(NmodParams), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p]),
     'nmod_describe_dispatch': (C.c_int, [C.POINTER(NmodParams), C.c_int64, C.c_int64, C.c_char_p, C.c_int32]),
     'nmod_write_sign_test': (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_void_p,
                                        C.c_char_p] + [C.c_void_p] * 10 + [C.c_int32]),

@@ -697,6 +697,60 @@ static int detect_f64(const nmod_params* prm, int64_t npos, const void* sig0, co
 
 #include "host_pipeline.hpp"
 
+
+// ---------------------------------------------------------------- down-sampling branch (myDetect.py:345-361)
+// Virtual rows: row v = (flagged position k, iteration it) of group g holds rsz[k] samples — drawn WITH replacement from the
+// position's rn[k] samples when rn[k] > rsz[k] (np.random.choice semantics), the samples themselves otherwise.  The draws are a
+// counter-based function of (seed, k, it, g, j): reproducible, any launch shape.
+struct ResampleArgs {
+  const char* rows; int esz; const int64_t* roff; const int32_t* rn; const int32_t* rsz; const int64_t* vbase;
+  int64_t nrows; int32_t iters; uint64_t seed; int32_t group; int64_t k0;      // k0: index of the chunk's first position among all flagged ones
+  char* out; int64_t* voff;                                                     // voff[nrows * iters + 1]: offsets of the virtual rows
+};
+__device__ __forceinline__ uint64_t draw_mix(uint64_t seed, int64_t k, int32_t it, int32_t g, uint32_t j) {
+  uint64_t x = seed + 0x9E3779B97F4A7C15ull * (uint64_t)((k * 2 + g) * 1000003ll + it);
+  x ^= (uint64_t)j * 0xD1B54A32D192ED03ull;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+__global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nv = a.nrows * a.iters;
+  for (int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); v < nv; v += (int64_t)gridDim.x * 4) {
+    const int64_t k = v / a.iters;
+    const int32_t it = (int32_t)(v - k * a.iters);
+    const int n = a.rn[k], sz = a.rsz[k];
+    const int64_t vo = a.vbase[k] + (int64_t)it * sz;
+    if (lane == 0) { a.voff[v] = vo; if (v == nv - 1) a.voff[nv] = vo + sz; }
+    const char* src = a.rows + a.roff[k] * a.esz;
+    char* dst = a.out + vo * a.esz;
+    const bool draw = n > sz;
+    for (int j = lane; j < sz; j += 64) {
+      int64_t idx = j;
+      if (draw) idx = (int64_t)__umul64hi(draw_mix(a.seed, a.k0 + k, it, a.group, (uint32_t)j), (uint64_t)n);   // floor(u n / 2^64): uniform on [0, n)
+      if (a.esz == 4) reinterpret_cast<uint32_t*>(dst)[j] = reinterpret_cast<const uint32_t*>(src)[idx];
+      else if (a.esz == 2) reinterpret_cast<uint16_t*>(dst)[j] = reinterpret_cast<const uint16_t*>(src)[idx];
+      else reinterpret_cast<uint64_t*>(dst)[j] = reinterpret_cast<const uint64_t*>(src)[idx];
+    }
+  }
+}
+// the pair at index `kth` of the p-sorted iterations of every position (np.argsort(p_array)[kth]; ties in p by iteration number)
+__global__ __launch_bounds__(256) void select_quantile_kernel(int64_t nrows, int32_t iters, int32_t kth, const double* d, const double* p,
+                                                              double* out_d, double* out_p) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < nrows; k += (int64_t)gridDim.x * 4) {
+    const double* pk = p + k * iters;
+    for (int e = lane; e < iters; e += 64) {
+      const double pe = pk[e];
+      int rank = 0;
+      for (int j = 0; j < iters; ++j) { const double pj = pk[j]; rank += (pj < pe || (pj == pe && j < e) || (pe != pe && pj == pj)) ? 1 : 0; }   // (NaN last)
+      if (rank == kth) { out_p[k] = pe; out_d[k] = d[k * iters + e]; }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- self test kernels
 __global__ void selftest_perm_kernel(int* out) {
   int lane = threadIdx.x & 63;
@@ -941,6 +995,105 @@ const char* nmod_build_info(void) {
     info += std::string(" | k1_i16_all: ") + rank_stats_build_flags_d1_a1();
   });
   return info.c_str();
+}
+
+int nmod_downsample_ks(const nmod_params* prm, int64_t nflag, const void* sig0, const int64_t* off0, const void* sig1, const int64_t* off1,
+                       const int64_t* positions, const int64_t* cov, int32_t iters, double quantile, uint64_t seed,
+                       double* ks_d, double* ks_p) {
+  int rc = check_params(prm);
+  if (rc != NMOD_OK) return rc;
+  if (nflag < 0 || iters <= 0 || iters > 65536 || !(quantile >= 0.0 && quantile < 1.0)) return NMOD_ERR_INVALID_ARG;
+  if (prm->memspace != NMOD_MEM_HOST) return NMOD_ERR_INVALID_ARG;                 // (the caller's arrays are host memory: mtest2's batch)
+  if (nflag == 0) return NMOD_OK;
+  if (!sig0 || !sig1 || !off0 || !off1 || !positions || !cov || !ks_d || !ks_p) return NMOD_ERR_INVALID_ARG;
+  if (nmod_device_count() <= prm->device || prm->device < 0) return NMOD_ERR_NO_DEVICE;
+  NMOD_HIP(hipSetDevice(prm->device));
+  hipStream_t stream = (hipStream_t)prm->stream;
+  const int esz = prm->dtype == NMOD_DTYPE_F32 ? 4 : (prm->dtype == NMOD_DTYPE_F64 ? 8 : 2);
+  const int kth = (int)((double)iters * quantile);
+  int num_cus = 0;
+  NMOD_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, prm->device));
+  const int64_t max_elements = env_i64("NMOD_DOWNSAMPLE_ELEMENTS", (int64_t)1 << 27);
+  std::vector<int32_t> rn[2], rsz[2];
+  std::vector<int64_t> roff[2], vbase[2];
+  std::vector<char> rows[2];
+  const void* sig[2] = {sig0, sig1};
+  const int64_t* off[2] = {off0, off1};
+  int64_t lo = 0;
+  while (lo < nflag) {
+    // ---- the chunk: as many flagged positions as fit max_elements virtual samples (at least one)
+    int64_t hi = lo, tot = 0, maxsz[2] = {1, 1};
+    for (int g = 0; g < 2; ++g) { rn[g].clear(); rsz[g].clear(); roff[g].clear(); vbase[g].clear(); rows[g].clear(); }
+    int64_t at[2] = {0, 0}, vat[2] = {0, 0};
+    while (hi < nflag) {
+      const int64_t p = positions[hi];
+      int64_t n[2], z[2];
+      for (int g = 0; g < 2; ++g) {
+        n[g] = off[g][p + 1] - off[g][p];
+        if (n[g] <= 0 || n[g] > NMOD_MAX_RANKED) return n[g] > NMOD_MAX_RANKED ? NMOD_ERR_TOO_LARGE : NMOD_ERR_INVALID_ARG;
+        z[g] = (cov[hi] > 0 && n[g] > cov[hi]) ? cov[hi] : n[g];
+      }
+      const int64_t add = (z[0] + z[1]) * (int64_t)iters;
+      if (hi > lo && tot + add > max_elements) break;
+      tot += add;
+      for (int g = 0; g < 2; ++g) {
+        rn[g].push_back((int32_t)n[g]); rsz[g].push_back((int32_t)z[g]); roff[g].push_back(at[g]); vbase[g].push_back(vat[g]);
+        const char* src = (const char*)sig[g] + off[g][p] * esz;
+        rows[g].insert(rows[g].end(), src, src + n[g] * esz);
+        at[g] += n[g]; vat[g] += z[g] * (int64_t)iters; maxsz[g] = std::max(maxsz[g], z[g]);
+      }
+      ++hi;
+    }
+    const int64_t nrows = hi - lo, nv = nrows * (int64_t)iters;
+    if (nv > INT32_MAX) return NMOD_ERR_INVALID_ARG;
+    // ---- device buffers of the chunk (stream-ordered, from the library's pool)
+    nmod_params dp = *prm;
+    dp.memspace = NMOD_MEM_DEVICE; dp.tests = NMOD_TEST_KS; dp.method = NMOD_METHOD_KS; dp.want_mstd = 0; dp.flags = 0;
+    dp.stride0 = 0; dp.stride1 = 0; dp.max_n0 = (int32_t)maxsz[0]; dp.max_n1 = (int32_t)maxsz[1];
+    const int64_t wsb = nmod_workspace_bytes(&dp, nv);
+    DevScratch d_rows[2], d_meta[2], d_virt[2], d_voff[2], d_ws, d_res;
+    for (int g = 0; g < 2; ++g) {
+      const size_t mbytes = (size_t)nrows * (4 + 4 + 8 + 8);
+      NMOD_HIP(d_rows[g].alloc(rows[g].size(), stream, prm->device));
+      NMOD_HIP(d_meta[g].alloc(mbytes, stream, prm->device));
+      NMOD_HIP(d_virt[g].alloc((size_t)vat[g] * esz + 256, stream, prm->device));
+      NMOD_HIP(d_voff[g].alloc((size_t)(nv + 1) * 8, stream, prm->device));
+      char* m = (char*)d_meta[g].p;
+      NMOD_HIP(hipMemcpyAsync(d_rows[g].p, rows[g].data(), rows[g].size(), hipMemcpyHostToDevice, stream));
+      NMOD_HIP(hipMemcpyAsync(m, roff[g].data(), (size_t)nrows * 8, hipMemcpyHostToDevice, stream));
+      NMOD_HIP(hipMemcpyAsync(m + nrows * 8, vbase[g].data(), (size_t)nrows * 8, hipMemcpyHostToDevice, stream));
+      NMOD_HIP(hipMemcpyAsync(m + nrows * 16, rn[g].data(), (size_t)nrows * 4, hipMemcpyHostToDevice, stream));
+      NMOD_HIP(hipMemcpyAsync(m + nrows * 20, rsz[g].data(), (size_t)nrows * 4, hipMemcpyHostToDevice, stream));
+      ResampleArgs ra;
+      ra.rows = (const char*)d_rows[g].p; ra.esz = esz; ra.roff = (const int64_t*)m; ra.vbase = (const int64_t*)(m + nrows * 8);
+      ra.rn = (const int32_t*)(m + nrows * 16); ra.rsz = (const int32_t*)(m + nrows * 20);
+      ra.nrows = nrows; ra.iters = iters; ra.seed = seed; ra.group = g; ra.k0 = lo; ra.out = (char*)d_virt[g].p; ra.voff = (int64_t*)d_voff[g].p;
+      hipLaunchKernelGGL(resample_kernel, dim3((unsigned)std::min<int64_t>((nv + 3) / 4, (int64_t)num_cus * 32)), dim3(256), 0, stream, ra);
+      NMOD_HIP(hipGetLastError());
+    }
+    NMOD_HIP(d_ws.alloc((size_t)wsb, stream, prm->device));
+    NMOD_HIP(d_res.alloc((size_t)nv * 17 + (size_t)nrows * 16 + 64, stream, prm->device));
+    double* v_d = (double*)d_res.p; double* v_p = v_d + nv; double* o_d = v_p + nv; double* o_p = o_d + nrows;
+    nmod_out vout;
+    memset(&vout, 0, sizeof(vout));
+    vout.ks_d = v_d; vout.ks_p = v_p; vout.status = (uint8_t*)(o_p + nrows);
+    // the 100 resamples of every flagged position through the same KS kernel as everything else
+    if (prm->dtype == NMOD_DTYPE_F64) {
+      const int64_t bounds[4] = {0, vat[0], 0, vat[1]};
+      rc = detect_f64(&dp, nv, d_virt[0].p, (const int64_t*)d_voff[0].p, d_virt[1].p, (const int64_t*)d_voff[1].p, nullptr, d_ws.p, wsb, &vout, bounds);
+    } else {
+      rc = detect_device(&dp, nv, d_virt[0].p, (const int64_t*)d_voff[0].p, d_virt[1].p, (const int64_t*)d_voff[1].p, nullptr, d_ws.p, wsb, &vout);
+    }
+    if (rc != NMOD_OK) { hipStreamSynchronize(stream); return rc; }
+    hipLaunchKernelGGL(select_quantile_kernel, dim3((unsigned)std::min<int64_t>((nrows + 3) / 4, (int64_t)num_cus * 32)), dim3(256), 0, stream,
+                       nrows, iters, kth, v_d, v_p, o_d, o_p);
+    NMOD_HIP(hipGetLastError());
+    NMOD_HIP(hipMemcpyAsync(ks_d + lo, o_d, (size_t)nrows * 8, hipMemcpyDeviceToHost, stream));
+    NMOD_HIP(hipMemcpyAsync(ks_p + lo, o_p, (size_t)nrows * 8, hipMemcpyDeviceToHost, stream));
+    NMOD_HIP(hipStreamSynchronize(stream));          // (the host vectors are reused by the next chunk)
+    lo = hi;
+  }
+  return NMOD_OK;
 }
 
 int nmod_trim_scratch(int32_t device) {

@@ -342,59 +342,31 @@ class DeviceDetector:
         return out
 
 
-def downsample_ks(sig0, off0, sig1, off1, positions, cov, *, iters=100, quantile=0.25, seed=0, device=0,
-                  max_elements=1 << 27):
+def downsample_ks(sig0, off0, sig1, off1, positions, cov, *, iters=100, quantile=0.25, seed=0, device=0):
     """The down-sampling branch of getKStest (myDetect.py:345-361) for the positions `positions` (indices into
-    the CSR arrays): `iters` times, a group with more than cov[i] samples is resampled WITH replacement to
-    cov[i] samples (np.random.choice semantics), KS is run on each resample, and the (D, p) pair at index
+    the CSR arrays) through nmod_downsample_ks: `iters` times, a group with more than cov[i] samples is resampled WITH
+    replacement to cov[i] samples (np.random.choice semantics), KS is run on each resample, and the (D, p) pair at index
     int(iters * quantile) of the p-sorted resamples is reported.  The reference draws from an unseeded
-    global RNG, so its numbers are not reproducible; here the draws come from a seeded device generator —
+    global RNG, so its numbers are not reproducible; here the draws come from a seeded counter-based device generator —
     statistically equivalent, not bit-comparable (SURVEY.md §8a row A3', §8f row 4).  The resampled rows are
-    materialised chunk by chunk in HBM and go through the same KS kernel as everything else.
+    materialised chunk by chunk in HBM and go through the same KS kernel as everything else; resampling, KS and the
+    quantile selection all run in the library (round 3 assembled the rows with torch indexing).
     Returns (ks_d, ks_p) numpy arrays aligned with `positions`."""
-    import torch
-    dev = 'cuda:%d' % device
-    det = DeviceDetector(device, method='ks', tests=L.TEST_KS)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(int(seed))
-    positions = np.asarray(positions, dtype=np.int64)
-    cov = np.asarray(cov, dtype=np.int64)
-    off0 = np.asarray(off0, dtype=np.int64); off1 = np.asarray(off1, dtype=np.int64)
-    d_sig = [torch.as_tensor(np.ascontiguousarray(sig0), device=dev), torch.as_tensor(np.ascontiguousarray(sig1), device=dev)]
-    n = [off0[positions + 1] - off0[positions], off1[positions + 1] - off1[positions]]
-    start = [off0[positions], off1[positions]]
-    size = [np.where(n[g] > cov, cov, n[g]) for g in (0, 1)]              # resampled size per group
-    per_pos = (size[0] + size[1]) * iters
+    lib = L.load()
+    _join_warm_up(device)
+    sig0 = np.ascontiguousarray(sig0); sig1 = np.ascontiguousarray(sig1)
+    if sig0.dtype != sig1.dtype or sig0.dtype not in (np.float32, np.int16, np.float64):
+        raise ValueError('sig0/sig1 must both be float32, both int16 (milli-units) or both float64')
+    dtype = {np.dtype(np.float32): L.DTYPE_F32, np.dtype(np.int16): L.DTYPE_I16_MILLI, np.dtype(np.float64): L.DTYPE_F64}[sig0.dtype]
+    positions = np.ascontiguousarray(positions, dtype=np.int64)
+    cov = np.ascontiguousarray(cov, dtype=np.int64)
+    off0 = np.ascontiguousarray(off0, dtype=np.int64); off1 = np.ascontiguousarray(off1, dtype=np.int64)
+    if positions.shape != cov.shape or (len(positions) and (positions.min() < 0 or positions.max() >= len(off0) - 1)):
+        raise ValueError('positions / cov must be aligned and index the CSR rows')
     out_d = np.empty(len(positions)); out_p = np.empty(len(positions))
-    k = int(iters * quantile)
-    lo = 0
-    while lo < len(positions):
-        hi = lo + 1
-        tot = per_pos[lo]
-        while hi < len(positions) and tot + per_pos[hi] <= max_elements:
-            tot += per_pos[hi]; hi += 1
-        npc = hi - lo
-        vsig, voff, vmax = [], [], []
-        for g in (0, 1):
-            sz = torch.as_tensor(np.repeat(size[g][lo:hi], iters), device=dev)                # rows: (position, iteration)
-            off = torch.zeros(npc * iters + 1, dtype=torch.int64, device=dev)
-            off[1:] = torch.cumsum(sz, 0)
-            total = int(off[-1].item())
-            row = torch.repeat_interleave(torch.arange(npc * iters, device=dev), sz, output_size=total)
-            within = torch.arange(total, device=dev) - off[row]
-            nn = torch.as_tensor(np.repeat(n[g][lo:hi], iters), device=dev)[row]
-            st = torch.as_tensor(np.repeat(start[g][lo:hi], iters), device=dev)[row]
-            res = torch.as_tensor(np.repeat(n[g][lo:hi] > cov[lo:hi], iters), device=dev)[row]
-            u = torch.rand(total, device=dev, generator=gen, dtype=torch.float64)
-            pick = torch.minimum((u * nn.to(torch.float64)).to(torch.int64), nn - 1)              # choice with replacement
-            idx = st + torch.where(res, pick, within)
-            vsig.append(d_sig[g][idx]); voff.append(off); vmax.append(int(size[g][lo:hi].max()))
-        rid = torch.zeros(npc * iters, dtype=torch.int32, device=dev)
-        r = det.run(vsig[0], vsig[1], rid, off0=voff[0], off1=voff[1], max_n0=vmax[0], max_n1=vmax[1])
-        p = r['ks_p'].view(npc, iters); d = r['ks_d'].view(npc, iters)
-        order = torch.argsort(p, dim=1)
-        sel = order[:, k:k + 1]
-        out_p[lo:hi] = torch.gather(p, 1, sel).squeeze(1).cpu().numpy()
-        out_d[lo:hi] = torch.gather(d, 1, sel).squeeze(1).cpu().numpy()
-        lo = hi
+    prm = L.make_params(device=device, memspace=L.MEM_HOST, dtype=dtype, tests=L.TEST_KS, method=L.METHOD_KS)
+    rc = lib.nmod_downsample_ks(C.byref(prm), len(positions), _np_ptr(sig0), _np_ptr(off0), _np_ptr(sig1), _np_ptr(off1),
+                                _np_ptr(positions), _np_ptr(cov), int(iters), float(quantile), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                _np_ptr(out_d), _np_ptr(out_p))
+    L.check(rc, 'nmod_downsample_ks')
     return out_d, out_p

@@ -581,6 +581,44 @@ def test_large_positions_fixed_stride_and_limit(nm):
             nm.detect_host(big, np.array([0, 65536]), big[:10], np.array([0, 10]), np.zeros(1, np.int32), tests=tests, method='ks')
 
 
+def test_downsample_entry_point_is_chunk_invariant_and_exact_without_draws(nm, monkeypatch):
+    """nmod_downsample_ks (the device form of myDetect.py:345-361): positions whose groups are under their threshold are not
+    drawn from — all `iters` virtual rows are the position itself, the selected pair is its plain KS pair, bit for bit; the draws
+    are keyed by the position's index among the flagged ones, so the chunking of the virtual rows changes nothing; another seed
+    changes the draws; float32, int16 and float64 rows."""
+    from nanomod_amd import engine
+    L = nm._lib
+    rng = np.random.default_rng(9)
+    npos = 90
+    n0 = rng.integers(10, 300, npos); n1 = rng.integers(10, 300, npos)
+    off0 = np.zeros(npos + 1, np.int64); off0[1:] = np.cumsum(n0)
+    off1 = np.zeros(npos + 1, np.int64); off1[1:] = np.cumsum(n1)
+    a = np.round(rng.normal(0, 1, off0[-1]), 3); b = np.round(rng.normal(0.3, 1, off1[-1]), 3)
+    for dtype in (np.float32, np.int16, np.float64):
+        s0 = np.rint(a * 1000).astype(np.int16) if dtype == np.int16 else a.astype(dtype)
+        s1 = np.rint(b * 1000).astype(np.int16) if dtype == np.int16 else b.astype(dtype)
+        plain = nm.detect_host(s0, off0, s1, off1, np.zeros(npos, np.int32), tests=L.TEST_KS, method='ks')
+        pos = np.arange(npos)[::-1].copy()                      # any order, every position
+        cov = np.where(np.arange(npos)[::-1] % 3 == 0, 100000, 60)   # a third of them far above both groups: no draws
+        d1, p1 = engine.downsample_ks(s0, off0, s1, off1, pos, cov, iters=100, quantile=0.25, seed=5)
+        nodraw = (n0[pos] <= cov) & (n1[pos] <= cov)
+        assert nodraw.sum() >= 25 and (~nodraw).sum() >= 25
+        assert np.array_equal(d1[nodraw], plain['ks_d'][pos][nodraw]) and np.array_equal(p1[nodraw], plain['ks_p'][pos][nodraw])
+        assert np.all((p1 > 0) & (p1 <= 1) & (d1 >= 0) & (d1 <= 1))
+        monkeypatch.setenv('NMOD_DOWNSAMPLE_ELEMENTS', '60000')     # ~3 positions per chunk
+        d2, p2 = engine.downsample_ks(s0, off0, s1, off1, pos, cov, iters=100, quantile=0.25, seed=5)
+        monkeypatch.delenv('NMOD_DOWNSAMPLE_ELEMENTS')
+        assert np.array_equal(d1, d2) and np.array_equal(p1, p2)
+        d3, p3 = engine.downsample_ks(s0, off0, s1, off1, pos, cov, iters=100, quantile=0.25, seed=6)
+        assert np.array_equal(p3[nodraw], p1[nodraw]) and np.mean(p3[~nodraw] != p1[~nodraw]) > 0.5
+        # the quantile index walks the sorted resamples: p at 0.0 <= p at 0.25 <= p at 0.9 for every position
+        plo = engine.downsample_ks(s0, off0, s1, off1, pos, cov, iters=100, quantile=0.0, seed=5)[1]
+        phi = engine.downsample_ks(s0, off0, s1, off1, pos, cov, iters=100, quantile=0.9, seed=5)[1]
+        assert np.all(plo <= p1) and np.all(p1 <= phi) and np.any(plo < phi)
+    d0, p0 = engine.downsample_ks(s0, off0, s1, off1, np.zeros(0, np.int64), np.zeros(0, np.int64))
+    assert len(d0) == 0 and len(p0) == 0
+
+
 def test_downsampling_branch_statistically_matches(nm):
     """--coverages > 0 (myDetect.py:345-361): seeded on the device, unseeded in the reference, so compare
     distributions: over many positions the selected 25th-percentile p-values of the two implementations must

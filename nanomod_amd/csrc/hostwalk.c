@@ -162,6 +162,83 @@ static int copy_row(PyObject* row, double* dst, Py_ssize_t n) {
   return 0;
 }
 
+/* The copy phase of join_strand on several threads.  The calling thread HOLDS the GIL while it waits, so no other Python code runs
+ * and no row can change; the helper threads touch no Python API that needs the GIL — only macros that read object memory (type
+ * flags, list item pointers, the double inside a float object, an ndarray's data pointer).  A row they cannot take that way (a
+ * tuple, an ndarray of another dtype, a list holding something that is not a float) is left for the caller (`slow`). */
+#include <pthread.h>
+typedef struct {
+  const ent_t* e; const Py_ssize_t* ix; const int* nn; const long long* start; double* dst;
+  Py_ssize_t lo, hi; unsigned char* slow;
+} copy_job_t;
+
+static void* copy_worker(void* arg) {
+  copy_job_t* jb = (copy_job_t*)arg;
+  for (Py_ssize_t j = jb->lo; j < jb->hi; ++j) {
+    if (j + 16 < jb->hi) __builtin_prefetch(jb->e[jb->ix[j + 16]].row);
+    if (j + 8 < jb->hi) {
+      PyObject* o = jb->e[jb->ix[j + 8]].row;
+      if (PyList_CheckExact(o)) __builtin_prefetch(((PyListObject*)o)->ob_item);
+      else if (PyArray_Check(o)) __builtin_prefetch(PyArray_DATA((PyArrayObject*)o));
+    }
+    PyObject* row = jb->e[jb->ix[j]].row;
+    double* d = jb->dst + jb->start[j];
+    const int n = jb->nn[j];
+    if (PyArray_Check(row) && PyArray_TYPE((PyArrayObject*)row) == NPY_DOUBLE && PyArray_IS_C_CONTIGUOUS((PyArrayObject*)row) &&
+        PyArray_NDIM((PyArrayObject*)row) == 1 && PyArray_DIM((PyArrayObject*)row, 0) == n) {
+      memcpy(d, PyArray_DATA((PyArrayObject*)row), (size_t)n * 8);
+    } else if (PyList_CheckExact(row) && PyList_GET_SIZE(row) == n) {
+      PyObject** items = ((PyListObject*)row)->ob_item;
+      int ok = 1;
+      for (int i = 0; i < n; ++i) {
+        PyObject* it = items[i];
+        if (!PyFloat_Check(it)) { ok = 0; break; }         /* numpy.float64 is a float subclass */
+        d[i] = PyFloat_AS_DOUBLE(it);
+      }
+      if (!ok) jb->slow[j] = 1;
+    } else {
+      jb->slow[j] = 1;
+    }
+  }
+  return NULL;
+}
+
+static int host_threads(void) {
+  const char* s = getenv("NMOD_HOSTWALK_THREADS");
+  int t = s ? atoi(s) : 4;
+  long q = -1, per = -1;
+  FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (f) { char buf[64]; if (fscanf(f, "%63s %ld", buf, &per) == 2 && strcmp(buf, "max") != 0) q = atol(buf); fclose(f); }
+  if (q > 0 && per > 0 && q / per < t) t = (int)(q / per);
+  return t < 1 ? 1 : (t > 16 ? 16 : t);
+}
+
+/* rows of one group -> dst (CSR order); 0 or -1 with an exception set */
+static int copy_rows(const ent_t* e, const Py_ssize_t* ix, const int* nn, Py_ssize_t n, double* dst) {
+  long long* start = (long long*)malloc((size_t)(n ? n : 1) * sizeof(long long));
+  unsigned char* slow = (unsigned char*)calloc((size_t)(n ? n : 1), 1);
+  if (!start || !slow) { free(start); free(slow); PyErr_NoMemory(); return -1; }
+  long long at = 0;
+  for (Py_ssize_t j = 0; j < n; ++j) { start[j] = at; at += nn[j]; }
+  int T = host_threads();
+  if (n < 4096) T = 1;
+  copy_job_t jobs[16]; pthread_t th[16]; int started[16];
+  long long per = at / T + 1, acc = 0; Py_ssize_t lo = 0; int used = 0;
+  for (Py_ssize_t j = 0; j < n && used < T - 1; ++j) {           /* ranges of about equal sample counts */
+    acc += nn[j];
+    if (acc >= per) { jobs[used] = (copy_job_t){e, ix, nn, start, dst, lo, j + 1, slow}; lo = j + 1; acc = 0; ++used; }
+  }
+  jobs[used] = (copy_job_t){e, ix, nn, start, dst, lo, n, slow}; ++used;
+  for (int t = 1; t < used; ++t) started[t] = pthread_create(&th[t], NULL, copy_worker, &jobs[t]) == 0;
+  copy_worker(&jobs[0]);
+  for (int t = 1; t < used; ++t) { if (started[t]) pthread_join(th[t], NULL); else copy_worker(&jobs[t]); }
+  int rc = 0;
+  for (Py_ssize_t j = 0; j < n && rc == 0; ++j)
+    if (slow[j]) rc = copy_row(e[ix[j]].row, dst + start[j], nn[j]);      /* under the GIL: sequence protocol, float() */
+  free(start); free(slow);
+  return rc;
+}
+
 /* join_strand(norm0, norm1, base0, base1) -> (pos int64[n], n0 int32[n], n1 int32[n], sig0 float64[sum n0], sig1 float64[sum n1],
  *                                             bases list[n] (group 2's, as mtest2 records them), mismatch list of indices,
  *                                             base_codes uint32[n]: the code point of a one-character base, else 0)
@@ -218,21 +295,7 @@ static PyObject* join_strand(PyObject* self, PyObject* args) {
   s0_a = PyArray_SimpleNew(1, &d0n, NPY_DOUBLE); s1_a = PyArray_SimpleNew(1, &d1n, NPY_DOUBLE);
   if (!s0_a || !s1_a) goto done;
   double* s0 = (double*)PyArray_DATA((PyArrayObject*)s0_a); double* s1 = (double*)PyArray_DATA((PyArrayObject*)s1_a);
-  for (int g = 0; g < 2; ++g) {                          /* one group after the other: each pass streams its own rows */
-    double* dst = g ? s1 : s0;
-    const ent_t* e = g ? e1 : e0; const Py_ssize_t* ix = g ? i1 : i0; const int* nn = g ? n1 : n0;
-    long long at = 0;
-    for (Py_ssize_t j = 0; j < n; ++j) {
-      if (j + 16 < n) __builtin_prefetch(e[ix[j + 16]].row);
-      if (j + 8 < n) {
-        PyObject* o = e[ix[j + 8]].row;
-        if (PyList_CheckExact(o)) __builtin_prefetch(((PyListObject*)o)->ob_item);
-        else if (PyArray_Check(o)) __builtin_prefetch(PyArray_DATA((PyArrayObject*)o));
-      }
-      if (copy_row(e[ix[j]].row, dst + at, nn[j]) < 0) goto done;
-      at += nn[j];
-    }
-  }
+  if (copy_rows(e0, i0, n0, n, s0) < 0 || copy_rows(e1, i1, n1, n, s1) < 0) goto done;   /* one group after the other */
   ret = PyTuple_Pack(8, pos_a, n0_a, n1_a, s0_a, s1_a, bases, mism, codes_a);
 done:
   free(e0); free(e1); free(eb0); free(eb1); free(i0); free(i1);

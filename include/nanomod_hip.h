@@ -19,6 +19,10 @@
  *     sig1[off1[i] .. off1[i+1])   samples of group 2 (--wrkBase2)
  * plus run_id[i]: equal ids <=> same chrom, same strand and consecutive
  * positions (restates pos_check, myDetect.py:366-371).
+ * Samples must be finite: NanoMod's normalised event means always are.  The
+ * kernels order keys with bare v_min / v_max and pad with +inf; a NaN (or an
+ * infinite) sample is not diagnosed and gives unspecified statistics for its
+ * position (never a fault, never another position's).
  */
 #ifndef NANOMOD_HIP_H
 #define NANOMOD_HIP_H

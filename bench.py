@@ -260,6 +260,57 @@ def cpu_baseline(rows, what, method, tests, threads, target_seconds=12.0, refpy=
             'reference_shaped_python': ref_shaped}
 
 
+def drop_in_leg(nm, dev_index, positions=460_000, reads=20):
+    """The function-level drop-in on the reference's own in-memory shape (myDetect.py:569-572: dict[(chrom, strand)][pos] -> list of
+    numpy.float64, built at :124) — mfilter_coverage + mtest2 (position set and order, CSR, PCIe, K1-K3, ranking, `_sign_test.txt`)
+    at a tenth of E. coli, 20 v 20 reads of 3-decimal values, two strands; per-position numpy arrays as the second shape.
+    The first 2 000 positions' p-values are checked against the oracle."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import oracle_c
+    rng = np.random.default_rng(SEED)
+    half = positions // 2
+    vals = {ds: np.round(rng.normal(shift, 1, (positions, reads)), 3) for ds, shift in (('A', 0.0), ('B', 0.1))}
+    out = {'positions': positions, 'reads_per_group': reads, 'dtype': 'float64 on the 0.001 grid',
+           'note': 'nanomod_amd.mfilter_coverage + nanomod_amd.mtest2 (testMethod stouffer, neighborPvalues 2, SaveTest 1) on the reference\'s '
+                   'dict shape; seconds are wall time of the two calls, the input dicts are built outside the clock'}
+    for shape in ('arrays', 'lists'):
+        tmp = tempfile.mkdtemp()
+        mo = {'ds2': ['A', 'B'], 'outLevel': 3, 'mstd': 0, 'coverages': [0, 0], 'downsampling': 100, 'downsampling_quantile': 0.25,
+              'neighborPvalues': NB, 'WeightsDif': WDIF, 'testMethod': 'stouffer', 'rankUse': 'pv', 'SaveTest': 1, 'RegionRankbyST': 0,
+              'outFolder': tmp, 'FileID': 'bench', 'MinCoverage': 5, 'nmod_device': dev_index}
+        for ds in ('A', 'B'):
+            v = vals[ds]
+            row = (lambda i: v[i]) if shape == 'arrays' else (lambda i: [np.float64(x) for x in v[i]])
+            mo[ds] = {'norm_mean': {('chr', '+'): {i: row(i) for i in range(half)}, ('chr', '-'): {i: row(i) for i in range(half, positions)}},
+                      'base': {('chr', '+'): {i: 'A' for i in range(half)}, ('chr', '-'): {i: 'C' for i in range(half, positions)}}, 'basedict': {}}
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            nm.mfilter_coverage(mo)
+            t1 = time.perf_counter()
+            nm.mtest2(mo)
+            t2 = time.perf_counter()
+        res = mo['sign_test_arrays']
+        vn = 2000
+        a = vals['A'][:vn].reshape(-1); b = vals['B'][:vn].reshape(-1)
+        off = np.arange(0, (vn + 1) * reads, reads, dtype=np.int64)
+        exp = oracle_c.detect_batch(np.rint(a * 1000).astype(np.int16), off, np.rint(b * 1000).astype(np.int16), off, np.zeros(vn, np.int32),
+                                    NB, WDIF, 'stouffer', tests=7)
+        inner = slice(0, vn - NB)
+        ok = all(bool(np.all(np.abs(res[k][:vn][inner] - exp[k][inner]) <= 1e-9 * np.abs(exp[k][inner]) + 1e-300)) for k in ('mwu_p', 't_p', 'ks_p', 'comb_p'))
+        ok = ok and bool(np.array_equal(res['mwu_u'][:vn], exp['mwu_u'])) and bool(np.array_equal(res['ks_d'][:vn], exp['ks_d']))
+        lines = sum(1 for _ in open(os.path.join(tmp, 'bench_sign_test.txt')))
+        shutil.rmtree(tmp, ignore_errors=True)
+        out[shape] = {'mfilter_coverage_s': t1 - t0, 'mtest2_s': t2 - t1, 'positions_per_s': positions / (t2 - t0),
+                      'table_lines': lines, 'first_ranked': list(mo['sorted_sign_test'][0][0][:3]), 'verify_ok': bool(ok and lines == positions)}
+        del mo
+    return out
+
+
 def gpu_local_cpus(torch, dev_index):
     """CPUs of the NUMA node the GPU hangs off (sysfs), or None.  A two-socket host copies from the far socket's memory at
     ~0.8 of the near rate; where the caller's arrays live is the caller's business, the measurement keeps its own near."""
@@ -485,7 +536,7 @@ def main():
     ap.add_argument('--refpy-seconds', type=float, default=6.0, help='reference-shaped Python CPU leg: at least this many seconds per process')
     ap.add_argument('--no-side', '--no-real-ties', dest='no_side', action='store_true',
                     help='skip the side measurements of the default run (all tests, int16, rational D, tie-heavy input)')
-    ap.add_argument('--side-legs', default='all', help='comma list of side measurements to run (all_tests,int16,rational_d,real_ties,presets); default all')
+    ap.add_argument('--side-legs', default='all', help='comma list of side measurements to run (all_tests,int16,rational_d,real_ties,presets,drop_in); default all')
     ap.add_argument('--no-host-path', action='store_true', help='skip the host-resident (NMOD_MEM_HOST, PCIe-bound) measurement')
     ap.add_argument('--rational-d', action='store_true', help='KS-only configurations: time NMOD_FLAG_KS_RATIONAL_D (D as the exact rational, <= 2 ulp '
                     'from ks_2samp\'s float form) instead of the library default (D bit for bit); the default run reports this rate as a side figure')
@@ -804,7 +855,7 @@ def main():
                 'roofline_frac': gbs / HBM_PEAK_GBS, 'achieved_GBps': gbs, 'note': note, 'verify': v}
 
     side = {}
-    legs = set(args.side_legs.split(',')) if args.side_legs != 'all' else {'all_tests', 'int16', 'rational_d', 'real_ties', 'presets'}
+    legs = set(args.side_legs.split(',')) if args.side_legs != 'all' else {'all_tests', 'int16', 'rational_d', 'real_ties', 'presets', 'drop_in'}
     simple = world == 1 and not csr and not args.force_collective and not args.no_side and chunks == 1
     headline_default = simple and args.config == 'ecoli' and args.dtype == 'f32' and args.ties == 'few' and not all_tests
     if headline_default and 'all_tests' in legs:
@@ -911,6 +962,14 @@ def main():
             verify['ok'] = False
             print('bench.py: the host-resident entry differs from the device-resident pass: %r' % bad, file=sys.stderr)
 
+    # ---- the function-level drop-in on the reference's dict shape (host glue + PCIe + kernels + table), a tenth of E. coli
+    drop_in = None
+    if headline_default and not args.no_host_path and not args.positions and 'drop_in' in legs:
+        drop_in = drop_in_leg(nm, local_rank)
+        if not all(v['verify_ok'] for v in drop_in.values() if isinstance(v, dict)):
+            verify['ok'] = False
+            print('bench.py: the drop-in mtest2 leg differs from the oracle: %r' % drop_in, file=sys.stderr)
+
     # (after the host-resident leg: freeing the presets' 79 GB of device memory slows the PCIe copies that follow for a while —
     # 0.77 instead of 0.95 of the pinned rate when the order is reversed)
     if headline_default and not args.positions and 'presets' in legs:
@@ -1001,6 +1060,8 @@ def main():
         line.update(side)
         if host_path is not None:
             line['host_path'] = host_path
+        if drop_in is not None:
+            line['drop_in_mtest2'] = drop_in
         if not args.no_cpu and world == 1:           # the CPU baseline is an N=1 figure
             line['cpu_baseline'] = cpu_baseline(cpu_rows, '%s, %s' % (reads_txt, tests_txt), method, 7 if all_tests else 1, usable_cpus(), refpy=refpy)
     ok = torch.tensor([1 if (rank != 0 or verify['ok']) else 0], device=dev)

@@ -45,3 +45,12 @@ def test_ragged_all_tests_grid_input_and_forced_collective():
     d = _bench(['--force-collective', '--config', 'ragged', '--positions', '60000', '--all-tests', '--chunks', '3'])
     v = d['verify']
     assert v['ok'] and v['gathered_track_equals_local'] and v['block_boundaries_checked'] == 2 and v['block_boundary_positions_differing'] == 0
+
+
+def test_drop_in_leg_on_the_reference_dict_shape():
+    d = _bench(['--side-legs', 'drop_in'])
+    di = d['drop_in_mtest2']
+    assert d['verify']['ok'] and di['positions'] == 460000
+    for shape in ('arrays', 'lists'):
+        assert di[shape]['verify_ok'] and di[shape]['table_lines'] == 460000 and di[shape]['mtest2_s'] < 5.0
+    assert di['arrays']['first_ranked'] == di['lists']['first_ranked']

@@ -181,8 +181,19 @@ def start_refpy_workers(cfg, procs):
     ctx = mp.get_context('spawn')
     go, results = ctx.Event(), ctx.Queue()
     ps = [ctx.Process(target=refpy_worker, args=(i, go, results, cfg), daemon=True) for i in range(procs)]
-    for p_ in ps:
-        p_.start()
+    # the children are CPU-only: they get no profiler preload (this run may sit under rocprofv3) and see no GPU
+    saved = dict(os.environ)
+    try:
+        for k in list(os.environ):
+            if k == 'LD_PRELOAD' or k.startswith(('ROCP', 'ROCPROF', 'HSA_TOOLS', 'ROCTX', 'RPD_')):
+                del os.environ[k]
+        os.environ['ROCR_VISIBLE_DEVICES'] = ''
+        os.environ['HIP_VISIBLE_DEVICES'] = ''
+        for p_ in ps:
+            p_.start()
+    finally:
+        os.environ.clear()
+        os.environ.update(saved)
     return {'go': go, 'results': results, 'procs': ps, 'cfg': cfg}
 
 

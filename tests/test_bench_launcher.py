@@ -89,3 +89,16 @@ def test_presets_name_the_baseline_configs():
     assert 900 < np.median(a) < 1100 and 45 < np.median(b) < 55
     # a function of the global position: a halo position gets the same size on every rank
     assert np.array_equal(bench.ragged_sizes(1, 5000, 100, 0), a[5000:5100])
+
+
+def test_cpu_leg_generator_is_the_device_generator():
+    """bench.synth_rows (what the reference-shaped CPU leg's children run on) restates the device generator exactly as
+    tests/helpers.synth_ref does (which the -m gpu tests hold against nmod_synth_fill bit for bit)"""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import bench
+    import helpers as H
+    for group, i16 in ((0, False), (1, False), (1, True)):
+        a = bench.synth_rows(bench.SEED, 9990, 30, group, 57, bench.PLANT_PERIOD, bench.PLANT_SHIFT, i16)
+        b = H.synth_ref(bench.SEED, 9990, 30, group, 57, bench.PLANT_PERIOD, bench.PLANT_SHIFT, 'i16' if i16 else 'f32')
+        assert a.shape == (30, 57) and np.array_equal(a.reshape(-1), b) and a.dtype == b.dtype

@@ -179,9 +179,8 @@ def start_refpy_workers(cfg, procs):
     """spawn (fresh interpreters, nothing inherited) the reference-shaped workers; they import, warm up and wait"""
     import multiprocessing as mp
     ctx = mp.get_context('spawn')
-    go, results = ctx.Event(), ctx.Queue()
-    ps = [ctx.Process(target=refpy_worker, args=(i, go, results, cfg), daemon=True) for i in range(procs)]
-    # the children are CPU-only: they get no profiler preload (this run may sit under rocprofv3) and see no GPU
+    # the children are CPU-only: they get no profiler preload (this run may sit under rocprofv3) and see no GPU.  The first
+    # SemLock starts multiprocessing's resource_tracker process, so Event / Queue are made AFTER the environment is scrubbed.
     saved = dict(os.environ)
     try:
         for k in list(os.environ):
@@ -189,6 +188,8 @@ def start_refpy_workers(cfg, procs):
                 del os.environ[k]
         os.environ['ROCR_VISIBLE_DEVICES'] = ''
         os.environ['HIP_VISIBLE_DEVICES'] = ''
+        go, results = ctx.Event(), ctx.Queue()
+        ps = [ctx.Process(target=refpy_worker, args=(i, go, results, cfg), daemon=True) for i in range(procs)]
         for p_ in ps:
             p_.start()
     finally:
@@ -499,6 +500,29 @@ def rank_plan(args, world, rank):
             'sample_bytes': samples * sb, 'device_bytes': dev_bytes, 'fits_288GB': bool(dev_bytes < 288e9 * 0.9)}
 
 
+def emit_line(text):
+    """One record = ONE write(2): torch.distributed.run starts its workers with `python -u`, where print() sends the body
+    and the newline separately and the lines of different ranks interleave on the shared pipe."""
+    sys.stdout.flush()
+    data = (text + '\n').encode()
+    while data:
+        data = data[os.write(1, data):]
+
+
+def split_json_objects(ln):
+    """A forwarded line may still hold several records back to back (`{...}{...}`): cut it into its top-level objects."""
+    dec, out, i = json.JSONDecoder(), [], 0
+    try:
+        while i < len(ln):
+            _, j = dec.raw_decode(ln, i)
+            out.append(ln[i:j]); i = j
+            while i < len(ln) and ln[i].isspace():
+                i += 1
+    except ValueError:
+        return [ln]
+    return out or [ln]
+
+
 def launch_ranks(args, argv):
     """N > 1 without an external launcher: one fresh child process per GPU.  This process has not imported torch.cuda
     or loaded the HIP library; it only forwards the children's output (rank 0's JSON line last) and their failure."""
@@ -510,16 +534,19 @@ def launch_ranks(args, argv):
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     last_json = None
     for ln in proc.stdout:
-        ln = ln.rstrip('\n')
+        ln = ln.strip('\n')
+        if not ln:
+            continue
         if ln.startswith('{') and ln.endswith('}'):
-            if last_json is not None:
-                print(last_json, flush=True)
-            last_json = ln
+            for rec in split_json_objects(ln):
+                if last_json is not None:
+                    emit_line(last_json)
+                last_json = rec
         else:
-            print(ln, flush=True)
+            emit_line(ln)
     rc = proc.wait()
     if last_json is not None:
-        print(last_json, flush=True)
+        emit_line(last_json)
     if rc != 0:
         print('bench.py: a rank failed (torch.distributed.run exit code %d); nothing is retried' % rc, file=sys.stderr)
     return rc if rc != 0 else (0 if last_json is not None else 1)
@@ -563,8 +590,8 @@ def main():
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
     if args.launch_only:
-        print(json.dumps({'launch_only': True, 'rank': rank, 'local_rank': local_rank, 'world_size': world, 'plan': rank_plan(args, world, rank),
-                          'master': '%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'))}), flush=True)
+        emit_line(json.dumps({'launch_only': True, 'rank': rank, 'local_rank': local_rank, 'world_size': world, 'plan': rank_plan(args, world, rank),
+                              'master': '%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'))}))
         return
 
     # the reference-shaped CPU leg: one fresh process per usable core, started BEFORE this process touches a GPU (they idle
@@ -1088,7 +1115,7 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+        emit_line(json.dumps(line))
     if int(ok.item()) == 0:
         sys.exit(3)                                  # a numerically wrong build must not look like a benchmark record
 

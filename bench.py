@@ -141,6 +141,33 @@ def synth_rows(seed, pos_begin, npos, group, n_per_pos, plant_period, plant_shif
     return v
 
 
+def synth_event_rows(seed, pos_begin, npos, group, n_per_pos, plant_period, plant_shift_milli, spread_milli, i16):
+    """numpy restatement of nmod_synth_fill_events (include/nanomod_hip.h; bit-equal, tests/test_gpu_parity.py) as an
+    [npos, n_per_pos] array: a level per position shared by both groups, reads spread around it, on the milli-unit grid."""
+    import numpy as np
+
+    def mix(sd, pos, group, read):
+        with np.errstate(over='ignore'):
+            x = np.uint64(sd) + np.uint64(0x9E3779B97F4A7C15) * (pos * 2 + group).astype(np.uint64)
+            x = x ^ (read * np.uint64(0xD1B54A32D192ED03))
+            x = x ^ (x >> np.uint64(30)); x = x * np.uint64(0xBF58476D1CE4E5B9)
+            x = x ^ (x >> np.uint64(27)); x = x * np.uint64(0x94D049BB133111EB)
+            x = x ^ (x >> np.uint64(31))
+        return x
+    pos = (np.arange(npos, dtype=np.int64) + pos_begin)[:, None]
+    read = np.arange(n_per_pos, dtype=np.uint64)[None, :]
+    lev = ((mix(np.uint64(seed) ^ np.uint64(0xA5A5A5A5DEADBEEF), pos, 0, np.zeros((1, 1), np.uint64)) >> np.uint64(40)) % np.uint64(6001)).astype(np.int64) - 3000
+    x = mix(seed, pos, group, read)
+    m = np.uint64(0xffff)
+    z = ((x & m) + ((x >> np.uint64(16)) & m) + ((x >> np.uint64(32)) & m) + (x >> np.uint64(48))).astype(np.int64) - 131070
+    k = lev + np.floor_divide(2 * z * int(spread_milli) + 37837, 75674)
+    if group == 1 and plant_period > 0:
+        mm = pos % plant_period
+        k = k + np.where((mm == 0) | (mm == 1) | (mm == plant_period - 1), int(plant_shift_milli), 0)
+    k = np.clip(k, -32767, 32767)
+    return k.astype(np.int16) if i16 else (k.astype(np.float64) / 1000.0).astype(np.float32)
+
+
 def refpy_worker(idx, go, results, cfg):
     """One process of the reference-shaped CPU leg: the reference's own shape of the computation — per position,
     in Python, the three scipy-1.2.1-style tests of getKStest (myDetect.py:327-343) through oracle/nanomod_oracle.py, then
@@ -162,8 +189,12 @@ def refpy_worker(idx, go, results, cfg):
             s0 = ragged_sizes(seed, pos, block, 0); s1 = ragged_sizes(seed, pos, block, 1)
         else:
             s0 = np.full(block, n0); s1 = np.full(block, n1)
-        a = synth_rows(seed, pos, block, 0, int(s0.max()), PLANT_PERIOD, PLANT_SHIFT, i16)
-        b = synth_rows(seed, pos, block, 1, int(s1.max()), PLANT_PERIOD, PLANT_SHIFT, i16)
+        if cfg.get('spread', 0) > 0:
+            a = synth_event_rows(seed, pos, block, 0, int(s0.max()), PLANT_PERIOD, int(round(PLANT_SHIFT * 1000)), cfg['spread'], i16)
+            b = synth_event_rows(seed, pos, block, 1, int(s1.max()), PLANT_PERIOD, int(round(PLANT_SHIFT * 1000)), cfg['spread'], i16)
+        else:
+            a = synth_rows(seed, pos, block, 0, int(s0.max()), PLANT_PERIOD, PLANT_SHIFT, i16)
+            b = synth_rows(seed, pos, block, 1, int(s1.max()), PLANT_PERIOD, PLANT_SHIFT, i16)
         for i in range(block):
             r = orc.getKStest(a[i, :s0[i]].astype(np.float64) * scale, b[i, :s1[i]].astype(np.float64) * scale)
             ksd.append(r[2][0]); ksp.append(r[2][1])
@@ -565,6 +596,8 @@ def main():
     ap.add_argument('--all-tests', action='store_true', help='KS + MWU + Welch-t + Fisher instead of the preset\'s tests')
     ap.add_argument('--ties', choices=('few', 'real'), default='few',
                     help='real: signals on the 3-decimal grid of NanoMod events (myRefBaseSignalAnnotation.py:1108)')
+    ap.add_argument('--spread', type=int, default=0, help='event-like rows (nmod_synth_fill_events): a level per position in +-3 units, reads spread '
+                    'SPREAD milli-units around it, on the 3-decimal grid (most samples of a position tie); 0 = the unit-variance generator')
     ap.add_argument('--strong', action='store_true', help='fixed total size: --positions in total, split over the ranks')
     ap.add_argument('--chunks', type=int, default=0, help='rounds of the block-cyclic pipeline (default 4 for N>1, 1 for N=1)')
     ap.add_argument('--force-collective', action='store_true', help='N=1: initialise RCCL with one rank and issue the all-gather anyway')
@@ -574,7 +607,7 @@ def main():
     ap.add_argument('--refpy-seconds', type=float, default=6.0, help='reference-shaped Python CPU leg: at least this many seconds per process')
     ap.add_argument('--no-side', '--no-real-ties', dest='no_side', action='store_true',
                     help='skip the side measurements of the default run (all tests, int16, rational D, tie-heavy input)')
-    ap.add_argument('--side-legs', default='all', help='comma list of side measurements to run (all_tests,int16,rational_d,real_ties,presets,drop_in); default all')
+    ap.add_argument('--side-legs', default='all', help='comma list of side measurements to run (all_tests,int16,rational_d,real_ties,real_spread,presets,drop_in); default all')
     ap.add_argument('--no-host-path', action='store_true', help='skip the host-resident (NMOD_MEM_HOST, PCIe-bound) measurement')
     ap.add_argument('--rational-d', action='store_true', help='KS-only configurations: time NMOD_FLAG_KS_RATIONAL_D (D as the exact rational, <= 2 ulp '
                     'from ks_2samp\'s float form) instead of the library default (D bit for bit); the default run reports this rate as a side figure')
@@ -601,7 +634,7 @@ def main():
         pz = PRESETS[args.config]
         at = bool(args.all_tests or pz['all_tests'])
         refpy = start_refpy_workers({'seed': SEED, 'n0': args.n0 or pz['n0'], 'n1': args.n1 or pz['n1'], 'csr': pz['layout'] == 'csr',
-                                     'i16': args.dtype == 'i16', 'method': 'fisher' if at else 'stouffer', 'pos_begin': 0,
+                                     'i16': args.dtype == 'i16', 'method': 'fisher' if at else 'stouffer', 'pos_begin': 0, 'spread': args.spread,
                                      'stride': 1_000_000, 'min_positions': args.refpy_positions, 'max_positions': 50 * args.refpy_positions,
                                      'budget_s': args.refpy_seconds, 'workload_positions': args.positions or pz['positions']}, usable_cpus())
 
@@ -642,11 +675,17 @@ def main():
                             flags=L.FLAG_KS_RATIONAL_D if rational_d else 0)
     d_gate = [KS_D_RATIONAL_ABS if rational_d else 0.0]
 
-    def fill(b, ties):
+    def fill(b, ties, spread=None, keys=('sig0', 'sig1')):
         """(re)generate a block's samples on the device from global position counters.  ties == 'real': the int16
-        milli-unit grid (float32 input: k / 1000 as float32 — equal k <=> equal value)."""
-        for g, key in ((0, 'sig0'), (1, 'sig1')):
+        milli-unit grid (float32 input: k / 1000 as float32 — equal k <=> equal value).  spread > 0: event-like rows
+        (nmod_synth_fill_events: a level per position, reads spread around it, on the grid)."""
+        spread = args.spread if spread is None else spread
+        for g, key in ((0, keys[0]), (1, keys[1])):
             dst = b[key]
+            if spread > 0:
+                det.synth_fill_events(dst, SEED, b['lo_h'], b['n'], g, n_per_pos=0 if csr else (n0, n1)[g], off=b['off%d' % g] if csr else None,
+                                      plant_period=PLANT_PERIOD, plant_shift_milli=int(round(PLANT_SHIFT * 1000)), spread_milli=spread)
+                continue
             grid = ties == 'real' and dst.dtype == torch.float32
             tgt = torch.empty(dst.numel(), dtype=torch.int16, device=dev) if grid else dst
             if csr:
@@ -727,6 +766,23 @@ def main():
             o1 = np.arange(0, (cap + 1) * n1, n1, dtype=np.int64)
         return b0['sig0'][:int(o0[-1])].cpu().numpy(), o0, b0['sig1'][:int(o1[-1])].cpu().numpy(), o1
 
+    def t_abs_gate(rows, vn):
+        """absolute tolerance of the Welch statistic (tests/helpers.py: t_abs_gate): any order of summation leaves a mean within
+        a few ulp, so t = (mean0 - mean1) / se is defined to ~ulp(max |mean|) / se — 1e-13 for event-like rows (|mean| ~ 3, se ~ 0.01)"""
+        sc = 1e-3 if rows[0].dtype == np.int16 else 1.0
+        mv = []
+        for sig, off in ((rows[0], rows[1]), (rows[2], rows[3])):
+            o = off[:vn + 1]
+            x = sig[:int(o[-1])].astype(np.float64) * sc
+            n = np.diff(o).astype(np.float64)
+            idx = np.minimum(o[:-1], max(len(x) - 1, 0))
+            s1 = np.add.reduceat(x, idx); s2 = np.add.reduceat(x * x, idx)
+            mean = s1 / n
+            mv.append((np.abs(mean), np.maximum(s2 - s1 * mean, 0.0) / np.maximum(n - 1.0, 1.0) / n))
+        with np.errstate(divide='ignore', invalid='ignore'):
+            g = 2e-14 + 6.0 * np.spacing(np.maximum(mv[0][0], mv[1][0])) / np.sqrt(mv[0][1] + mv[1][1])
+        return np.where(np.isfinite(g), g, 2e-14)
+
     def verify_against_oracle(rows, vn, outs=None, leg_all=None, leg_method=None, gate=None):
         """one finished pass of rank 0's first block against the oracle on its first vn positions (tests/helpers.py gates)"""
         outs = blocks[0]['out'] if outs is None else outs
@@ -757,7 +813,7 @@ def main():
             elif k == 'mwu_u':
                 good = ab == 0.0
             elif k == 't_t':
-                good = bool(np.all(err <= 1e-11 * np.abs(e[fin]) + 2e-14))
+                good = bool(np.all(err <= 1e-11 * np.abs(e[fin]) + t_abs_gate(rows, vn)[inner][fin]))
             else:
                 good = bool(np.all(err <= 1e-9 * np.abs(e[fin]) + 1e-12))
             ok = ok and same_special and good
@@ -893,9 +949,9 @@ def main():
                 'roofline_frac': gbs / HBM_PEAK_GBS, 'achieved_GBps': gbs, 'note': note, 'verify': v}
 
     side = {}
-    legs = set(args.side_legs.split(',')) if args.side_legs != 'all' else {'all_tests', 'int16', 'rational_d', 'real_ties', 'presets', 'drop_in'}
+    legs = set(args.side_legs.split(',')) if args.side_legs != 'all' else {'all_tests', 'int16', 'rational_d', 'real_ties', 'real_spread', 'presets', 'drop_in'}
     simple = world == 1 and not csr and not args.force_collective and not args.no_side and chunks == 1
-    headline_default = simple and args.config == 'ecoli' and args.dtype == 'f32' and args.ties == 'few' and not all_tests
+    headline_default = simple and args.config == 'ecoli' and args.dtype == 'f32' and args.ties == 'few' and not all_tests and args.spread == 0
     if headline_default and 'all_tests' in legs:
         # (a) all three tests + Fisher on the same buffers: what every real getKStest call computes (myDetect.py:331-343), BASELINE configs[2]
         det_all = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method='fisher', tests=L.TEST_ALL)
@@ -920,7 +976,7 @@ def main():
         det_r = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests, flags=L.FLAG_KS_RATIONAL_D)
         side['rational_d'] = side_leg(det_r, ('sig0', 'sig1'), blocks[0]['out'], False, method, KS_D_RATIONAL_ABS,
                                       'flags = NMOD_FLAG_KS_RATIONAL_D (skips the float-form pass of D; gate 4.5e-16); the headline of BENCH_r01..r03')
-    if simple and args.ties == 'few' and args.dtype == 'f32' and args.config in ('ecoli', 'alltests') and 'real_ties' in legs:
+    if simple and args.ties == 'few' and args.spread == 0 and args.dtype == 'f32' and args.config in ('ecoli', 'alltests') and 'real_ties' in legs:
         # (d) tie-heavy input (real NanoMod events are 3-decimal values): the buffers are refilled in place — last, nothing
         # after this leg sees the headline's rows
         for b in blocks:
@@ -928,6 +984,31 @@ def main():
         side['real_ties'] = side_leg(det, ('sig0', 'sig1'), blocks[0]['out'], all_tests, method, d_gate[0],
                                      'the same generator on the 3-decimal grid (round(1000 x) / 1000 as float32): ties between and inside the groups as in real events')
         for b in blocks:
+            fill(b, args.ties)
+    if headline_default and 'real_spread' in legs:
+        # (e) event-like rows: a signal level per position (+-3 units, both groups), reads spread sigma around it, 3-decimal grid —
+        # most samples of a position tie with another one.  All three tests (what getKStest runs on every position) at
+        # sigma = 0.1 / 0.2 / 0.4 as float32 and as int16 milli-units, KS + Stouffer at 0.2; each pass checked against the oracle
+        det_all = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method='fisher', tests=L.TEST_ALL)
+        outs_all = det_all.alloc_outputs(blocks[0]['n'])
+        det_q = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests, flags=det.flags)
+        for b in blocks:
+            b['q0'] = torch.empty(b['n'] * n0, dtype=torch.int16, device=dev); b['q1'] = torch.empty(b['n'] * n1, dtype=torch.int16, device=dev)
+        rs = {'note': 'nmod_synth_fill_events: level(position) in +-3 units shared by both groups, reads spread sigma around it, values on the '
+                      '3-decimal grid of stored events (myRefBaseSignalAnnotation.py:1108); the same 4.6 M x 200 v 200 positions'}
+        for sg in (200, 100, 400):
+            for b in blocks:
+                fill(b, 'few', sg); fill(b, 'few', sg, ('q0', 'q1'))
+            tag = 'sigma_0.%d' % (sg // 100)
+            rs['all_tests_f32_' + tag] = side_leg(det_all, ('sig0', 'sig1'), outs_all, True, 'fisher', 0.0, 'all three tests + Fisher, float32 rows, sigma = %.1f' % (sg / 1000))
+            rs['all_tests_i16_' + tag] = side_leg(det_all, ('q0', 'q1'), outs_all, True, 'fisher', 0.0, 'all three tests + Fisher, int16 milli-unit rows, sigma = %.1f' % (sg / 1000))
+            if sg == 200:
+                rs['ks_f32_' + tag] = side_leg(det, ('sig0', 'sig1'), blocks[0]['out'], False, method, d_gate[0], 'KS + Stouffer, float32 rows, sigma = 0.2')
+                rs['ks_i16_' + tag] = side_leg(det_q, ('q0', 'q1'), blocks[0]['out'], False, method, d_gate[0], 'KS + Stouffer, int16 milli-unit rows, sigma = 0.2')
+        side['real_spread'] = rs
+        del outs_all
+        for b in blocks:
+            del b['q0'], b['q1']
             fill(b, args.ties)
     if side:
         step(False); state.wait(); torch.cuda.synchronize()     # the headline's outputs are back for what follows
@@ -1039,7 +1120,7 @@ def main():
         kbuf = ctypes.create_string_buffer(96)
         L.check(L.load().nmod_describe_dispatch(ctypes.byref(prm), n0, n1, kbuf, 96), 'nmod_describe_dispatch')
         shape = 'ragged' if csr else '%dv%d' % (n0, n1)
-        key = '%s_%s_%s_%d%s' % ('all' if all_tests else 'ks', args.dtype, shape, int(pos_per_launch), ('_realties' if args.ties == 'real' else '') + ('_rationald' if rational_d else ''))
+        key = '%s_%s_%s_%d%s' % ('all' if all_tests else 'ks', args.dtype, shape, int(pos_per_launch), ('_realties' if args.ties == 'real' else '') + ('_spread%d' % args.spread if args.spread else '') + ('_rationald' if rational_d else ''))
         rec = profile_record(L.LIB_PATH, key) or {}
         tests_txt = 'KS + MWU + Welch-t + Fisher window=%d' % (2 * NB + 1) if all_tests else 'KS + weighted Stouffer window=%d' % (2 * NB + 1)
         reads_txt = ('n0 ~ LogNormal(ln 1000, 0.5) in [5, 4000], n1 ~ LogNormal(ln 50, 0.5) in [5, 400] (means %.0f v %.0f), CSR'
@@ -1050,13 +1131,16 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
             'vs_baseline': None, 'dtype': '%s keys / f64 p-values' % args.dtype,
-            'data': 'synthetic (counter-based Irwin-Hall(4) on a 262 141-value grid, support +-3.46 sigma, unit variance — '
+            'data': ('synthetic event-like rows (nmod_synth_fill_events: a level per position in +-3 units shared by both groups, reads spread '
+                     '%.1f units around it — counter-based Irwin-Hall(4), support +-3.46 sigma — on the 3-decimal grid of stored events: most '
+                     'samples of a position tie; +0.8 shift planted in group 2 every 10 000 positions)' % (args.spread / 1000)) if args.spread else
+                    'synthetic (counter-based Irwin-Hall(4) on a 262 141-value grid, support +-3.46 sigma, unit variance — '
                     'a stand-in for N(0,1); %s; +0.8 shift planted in group 2 every 10 000 positions)'
                     % ('~1 tie per position' if args.ties == 'few' and args.dtype == 'f32' else 'on the 3-decimal grid of real events: ~11 ties between the groups per 200 v 200 position'),
             'config': {'workload': '%s%s: %d positions in total (%d per GPU), %s, %s'
                                    % (preset['name'], ' x %d' % world if (world > 1 and not args.strong) else '', total, total // world, reads_txt, tests_txt),
                        'preset': args.config, 'positions_total': total, 'positions_per_gpu': total // world, 'n0': n0, 'n1': n1,
-                       'layout': 'csr' if csr else 'fixed stride', 'neighborPvalues': NB, 'WeightsDif': WDIF, 'ties': args.ties,
+                       'layout': 'csr' if csr else 'fixed stride', 'neighborPvalues': NB, 'WeightsDif': WDIF, 'ties': args.ties, 'spread_milli': args.spread,
                        'ks_d': ('exact rational max|c0 n1 - c1 n0| / (n0 n1), correctly rounded (NMOD_FLAG_KS_RATIONAL_D; <= 2 ulp from '
                                 'ks_2samp\'s float form, gate 4.5e-16)') if rational_d else
                                'ks_2samp\'s float form bit for bit (library default, flags = 0)',

@@ -236,6 +236,21 @@ int nmod_synth_fill_csr(const nmod_params* prm, uint64_t seed, int64_t pos_begin
                         int32_t group, const int64_t* off, int64_t plant_period, float plant_shift,
                         void* sig_out);
 
+/* Synthetic EVENT rows the way NanoMod stores them (benchmark input, no reference counterpart): every position has a signal
+ * LEVEL shared by both groups (+-3 normalised units: the k-mer under the pore) and each read spreads around it with standard
+ * deviation spread_milli / 1000 units; values sit on the 3-decimal grid (myRefBaseSignalAnnotation.py:1108 rounds norm_mean to
+ * 3 decimals), so most of a position's samples tie with another one — the unit-variance rows of nmod_synth_fill tie ~11 times
+ * per 200 v 200 position.  Integer-only up to the last quotient, so tests restate it bit for bit:
+ *   level(pos) = (mix64(seed ^ 0xA5A5A5A5DEADBEEF, pos, 0, 0) >> 40) % 6001 - 3000                          [milli-units]
+ *   z = (sum of the four 16-bit fields of mix64(seed, group, pos, read)) - 131070     (as nmod_synth_fill; sd 37837.2)
+ *   k = level + floor((2 z spread_milli + 37837) / 75674)  [+ plant_shift_milli at planted positions of group 1], |k| <= 32767
+ * int16 output: k.  float32 output: (float)((double)k / 1000.0), the float32 image of the stored 3-decimal value.
+ * Rows: n_per_pos > 0 fixed stride (off ignored), else `off` = DEVICE array of npos + 1 element offsets into sig_out.
+ * 0 <= spread_milli <= 8000. */
+int nmod_synth_fill_events(const nmod_params* prm, uint64_t seed, int64_t pos_begin, int64_t npos,
+                           int32_t group, int32_t n_per_pos, const int64_t* off, int64_t plant_period,
+                           int32_t plant_shift_milli, int32_t spread_milli, void* sig_out);
+
 /* HIP-event timer: records (start, stop) around every kernel the library
  * launches while prm->timer points to it; read it after synchronising. */
 enum { NMOD_KERNEL_RANK_STATS = 0, NMOD_KERNEL_FINALIZE = 1, NMOD_KERNEL_COMBINE = 2,

@@ -67,6 +67,8 @@ _SIGNATURES = {
                                   C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
     'nmod_synth_fill_csr': (C.c_int, [C.POINTER(NmodParams), C.c_uint64, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    'nmod_synth_fill_events': (C.c_int, [C.POINTER(NmodParams), C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     'nmod_evtimer_create': (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
     'nmod_evtimer_reset': (C.c_int, [C.c_void_p]),
     'nmod_evtimer_read': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

@@ -932,6 +932,28 @@ int nmod_synth_fill_csr(const nmod_params* prm, uint64_t seed, int64_t pos_begin
   return NMOD_OK;
 }
 
+int nmod_synth_fill_events(const nmod_params* prm, uint64_t seed, int64_t pos_begin, int64_t npos, int32_t group,
+                           int32_t n_per_pos, const int64_t* off, int64_t plant_period, int32_t plant_shift_milli,
+                           int32_t spread_milli, void* sig_out) {
+  int rc = check_params(prm);
+  if (rc != NMOD_OK) return rc;
+  if (npos < 0 || !sig_out || (group != 0 && group != 1) || n_per_pos < 0 || (n_per_pos == 0 && !off)) return NMOD_ERR_INVALID_ARG;
+  if (spread_milli < 0 || spread_milli > 8000 || plant_shift_milli < -16000 || plant_shift_milli > 16000) return NMOD_ERR_INVALID_ARG;
+  if (prm->memspace != NMOD_MEM_DEVICE || (prm->dtype != NMOD_DTYPE_F32 && prm->dtype != NMOD_DTYPE_I16_MILLI)) return NMOD_ERR_INVALID_ARG;
+  if (nmod_device_count() <= prm->device || prm->device < 0) return NMOD_ERR_NO_DEVICE;
+  NMOD_HIP(hipSetDevice(prm->device));
+  if (npos == 0) return NMOD_OK;
+  hipStream_t stream = (hipStream_t)prm->stream;
+  SynthEventArgs sa;
+  sa.seed = seed; sa.pos_begin = pos_begin; sa.npos = npos; sa.group = group; sa.n_per_pos = n_per_pos; sa.off = off;
+  sa.plant_period = plant_period; sa.plant_shift_milli = plant_shift_milli; sa.spread_milli = spread_milli; sa.dtype = prm->dtype; sa.out = sig_out;
+  unsigned blocks = (unsigned)std::min<int64_t>((npos + 3) / 4, 256 * 32);
+  ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_SYNTH, stream);
+  hipLaunchKernelGGL(synth_event_kernel, dim3(blocks), dim3(256), 0, stream, sa);
+  NMOD_HIP(hipGetLastError());
+  return NMOD_OK;
+}
+
 int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char* buf, int32_t buflen) {
   int rc = check_params(prm);
   if (rc != NMOD_OK) return rc;

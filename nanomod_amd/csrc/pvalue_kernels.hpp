@@ -230,4 +230,51 @@ __global__ __launch_bounds__(256) void synth_csr_kernel(SynthCsrArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// K5b synthetic EVENT rows (include/nanomod_hip.h: nmod_synth_fill_events): a level per position (both groups share it)
+// plus a per-read spread, on the milli-unit grid of stored NanoMod events.  Integer-only up to the final quotient:
+//   level(pos) = (mix(seed ^ kLevelSalt, pos, 0, 0) >> 40) % 6001 - 3000                       milli-units, +-3 units
+//   k = level + floor((2 z spread_milli + 37837) / 75674)  [+ shift_milli: planted positions of group 1],  z = s - 131070
+// (z has standard deviation 37837.2: k - level is z spread / sd rounded to the nearest milli-unit), clamped to int16;
+// float32 output is the float64 quotient k / 1000.0 rounded to float32 — what a stored 3-decimal event value is.
+constexpr uint64_t kLevelSalt = 0xA5A5A5A5DEADBEEFull;
+
+__device__ __forceinline__ int synth_event_level(uint64_t seed, int64_t pos) {
+  return (int)((synth_mix(seed ^ kLevelSalt, pos, 0, 0u) >> 40) % 6001ull) - 3000;
+}
+__device__ __forceinline__ int synth_event_key(uint64_t seed, int64_t pos, int32_t group, uint32_t read, int level, int spread_milli, int shift) {
+  const uint64_t h = synth_mix(seed, pos, group, read);
+  const int z = (int)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + (h >> 48)) - 131070;
+  constexpr int kBias = 4096;                                    // (floor division through a non-negative numerator)
+  const int q = (2 * z * spread_milli + 37837 + kBias * 75674) / 75674 - kBias;
+  return min(max(level + q + shift, -32767), 32767);
+}
+
+struct SynthEventArgs {
+  uint64_t seed; int64_t pos_begin; int64_t npos; int32_t group; int32_t n_per_pos; const int64_t* off;
+  int64_t plant_period; int32_t plant_shift_milli; int32_t spread_milli; int32_t dtype; void* out;
+};
+
+// one wave per row (fixed stride or CSR)
+__global__ __launch_bounds__(256) void synth_event_kernel(SynthEventArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int64_t rel = wave; rel < a.npos; rel += (int64_t)gridDim.x * 4) {
+    const int64_t o = a.n_per_pos > 0 ? rel * (int64_t)a.n_per_pos : a.off[rel];
+    const int n = a.n_per_pos > 0 ? a.n_per_pos : (int)(a.off[rel + 1] - o);
+    const int64_t pos = a.pos_begin + rel;
+    int shift = 0;
+    if (a.group == 1 && a.plant_period > 0) {
+      const int64_t m = pos % a.plant_period;
+      if (m == 0 || m == 1 || m == a.plant_period - 1) shift = a.plant_shift_milli;
+    }
+    const int level = synth_event_level(a.seed, pos);
+    for (int read = lane; read < n; read += 64) {
+      const int k = synth_event_key(a.seed, pos, a.group, (uint32_t)read, level, a.spread_milli, shift);
+      if (a.dtype == NMOD_DTYPE_F32) reinterpret_cast<float*>(a.out)[o + read] = (float)((double)k / 1000.0);
+      else reinterpret_cast<int16_t*>(a.out)[o + read] = (int16_t)k;
+    }
+  }
+}
+
 }  // namespace nmod

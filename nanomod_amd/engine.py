@@ -341,6 +341,17 @@ class DeviceDetector:
         L.check(rc, 'nmod_synth_fill_csr')
         return out
 
+    def synth_fill_events(self, out, seed, pos_begin, npos, group, n_per_pos=0, off=None, plant_period=0, plant_shift_milli=0,
+                          spread_milli=200):
+        """event-like rows (nmod_synth_fill_events): a level per position, reads spread `spread_milli` around it, on the
+        3-decimal grid; fixed stride (n_per_pos > 0) or ragged (`off` = int64 CUDA tensor of npos + 1 offsets)"""
+        prm = self._params(self._dtype_of(out), 0, 0, 0, 0)
+        rc = self.lib.nmod_synth_fill_events(C.byref(prm), seed, pos_begin, npos, group, n_per_pos,
+                                             off.data_ptr() if off is not None else None, plant_period,
+                                             int(plant_shift_milli), int(spread_milli), out.data_ptr())
+        L.check(rc, 'nmod_synth_fill_events')
+        return out
+
 
 def downsample_ks(sig0, off0, sig1, off1, positions, cov, *, iters=100, quantile=0.25, seed=0, device=0):
     """The down-sampling branch of getKStest (myDetect.py:345-361) for the positions `positions` (indices into

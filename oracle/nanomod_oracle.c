@@ -138,6 +138,32 @@ static double chi2_sf_even(double X, int W) {
 }
 
 /* ---- per-position tests ------------------------------------------------ */
+/* numpy's add.reduce over a contiguous double array (numpy/core/src/umath/loops_utils.h, DOUBLE_pairwise_sum; the same
+ * since numpy 1.9, so also the reference's 1.16.6): fewer than 8 elements in order, up to 128 with eight strided
+ * accumulators, longer arrays split in halves (the first a multiple of 8).  np.mean and np.var — and through them
+ * scipy's ttest_ind, myDetect.py:335 — sum this way, so the Welch statistic is restated with the same rounding order:
+ * on rows with a large common level a sequential sum differs from it by ~1e-13 in t. */
+static double np_pairwise_sum(const double* a, int64_t n) {
+  if (n < 8) {
+    double res = 0.0;
+    for (int64_t i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int64_t i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int64_t n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
 static int cmp_double(const void* a, const void* b) {
   double x = *(const double*)a, y = *(const double*)b;
   return (x > y) - (x < y);
@@ -199,12 +225,13 @@ static void test_position(const double* a, int n0, const double* b, int n1, int 
   }
   if (tests & 4) {
     /* ttest_ind(equal_var=False) */
-    double m0 = 0, m1 = 0, q0 = 0, q1 = 0;
-    for (int i = 0; i < n0; ++i) m0 += a[i];
-    for (int j = 0; j < n1; ++j) m1 += b[j];
-    m0 /= n0; m1 /= n1;
-    for (int i = 0; i < n0; ++i) q0 += (a[i] - m0) * (a[i] - m0);
-    for (int j = 0; j < n1; ++j) q1 += (b[j] - m1) * (b[j] - m1);
+    /* np.mean / np.var(ddof=1) as scipy's ttest_ind calls them: numpy's pairwise summation (below), the squared
+       deviations formed first (work) and summed the same way */
+    double m0 = np_pairwise_sum(a, n0) / n0, m1 = np_pairwise_sum(b, n1) / n1;
+    for (int i = 0; i < n0; ++i) work[i] = (a[i] - m0) * (a[i] - m0);
+    double q0 = np_pairwise_sum(work, n0);
+    for (int j = 0; j < n1; ++j) work[j] = (b[j] - m1) * (b[j] - m1);
+    double q1 = np_pairwise_sum(work, n1);
     double v1 = q0 / (n0 - 1.0), v2 = q1 / (n1 - 1.0), vn1 = v1 / n0, vn2 = v2 / n1;
     double df = (vn1 + vn2) * (vn1 + vn2) / (vn1 * vn1 / (n0 - 1.0) + vn2 * vn2 / (n1 - 1.0));
     if (isnan(df)) df = 1.0;

@@ -102,3 +102,7 @@ def test_cpu_leg_generator_is_the_device_generator():
         a = bench.synth_rows(bench.SEED, 9990, 30, group, 57, bench.PLANT_PERIOD, bench.PLANT_SHIFT, i16)
         b = H.synth_ref(bench.SEED, 9990, 30, group, 57, bench.PLANT_PERIOD, bench.PLANT_SHIFT, 'i16' if i16 else 'f32')
         assert a.shape == (30, 57) and np.array_equal(a.reshape(-1), b) and a.dtype == b.dtype
+    for group, i16, spread in ((0, False, 200), (1, False, 100), (1, True, 400)):
+        a = bench.synth_event_rows(bench.SEED, 9990, 30, group, 57, bench.PLANT_PERIOD, 800, spread, i16)
+        b = H.synth_events_ref(bench.SEED, 9990, 30, group, 57, bench.PLANT_PERIOD, 800, spread, 'i16' if i16 else 'f32')
+        assert a.shape == (30, 57) and np.array_equal(a, b) and a.dtype == b.dtype

@@ -133,6 +133,76 @@ def _random_batch(rng, npos, lo0, hi0, lo1, hi1, grid=False, shift_every=7):
     return np.concatenate(ca), off0, np.concatenate(cb), off1, rid
 
 
+def test_synth_fill_events_matches_the_numpy_restatement(nm):
+    """nmod_synth_fill_events (bench.py's `real_spread` legs): level per position + spread per read on the milli-unit grid,
+    fixed stride and ragged rows, float32 and int16 output, planted shift, counter-based (any pos_begin)"""
+    import torch
+    L = nm._lib
+    rng = np.random.default_rng(4)
+    P, begin = 600, 9_990
+    sizes = rng.integers(0, 300, P); sizes[5] = 0; sizes[17] = 1
+    off = np.zeros(P + 1, np.int64); off[1:] = np.cumsum(sizes)
+    det = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    d_off = torch.from_numpy(off).cuda()
+    nmax = int(sizes.max())
+    for tdt, name in ((torch.float32, 'f32'), (torch.int16, 'i16')):
+        for g in (0, 1):
+            for spread in (0, 100, 200, 400):
+                ref = H.synth_events_ref(77, begin, P, g, nmax, 10000, 800, spread, dtype=name)
+                out = torch.zeros(int(off[-1]), dtype=tdt, device='cuda:0')
+                det.synth_fill_events(out, 77, begin, P, g, off=d_off, plant_period=10000, plant_shift_milli=800, spread_milli=spread)
+                exp = np.concatenate([ref[i, :sizes[i]] for i in range(P)])
+                assert np.array_equal(out.cpu().numpy(), exp), (name, g, spread, 'csr')
+                out = torch.zeros(P * 37, dtype=tdt, device='cuda:0')
+                det.synth_fill_events(out, 77, begin, P, g, n_per_pos=37, plant_period=10000, plant_shift_milli=800, spread_milli=spread)
+                assert np.array_equal(out.cpu().numpy().reshape(P, 37), ref[:, :37]), (name, g, spread, 'stride')
+    # both groups share the level; the float32 image is the stored 3-decimal value
+    a = H.synth_events_ref(77, 0, 50, 0, 200, 0, 0, 100, 'i16'); b = H.synth_events_ref(77, 0, 50, 1, 200, 0, 0, 100, 'i16')
+    assert np.all(np.abs(a.mean(axis=1) - b.mean(axis=1)) < 60) and a.mean(axis=1).std() > 1000
+    f = H.synth_events_ref(77, 0, 50, 0, 200, 0, 0, 100, 'f32')
+    assert np.array_equal(f, (a.astype(np.float64) / 1000.0).astype(np.float32))
+    bad = L.make_params(device=0, memspace=L.MEM_DEVICE, dtype=L.DTYPE_F32)
+    assert L.load().nmod_synth_fill_events(bad, 1, 0, 10, 0, 5, None, 0, 0, 9000, 1) == -1
+    assert L.load().nmod_synth_fill_events(bad, 1, 0, 10, 0, 0, None, 0, 0, 100, 1) == -1
+
+
+@pytest.mark.parametrize('spread', [100, 200, 400])
+@pytest.mark.parametrize('dtype', ['f32', 'i16'])
+def test_event_like_batches_vs_oracle(nm, spread, dtype):
+    """event-like rows (a level per position, reads spread 0.1 / 0.2 / 0.4 units around it, 3-decimal grid: most samples tie):
+    200 v 200 fixed stride and ragged sizes around it, KS-only and all tests, against the oracle"""
+    import nanomod_oracle as orc
+    import oracle_c
+    L = nm._lib
+    P = 1200
+    a = H.synth_events_ref(11, 4990, P, 0, 256, 5000, 800, spread, dtype)
+    b = H.synth_events_ref(11, 4990, P, 1, 256, 5000, 800, spread, dtype)
+    rid = np.zeros(P, np.int32)
+    rng = np.random.default_rng(spread)
+    for shape in ('stride', 'ragged'):
+        if shape == 'stride':
+            s0 = np.full(P, 200); s1 = np.full(P, 200)
+        else:
+            s0 = rng.integers(120, 257, P); s1 = rng.integers(120, 257, P)
+            s0[:4] = (255, 256, 255, 256); s1[:4] = (255, 255, 256, 256)
+        off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum(s0)
+        off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum(s1)
+        sig0 = np.concatenate([a[i, :s0[i]] for i in range(P)]); sig1 = np.concatenate([b[i, :s1[i]] for i in range(P)])
+        exp = oracle_c.detect_batch(sig0, off0, sig1, off1, rid, 2, 2.0, 'fisher', tests=7)
+        kw = dict(stride0=200, stride1=200) if shape == 'stride' else {}
+        got = nm.detect_host(sig0, None if shape == 'stride' else off0, sig1, None if shape == 'stride' else off1, rid, nb=2,
+                             weights_dif=2.0, method='fisher', **kw)
+        H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(sig0, off0, sig1, off1))
+        assert np.array_equal(got['status'], exp['status'])
+        got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='fisher', tests=L.TEST_KS)
+        assert np.array_equal(got['ks_d'], exp['ks_d'])
+        H.assert_close_p(got['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
+        H.assert_close_p(got['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
+    # the oracle's two implementations agree on such rows (the C one is what the big comparisons use)
+    e2 = orc.detect_batch(sig0[:off0[40]], off0[:41], sig1[:off1[40]], off1[:41], rid[:40], 2, 2.0, orc.METHOD_FISHER)
+    assert np.array_equal(e2['mwu_u'], exp['mwu_u'][:40]) and np.array_equal(e2['ks_d'], exp['ks_d'][:40])
+
+
 # general (64 lanes per group) and packed (two positions per wave) kernels, every capacity class
 @pytest.mark.parametrize('sizes', [(5, 64, 5, 64), (65, 128, 3, 30), (65, 128, 65, 128), (129, 256, 129, 256),
                                    (100, 128, 129, 220), (257, 512, 257, 512), (300, 512, 20, 256),

@@ -47,6 +47,25 @@ def test_c_edge_cases_and_int16():
     H.compare_outputs(g, e, True)
 
 
+def test_c_welch_sums_like_numpy():
+    """np.mean / np.var under scipy's ttest_ind sum pairwise (numpy's add.reduce): on rows that share a large level the order of
+    summation is visible in t at 1e-13; the C restatement follows numpy's order and gives the Python oracle's t bit for bit"""
+    for dt in ('i16', 'f32'):
+        for n in (5, 8, 37, 128, 129, 200, 255, 1000):
+            P = 120
+            a = H.synth_events_ref(11, 0, P, 0, n, 0, 0, 100, dt); b = H.synth_events_ref(11, 0, P, 1, n, 0, 0, 100, dt)
+            off = np.arange(0, (P + 1) * n, n, dtype=np.int64)
+            got = oracle_c.detect_batch(a.reshape(-1), off, b.reshape(-1), off, np.zeros(P, np.int32), 2, 2.0, 'fisher', tests=7)
+            sc = 1000.0 if dt == 'i16' else 1.0
+            tt = np.array([orc.ttest_welch(a[i].astype(np.float64) / sc, b[i].astype(np.float64) / sc)[0] for i in range(P)])
+            assert np.array_equal(tt, got['t_t']), (dt, n)
+    # the gate the GPU tests use for t on such rows (helpers.t_abs_gate) is ~1e-13 there and 2e-14 around zero
+    g = H.t_abs_gate(a.reshape(-1), off, b.reshape(-1), off)
+    assert g.shape == (P,) and 2e-14 < np.median(g) < 2e-12
+    z = np.random.default_rng(1).normal(0, 1, 800).astype(np.float32)
+    assert H.t_abs_gate(z[:400], np.array([0, 200, 400]), z[400:], np.array([0, 200, 400])).max() < 3e-14
+
+
 def test_c_special_function_tails():
     """p-values down to DBL_MIN: extreme separation, tiny windows"""
     n = 2000

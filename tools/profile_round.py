@@ -32,7 +32,9 @@ SHA = hashlib.sha256(open(LIB, 'rb').read()).hexdigest()[:16]
 
 CONFIGS = [('ks_f32', []), ('all_f32', ['--config', 'alltests']), ('ks_i16', ['--dtype', 'i16']),
            ('all_i16', ['--config', 'alltests', '--dtype', 'i16']), ('ks_f32_realties', ['--ties', 'real']),
-           ('ks_f32_rationald', ['--rational-d'])]
+           ('ks_f32_rationald', ['--rational-d']),
+           ('all_f32_spread200', ['--config', 'alltests', '--spread', '200']), ('all_i16_spread200', ['--config', 'alltests', '--spread', '200', '--dtype', 'i16']),
+           ('ks_f32_spread200', ['--spread', '200']), ('ks_i16_spread200', ['--spread', '200', '--dtype', 'i16'])]
 if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minutes per pass): only on request
     CONFIGS += [('ragged_all_f32', ['--config', 'ragged', '--all-tests', '--steps', '3', '--warmup', '1']),
                 ('ragged_all_f32_realties', ['--config', 'ragged', '--all-tests', '--ties', 'real', '--steps', '3', '--warmup', '1']),
@@ -41,7 +43,7 @@ if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minut
                 ('chr20_ks_f32', ['--config', 'chr20', '--steps', '3', '--warmup', '1'])]
 if len(sys.argv) > 2:                      # python3 tools/profile_round.py r3 ks_f32,all_f32
     CONFIGS = [c for c in CONFIGS if c[0] in sys.argv[2].split(',')]
-K1_NAMES = ('ks_rank_kernel', 'rank_hist_kernel', 'rank_pair_kernel', 'big_rank_kernel', 'big_hist_kernel')
+K1_NAMES = ('ks_rank_kernel', 'rank_hist_kernel', 'rank_pair_kernel', 'big_rank_kernel', 'big_hist_kernel', 'rank_count_kernel')
 PMC_GROUPS = [
     ['FETCH_SIZE'], ['WRITE_SIZE'],
     ['SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_VALU', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY'],

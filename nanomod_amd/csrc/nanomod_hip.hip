@@ -63,7 +63,7 @@ struct ScopedKernelTimer {
 struct Workspace {
   uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments;
   double* tmp_ks_d; double* tmp_ks_p; double* ks_d_ref;
-  int32_t* order; int32_t* redo; uint8_t* cls; uint8_t* tied; int32_t* meta;   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
+  int32_t* order; int32_t* redo; uint8_t* cls; uint8_t* tied; uint8_t* cnt_done; int32_t* meta;   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
   int64_t bytes;
 };
 constexpr int kMetaInts = 256;
@@ -71,10 +71,11 @@ constexpr int kMetaMax = 3 * kClassStride;      // [168..169] max n0 / n1
 constexpr int kMetaBigTotal = kMetaMax + 2;     // [170..171] u64: scratch floats the large positions need
 constexpr int kMetaBigCursor = kMetaMax + 4;    // [172..173] u64: bump allocator of big_rank_kernel
 constexpr int kMetaWideRedo = kMetaMax + 8;     // [176] positions on the WIDE form's redo list (wide_redo_kernel)
+constexpr int kMetaCntGate = kMetaMax + 10;     // [178] the counting form's gate (cnt_probe_kernel: 1 = the batch is event-like)
 constexpr int kMetaRedo = 184;                  // float64 front end: [184] count of positions to redo, [184 + kClassStride] = 0 (their
                                                 // offset in the list), [242..243] u64 scratch keys they need, [244..245] u64 bump allocator
 constexpr int kMetaRedoTotal = 242, kMetaRedoCursor = 244;
-static_assert(kMetaRedo + kClassStride < kMetaRedoTotal && kMetaRedoCursor + 2 <= kMetaInts && kMetaBigCursor + 2 <= kMetaWideRedo && kMetaWideRedo < kMetaRedo, "meta layout");
+static_assert(kMetaRedo + kClassStride < kMetaRedoTotal && kMetaRedoCursor + 2 <= kMetaInts && kMetaBigCursor + 2 <= kMetaWideRedo && kMetaWideRedo < kMetaCntGate && kMetaCntGate < kMetaRedo, "meta layout");
 // (kBigClass, kBigHistClass, kWideBigBase .., kNumPairs: rank_stats_launch.hpp)
 static_assert(kNumPairs <= kClassStride, "class tables");
 
@@ -96,6 +97,7 @@ static Workspace carve(void* base, int64_t npos) {
   w.redo = (int32_t*)take(4 * npos);
   w.cls = (uint8_t*)take(npos);
   w.tied = (uint8_t*)take(npos);
+  w.cnt_done = (uint8_t*)take(npos + 16);        // counting form (rank_count.hpp): one flag byte per entry of the work list, dword per item
   w.meta = (int32_t*)take(kMetaInts * 4);
   w.bytes = o;
   return w;
@@ -485,6 +487,11 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     return NMOD_OK;
   };
   const bool wide_f32 = all && prm->dtype == NMOD_DTYPE_F32;
+  // all tests on capacity-256 positions: the counting form is tried first (rank_count.hpp; a device-side probe decides whether
+  // the batch is event-like, positions it cannot take fall through to rank_hist_kernel).  Not for float32 images of float64
+  // samples (their grid positions carry k, not k / 1000, as keys).  NMOD_NO_COUNTING=1 in the environment turns it off (A/B).
+  static const bool counting_off = []() { const char* e = getenv("NMOD_NO_COUNTING"); return e && *e && *e != '0'; }();
+  if (all && !f64 && !counting_off) { ra.cnt_gate = ws.meta + kMetaCntGate; ra.cnt_done = ws.cnt_done; }
 
   auto launch = [&](int cls, int64_t work) -> hipError_t {
     ra.class_id = cls;

@@ -183,9 +183,14 @@ __device__ __forceinline__ unsigned pos_allsum_u32(unsigned v) {     // sum over
 constexpr unsigned kWideEmpty = 0xffffffffu;
 constexpr int kWideList = 128;                     // words of the list in front of the exact table: < 64 waiting + <= 64 of one flush
 
-template <int R, int LG, int DTYPE, bool WIDE = false>
+// AFTER (R = LG = 16 only): the launch follows rank_count_kernel (rank_count.hpp) over the same work list.  When the probe's
+// gate is set, that kernel has left one flag byte per position, four per work item (cnt_done as dwords): a wave reads the
+// dwords of its next 64 items with one load and walks only the items that still hold a position (a 64-bit mask), and
+// inside such an item only those positions are valid.  Gate clear: every item, as without AFTER.
+template <int R, int LG, int DTYPE, bool WIDE = false, bool AFTER = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (WIDE ? 2 : (R <= 16 ? NMOD_HIST_WAVES : 2)))
 void rank_hist_kernel(RankStatsArgs args) {
+  static_assert(!AFTER || (!WIDE && 64 / LG == 4), "the counting form works on items of four positions");
   static_assert(WIDE ? (LG == 64 && (R == 1 || R == 2 || R == 4)) : (LG == 8 || LG == 16 || LG == 32 || LG == 64), "lanes per sorted group");
   static_assert(WIDE || (R >= 8 && R <= 32 && (R & (R - 1)) == 0), "registers per lane");
   static_assert(R * LG <= 1024, "32-bit tie sums and 15-bit counts need sorted groups of at most 1024 samples");   // (WIDE: Q <= 4096 < 2^15)
@@ -224,12 +229,39 @@ void rank_hist_kernel(RankStatsArgs args) {
   const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * kWavesPerBlock;
 
+  // AFTER: the items this wave still has to do among its next 64 (item `win_base + j * wave_stride` <-> bit j / lane j's dword)
+  bool after_count = false;
+  int64_t win_base = wave_global;
+  unsigned long long win_todo = 0ull;
+  unsigned win_flags = 0u;                       // lane j: the four flag bytes of item win_base + j * wave_stride (1 = done)
+  unsigned cur_flags = 0u;                       // ... of the item being described
+  if constexpr (AFTER) after_count = args.cnt_gate[0] != 0;
+  [[maybe_unused]] auto load_window = [&]() {
+    const int64_t mine = win_base + (int64_t)(threadIdx.x & 63) * wave_stride;
+    win_flags = 0x01010101u;
+    if (mine < items) win_flags = after_count ? reinterpret_cast<const unsigned*>(args.cnt_done)[mine] : 0u;
+    win_todo = __ballot(win_flags != 0x01010101u);
+  };
+  // the first item at or after the window's start that still holds work (>= items: none)
+  [[maybe_unused]] auto next_in_windows = [&]() -> int64_t {
+    while (win_todo == 0ull) {
+      win_base += 64 * wave_stride;
+      if (win_base >= items) return items;
+      load_window();
+    }
+    const int j = __ffsll((long long)win_todo) - 1;
+    win_todo &= win_todo - 1ull;
+    cur_flags = (unsigned)__builtin_amdgcn_readlane((int)win_flags, j);
+    return win_base + (int64_t)j * wave_stride;
+  };
+
   // One work item = the PW positions of a wave.  S = the smaller group (ties: group 1).
   struct Item { bool valid, swap; int m, q; int64_t pos, off_s, off_q; };
   auto describe = [&](int64_t it) {
     Item d;
     const int64_t li = it * PW + slot;
     d.valid = it < items && li < count;
+    if constexpr (AFTER) d.valid = d.valid && ((cur_flags >> (8 * slot)) & 0xffu) == 0u;
     d.pos = d.valid ? (list ? (int64_t)list[li] : li) : 0;
     int64_t o0 = 0, o1 = 0; int n0 = 0, n1 = 0;
     if (d.valid) {
@@ -265,7 +297,11 @@ void rank_hist_kernel(RankStatsArgs args) {
   }
   __syncthreads();
 
-  Item cur = describe(wave_global);
+  int64_t it_first = wave_global;
+  if constexpr (AFTER) {
+    if (win_base < items) { load_window(); it_first = next_in_windows(); } else it_first = items;
+  }
+  Item cur = describe(it_first);
   constexpr bool PACKED = !WIDE && ks_packed_sort(R, LG, DTYPE);           // int16 rows sorted two keys per register
   float x[R];
   unsigned pk[8];                                  // PACKED: the item's S rows as packed int16 keys (x is filled by the sort)
@@ -280,7 +316,8 @@ void rank_hist_kernel(RankStatsArgs args) {
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 
   const int lane_k = lane;
-  for (int64_t it = wave_global; it < items; it += wave_stride) {
+  int64_t it_next = 0;
+  for (int64_t it = it_first; it < items; it = it_next) {
     // everything derived from the lane number is re-derived per item from an opaque copy: hoisted out of the loop
     // the index constants of the unrolled sweeps (gl * R + r, ...) would occupy ~40 registers for the whole kernel
     int lane = lane_k;
@@ -1059,7 +1096,8 @@ void rank_hist_kernel(RankStatsArgs args) {
 
     // the next item's S rows: requested as late as the rest of the iteration can still cover the round trip (they
     // occupy 16 registers from here on)
-    const Item nxt = describe(it + wave_stride);
+    if constexpr (AFTER) it_next = next_in_windows(); else it_next = it + wave_stride;
+    const Item nxt = describe(it_next);
     KsRows<(WIDE ? 4 : R), LG, DTYPE> rows_next;                             // (WIDE: unused; its rows are R < 4 plain loads)
     float xn[WIDE ? R : 1];
     if constexpr (WIDE) load_group<R, DTYPE>(xn, nxt.swap ? args.sig1 : args.sig0, nxt.off_s, nxt.m, lane);

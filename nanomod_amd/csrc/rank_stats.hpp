@@ -43,6 +43,10 @@ struct RankStatsArgs {
   double* ks_d_ref;                            // [npos] max |fl(c0/n0) - fl(c1/n1)| exactly as ks_2samp forms it (all-tests mode)
   uint8_t* tied;                               // [npos] or null: 1 where the position's keys tie (see ks_rank_kernel FLAGS; all-tests: any tie)
   int32_t* redo_list; int32_t* redo_count;     // WIDE float32 form: positions whose streamed group's ties are counted by wide_redo_kernel
+  // counting form (rank_count.hpp): gate[0] != 0 <=> cnt_probe_kernel found the batch event-like and rank_count_kernel ran;
+  // cnt_done: one byte per entry of the work list (four per item, read as a dword), 1 where it produced the position's results
+  // (0: left to the rank_hist_kernel<.., AFTER> launch that follows).  Both null: the counting form is not tried.
+  int32_t* cnt_gate; uint8_t* cnt_done;
 };
 
 // compare-exchange of two registers.  (fminf / fmaxf put a canonicalising v_max x, x in front of every value of unknown

@@ -7,6 +7,7 @@
 #include "ks_rank.hpp"
 #include "rank_all.hpp"
 #include "rank_hist.hpp"
+#include "rank_count.hpp"
 #include "rank_stats_launch.hpp"
 #include "build_info.hpp"
 
@@ -54,7 +55,8 @@ KernelFn pick_wide(int cmin) {
     default: return rank_hist_kernel<4, 64, DT, true>;
   }
 }
-KernelFn pick_packed(int cm) {
+KernelFn pick_packed(int cm, bool after_count) {
+  if (after_count) return rank_hist_kernel<16, 16, DT, false, true>;     // (cm == 2: behind rank_count_kernel)
   switch (cm) {
     case 0: return rank_hist_kernel<8, 8, DT>;
     case 1: return rank_hist_kernel<16, 8, DT>;
@@ -107,7 +109,9 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
 #if NMOD_INST_ALL
   if (ks) return hipErrorInvalidValue;
   const bool wide = wide_class(cls);
-  fn = packed ? pick_packed(cls - kNumGeneralClasses)
+  // capacity-256 positions with all tests: the counting form first (rank_count.hpp) when the caller provided its gate and flags
+  const bool counting = packed && cls - kNumGeneralClasses == 2 && args.cnt_gate != nullptr && args.cnt_done != nullptr;
+  fn = packed ? pick_packed(cls - kNumGeneralClasses, counting)
        : wide ? pick_wide(wide_class_of_s(cls))
               : pick(cls / kNumSizeClasses, cls % kNumSizeClasses);
 #else
@@ -124,7 +128,11 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
   static std::atomic<int> per_cu_cache[64][2 * kClassStride];     // [class] and [kClassStride + class] for the FLAGS instances
   int dev = 0;
   const bool cacheable = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+#if NMOD_INST_ALL
+  const int slot_id = cls + (counting ? kClassStride : 0);
+#else
   const int slot_id = cls + ((ks && args.tied) ? kClassStride : 0);
+#endif
   int per_cu = cacheable ? per_cu_cache[dev][slot_id].load(std::memory_order_relaxed) : 0;
   if (per_cu <= 0) {
     // (one WIDE instance serves every class of the larger group: its limit is that of the largest)
@@ -140,6 +148,32 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
     if (per_cu < 1) return hipErrorLaunchOutOfResources;     // (never launch a block that cannot get its LDS: its table walks would not end)
     if (cacheable) per_cu_cache[dev][slot_id].store(per_cu, std::memory_order_relaxed);
   }
+#if NMOD_INST_ALL
+  if (counting) {
+    // probe (one block: is the batch event-like?) -> rank_count_kernel (exits at once when it is not) -> the AFTER instance below
+    CntProbeArgs pa;
+    pa.sig0 = args.sig0; pa.sig1 = args.sig1; pa.off0 = args.off0; pa.off1 = args.off1; pa.stride0 = args.stride0; pa.stride1 = args.stride1;
+    pa.npos = args.npos; pa.pos_list = args.pos_list; pa.class_meta = args.class_meta; pa.class_id = args.class_id; pa.dtype = DT; pa.gate = args.cnt_gate;
+    hipLaunchKernelGGL(cnt_probe_kernel<DT>, dim3(1), dim3(1024), 0, stream, pa);
+    static std::atomic<int> cnt_per_cu[64];
+    KernelFn cfn = rank_count_kernel<DT>;
+    const size_t clds = rank_count_lds_bytes();
+    int cpc = cacheable ? cnt_per_cu[dev].load(std::memory_order_relaxed) : 0;
+    if (cpc <= 0) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds);
+      if (e != hipSuccess) return e;
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&cpc, cfn, 64 * kWavesPerBlock, clds);
+      if (e != hipSuccess) return e;
+      if (cpc < 1) return hipErrorLaunchOutOfResources;
+      if (cacheable) cnt_per_cu[dev].store(cpc, std::memory_order_relaxed);
+    }
+    int64_t cblocks = std::min<int64_t>((work_items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)num_cus * cpc);
+    if (cblocks < 1) cblocks = 1;
+    hipLaunchKernelGGL(cfn, dim3((unsigned)cblocks), dim3(64 * kWavesPerBlock), clds, stream, args);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+#endif
   int64_t blocks = (work_items + kWavesPerBlock - 1) / kWavesPerBlock;
   int64_t cap = (int64_t)num_cus * per_cu;
   if (blocks > cap) blocks = cap;

@@ -47,8 +47,22 @@ constexpr int kCntMaxN = 255;                                   // byte counters
 constexpr int kCntMinN = 4;                                     // (KsRows reads shorter rows through a conditional path)
 __host__ __device__ constexpr size_t rank_count_lds_bytes() { return (size_t)kWavesPerBlock * 4 * kCntPosWords * 4 + 16; }
 
-typedef __attribute__((address_space(3))) const unsigned char* CntLdsU8;
 typedef __attribute__((address_space(3))) unsigned* CntLdsU32;
+typedef short CntS2 __attribute__((ext_vector_type(2)));
+typedef unsigned short CntU2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const unsigned char* CntLdsU8;
+// lo[h] = cum[u - 1], hi[h] = cum[u] of the two slots whose byte addresses (of cum[u - 1]) are the halves of ap0 / ap1
+__device__ __forceinline__ void cnt_lookup_chunk(unsigned ap0, unsigned ap1, unsigned (&lo)[2], unsigned (&hi)[2]) {
+  unsigned b[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const unsigned ap = h ? ap1 : ap0;
+    const CntLdsU8 p0 = (CntLdsU8)(uintptr_t)(ap & 0xffffu), p1 = (CntLdsU8)(uintptr_t)(ap >> 16);
+    b[4 * h] = p0[0]; b[4 * h + 1] = p0[1]; b[4 * h + 2] = p1[0]; b[4 * h + 3] = p1[1];
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { lo[h] = b[4 * h] | (b[4 * h + 2] << 16); hi[h] = b[4 * h + 1] | (b[4 * h + 3] << 16); }
+}
 
 #ifndef NMOD_CNT_SKIP
 #define NMOD_CNT_SKIP 0
@@ -179,65 +193,84 @@ void rank_count_kernel(RankStatsArgs args) {
     const int n0 = cur.n0, n1 = cur.n1;
     bool fit = rows_n(cur, 1) != 0;
 
-    // ---- keys.  Slot s = 4 c + j of group g: component j of chunk c.  A chunk that holds the end of a row was read as the
-    // row's LAST four samples (KsRows): its components j >= 4 - t are this lane's, t = samples left at the chunk's start.
-    int k[2 * NS];                                       // integer keys (milli-units); a slot without a sample: the group's first key
-    unsigned vmask = 0u;                                 // bit s of group g at 16 g + s: the slot holds a sample
+    // ---- keys, two per register (int16 halves).  Chunk c of group g = registers KP[8 g + 2 c], KP[8 g + 2 c + 1]: components
+    // (0, 1) and (2, 3), i.e. samples 64 c + 4 gl + 0 .. 3.  A chunk that holds the end of a row was read as the row's LAST four
+    // samples (KsRows): its components j >= 4 - t are this lane's, t = samples left at the chunk's start.  Per chunk, wave-wide:
+    // `full` — every lane of the wave holds four samples (no selects anywhere); `any` — some lane holds a sample (a chunk without
+    // any is skipped in every phase).  A slot without a sample carries the group's first key.
+    unsigned KP[NS];                                     // [8 g + 2 c + h]
+    unsigned vmask = 0u;                                 // bit 16 g + 4 c + j: the slot holds a sample (chunks that are not full)
+    unsigned fullm = 0u, anym = 0u;                      // wave-uniform: bit 4 g + c
     bool bad = false;                                    // float32: a sample of this lane is off the grid
     double f1[2] = {0.0, 0.0}, f2[2] = {0.0, 0.0};       // float32: shifted moment sums of the values
     int i1[2] = {0, 0}, i2[2] = {0, 0};                  // int16: exact moment sums of k - first key
-    int kfirst[2];
+    int kfirst[2] = {0, 0};
+    float xfirst2[2] = {0.0f, 0.0f};
+    CntS2 MN = {32767, 32767}, MX = {-32768, -32768};
+    const CntS2 ones = {1, 1};
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const Rows& rw = g ? rw1 : rw0;
       const int n = rows_n(cur, g ? n1 : n0);
-      float xf[NS];
-      int ki[NS];
+      // the group's first sample (lane 0, chunk 0, component 0: there for every row of at least 4 samples) stands in the empty slots
+      float xfirst = 0.0f; double K = 0.0; int kf = 0;
+      if constexpr (DTYPE == 0) {
+        xfirst = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & ~(LG - 1)) << 2, __float_as_int((float)rw.v[0].x)));
+        K = (double)xfirst;
+        xfirst2[g] = xfirst;
+      } else {
+        kf = __builtin_amdgcn_ds_bpermute((lane & ~(LG - 1)) << 2, (int)rw.v[0].x);
+      }
+      kfirst[g] = kf;
+      const unsigned kf2 = ((unsigned)kf & 0xffffu) | ((unsigned)kf << 16);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        if constexpr (DTYPE == 0) { xf[4 * c] = rw.v[c].x; xf[4 * c + 1] = rw.v[c].y; xf[4 * c + 2] = rw.v[c].z; xf[4 * c + 3] = rw.v[c].w; }
-        else { ki[4 * c] = (int)rw.v[c].x; ki[4 * c + 1] = (int)rw.v[c].y; ki[4 * c + 2] = (int)rw.v[c].z; ki[4 * c + 3] = (int)rw.v[c].w; }
         const int t = n - (c * 64 + 4 * gl);
-        const int first = (t >= 4) ? 0 : ((t <= 0) ? 4 : 4 - t);        // components first .. 3 are samples of this lane
+        const bool full = __ballot(t < 4) == 0ull;
+        const bool any = __ballot(t > 0) != 0ull;
+        fullm |= full ? (1u << (4 * g + c)) : 0u;
+        anym |= any ? (1u << (4 * g + c)) : 0u;
+        if (!any) continue;
+        const int first = (t >= 4) ? 0 : ((t <= 0) ? 4 : 4 - t);          // components first .. 3 are samples of this lane
+        if (!full) vmask |= (0xfu & (0xfu << first)) << (16 * g + 4 * c);
+        if constexpr (DTYPE == 0) {
+          auto four = [&](auto full_tag) {
+            int kk[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vmask |= (j >= first) ? (1u << (16 * g + 4 * c + j)) : 0u;
-      }
-      // the group's first sample (lane 0, chunk 0, component 0: there for every row of at least 4 samples) stands in the empty slots
-      if constexpr (DTYPE == 0) {
-        const float xfirst = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & ~(LG - 1)) << 2, __float_as_int(xf[0])));
-        const double K = (double)xfirst;
+            for (int j = 0; j < 4; ++j) {
+              const float xr = (j == 0) ? rw.v[c].x : (j == 1) ? rw.v[c].y : (j == 2) ? rw.v[c].z : rw.v[c].w;
+              const float x = (decltype(full_tag)::value || j >= first) ? xr : xfirst;
+              const bool ok = grid_key<true>(x, kk[j]);                    // (|k| <= 32 767: the key fits its half)
+              bad = bad || !ok;
+              const double d = (double)x - K;
+              f1[g] += d;
+              f2[g] = __fma_rn(d, d, f2[g]);
+            }
+            KP[8 * g + 2 * c] = ((unsigned)kk[0] & 0xffffu) | ((unsigned)kk[1] << 16);
+            KP[8 * g + 2 * c + 1] = ((unsigned)kk[2] & 0xffffu) | ((unsigned)kk[3] << 16);
+          };
+          if (full) four(std::true_type{}); else four(std::false_type{});
+        } else {
+          unsigned p0 = ((unsigned)(unsigned short)rw.v[c].x) | ((unsigned)(unsigned short)rw.v[c].y << 16);
+          unsigned p1 = ((unsigned)(unsigned short)rw.v[c].z) | ((unsigned)(unsigned short)rw.v[c].w << 16);
+          if (!full) {                                                      // the components below `first`: the group's first key
+            const unsigned m0 = (first <= 0 ? 0xffffu : 0u) | (first <= 1 ? 0xffff0000u : 0u);
+            const unsigned m1 = (first <= 2 ? 0xffffu : 0u) | (first <= 3 ? 0xffff0000u : 0u);
+            p0 = (p0 & m0) | (kf2 & ~m0);
+            p1 = (p1 & m1) | (kf2 & ~m1);
+          }
+          KP[8 * g + 2 * c] = p0; KP[8 * g + 2 * c + 1] = p1;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          const bool have = (vmask >> (16 * g + s)) & 1u;
-          const float x = have ? xf[s] : xfirst;
-          int kk;
-          const bool ok = grid_key<true>(x, kk);
-          bad = bad || !ok;
-          k[NS * g + s] = kk;
-          const double d = (double)x - K;
-          f1[g] += d;
-          f2[g] = __fma_rn(d, d, f2[g]);
-          if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          for (int h = 0; h < 2; ++h) {                                     // exact moment sums of k - first key (|d| <= 2 047 where the position fits)
+            const CntS2 d = __builtin_bit_cast(CntS2, h ? p1 : p0) - __builtin_bit_cast(CntS2, kf2);
+            i1[g] = __builtin_amdgcn_sdot2(d, ones, i1[g], false);
+            i2[g] = __builtin_amdgcn_sdot2(d, d, i2[g], false);
+          }
         }
-        kfirst[g] = 0;
-        f1[g] = seg_allsum_f64<LG>(f1[g]);
-        f2[g] = seg_allsum_f64<LG>(f2[g]);
-        const double dn = (double)(g ? n1 : n0);
-        const double rn = uniform ? recip[g] : 1.0 / dn;
-        const double mu = K + f1[g] * rn, qq = f2[g] - f1[g] * f1[g] * rn;
-        f1[g] = mu; f2[g] = qq;
-        __builtin_amdgcn_sched_barrier(0);
-      } else {
-        const int kf = __builtin_amdgcn_ds_bpermute((lane & ~(LG - 1)) << 2, ki[0]);
-        kfirst[g] = kf;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          const bool have = (vmask >> (16 * g + s)) & 1u;
-          const int kk = have ? ki[s] : kf;
-          k[NS * g + s] = kk;
-          const int d = kk - kf;                         // (|d| <= 65 535 for any int16 row; <= 2 047 for one that fits the window)
-          i1[g] += d;
-          i2[g] = (int)((unsigned)i2[g] + (unsigned)__mul24(d, d));
+        for (int h = 0; h < 2; ++h) {
+          const CntS2 kp = __builtin_bit_cast(CntS2, KP[8 * g + 2 * c + h]);
+          MN = __builtin_elementwise_min(MN, kp); MX = __builtin_elementwise_max(MX, kp);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -245,14 +278,16 @@ void rank_count_kernel(RankStatsArgs args) {
     // ---- the moments are final here: written at once (a position that turns out not to fit is written again by rank_hist_kernel)
     {
       double mean[2], m2[2];
-      if constexpr (DTYPE == 0) {
-        mean[0] = f1[0]; m2[0] = f2[0]; mean[1] = f1[1]; m2[1] = f2[1];
-      } else {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+      for (int g = 0; g < 2; ++g) {
+        const double dn = (double)(g ? n1 : n0);
+        const double rn = uniform ? recip[g] : 1.0 / dn;
+        if constexpr (DTYPE == 0) {
+          const double s1 = seg_allsum_f64<LG>(f1[g]), s2 = seg_allsum_f64<LG>(f2[g]);
+          const double K = (double)xfirst2[g];
+          mean[g] = K + s1 * rn; m2[g] = s2 - s1 * s1 * rn;
+        } else {
           const double S1 = (double)cnt_allsum_i32(i1[g]), S2 = (double)cnt_allsum_i32(i2[g]);   // exact: |S1| < 2^20, S2 < 2^31 (fitting positions)
-          const double dn = (double)(g ? n1 : n0);
-          const double rn = uniform ? recip[g] : 1.0 / dn;
           mean[g] = ((double)kfirst[g] + S1 * rn) * 1e-3;
           m2[g] = __fma_rn(dn, S2, -S1 * S1) * rn * 1e-6;                                       // (n S2 - S1^2: exact integers)
         }
@@ -263,63 +298,114 @@ void rank_count_kernel(RankStatsArgs args) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- the window: the position's smallest key is value 0
-    int kmin = k[0], kmax = k[0];
-#pragma unroll
-    for (int s = 1; s < 2 * NS; ++s) { kmin = min(kmin, k[s]); kmax = max(kmax, k[s]); }
-    kmin = cnt_allmin_i32(kmin); kmax = cnt_allmax_i32(kmax);
+    // ---- the window: the position's smallest key is value 0; the lane blocks are as long as the widest position of the wave needs
+    const int kmin = cnt_allmin_i32(min((int)MN.x, (int)MN.y)), kmax = cnt_allmax_i32(max((int)MX.x, (int)MX.y));
     {
       const unsigned long long bm = __ballot(bad);
       const bool pos_bad = ((unsigned)(bm >> (lane & 48)) & 0xffffu) != 0u;
       fit = fit && !pos_bad && (unsigned)(kmax - kmin) < (unsigned)kCntWindow;
     }
-    // (int16 moments: sums of squares of a position that does not fit may have wrapped; they are not used then)
+    // 16-byte chunks per lane block: 2, 4, 6 or 8 (block = 32 .. 128 values; an even count keeps the padded block stride an odd
+    // number of 16-byte units: the lanes' 16-byte accesses of the scan stay on different banks)
+    int nc;
+    {
+      const int need = fit ? 2 * (((kmax - kmin) >> 9) + 1) : 2;
+      nc = max(max(__builtin_amdgcn_readlane(need, 0), __builtin_amdgcn_readlane(need, 16)),
+               max(__builtin_amdgcn_readlane(need, 32), __builtin_amdgcn_readlane(need, 48)));
+    }
+    const unsigned bdiv = (nc == 2) ? 131072u : (nc == 4) ? 65536u : (nc == 6) ? 43691u : 32768u;   // ceil(2^22 / (16 nc)): u * bdiv >> 22 = u / (16 nc), u < 2048
+    const int bstride = 16 * nc + 16;                    // bytes from a lane's block to the next (its 16-byte pad first)
 
-    unsigned best = 0u, slu = 0u, tsq = 0u;
+    // Only group 1's samples are looked up (in both tables); group 2's are only counted.  Every pooled point that can carry the
+    // KS maximum is a point (A[v], B[v]) or (A[v-1], B[v-1]) at a value v of group 1 (between two values of group 1 F_A is
+    // constant and F_B rises: the extremes sit at the ends); mwu_s = sum over a in group 1 of (B[a-1] + B[a]); and with a(v), b(v)
+    // the two groups' counts of value v, sum_v (a + b)^3 = sum_{e in group 1} (a^2 + 3 a b + 3 b^2)(e) + sum_v b^3, the last term
+    // from the arrival numbers the counting adds of group 2 return: sum_{e in group 2} (3 p^2 + 3 p + 1), p = earlier copies.
+    unsigned mws = 0u, saa = 0u, sab = 0u, sbb = 0u, b3 = 0u;
+    CntU2 BEST = {0, 0};
     double dmax = 0.0;
-    unsigned reg[2 * NS];
+    constexpr int NP = NS / 2;                           // pairs of group 1's slots
+    unsigned CAp[NP], CA1p[NP];                          // per pair: A[u], A[u-1]
+    unsigned N0p[NP], N1p[NP];                           // per pair: |A[u] n1 - B[u] n0|, |A[u-1] n1 - B[u-1] n0|
+    Item nxt;
+    Rows nx0, nx1;
+    auto request_next = [&](int part) {                 // part 0: describe + group 1's rows; 1: group 2's rows; 2: both
+      if (part != 1) { nxt = describe(it + wave_stride); nx0.request(args.sig0, nxt.o0, rows_n(nxt, nxt.n0), gl); }
+      if (part != 0) nx1.request(args.sig1, nxt.o1, rows_n(nxt, nxt.n1), gl);
+    };
     if (fit) {
-      // byte address of cum[u - 1]: tb + 15 + u + 16 (u >> 7)  (block u >> 7 starts 16 pad bytes later than a flat table would);
-      // a slot without a sample: the first two bytes of the first pad, always zero
+      // byte address of cum[u - 1]: tb + 15 + u + 16 (u / block)  (block b starts 16 (b + 1) bytes later than in a flat table),
+      // two per register; a slot without a sample: the first two bytes of the first pad, always zero
+      const unsigned kmin2 = ((unsigned)kmin & 0xffffu) | ((unsigned)kmin << 16);
 #pragma unroll
-      for (int s = 0; s < 2 * NS; ++s) {
-        const unsigned u = (unsigned)(k[s] - kmin);
-        const unsigned a = tb + 15u + u + ((u >> 7) << 4);
-        reg[s] = ((vmask >> s) & 1u) ? a : tb;
+      for (int ch = 0; ch < 8; ++ch) {
+        if (!((anym >> ch) & 1u)) continue;
+        auto addr = [&](auto full_tag) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const CntU2 u2 = __builtin_bit_cast(CntU2, __builtin_bit_cast(CntS2, KP[2 * ch + h]) - __builtin_bit_cast(CntS2, kmin2));
+            unsigned a[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const unsigned u = e ? (unsigned)u2.y : (unsigned)u2.x;
+              a[e] = tb + 15u + u + ((__umul24(u, bdiv) >> 22) << 4);
+              if constexpr (!decltype(full_tag)::value) a[e] = ((vmask >> (4 * ch + 2 * h + e)) & 1u) ? a[e] : tb;
+            }
+            KP[2 * ch + h] = a[0] | (a[1] << 16);
+          }
+        };
+        if ((fullm >> ch) & 1u) addr(std::true_type{}); else addr(std::false_type{});
       }
-      // (the packed registers are made opaque after every phase: otherwise the compiler keeps the unpacked addresses — 32
-      // more registers — alive beside them for the later phases)
+      // (made opaque after every phase: otherwise the compiler keeps unpacked copies alive beside the packed registers)
 #pragma unroll
-      for (int s = 0; s < 2 * NS; ++s) asm volatile("" : "+v"(reg[s]));
+      for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(KP[s]));
       __builtin_amdgcn_sched_barrier(0);
+      uint4* blk = reinterpret_cast<uint4*>(__builtin_assume_aligned(reinterpret_cast<char*>(tbl) + gl * bstride + 16, 16));   // the lane's block (behind its pad)
       auto clear_table = [&]() {
+        unsigned z = 0u;
+        asm volatile("" : "+v"(z));                       // (a fresh zero per call: hoisted out of the item loop, the zero quad is spilled and reloaded per store)
 #pragma unroll
-        for (int i = 0; i < 9; ++i) reinterpret_cast<uint4*>(tbl)[gl + 16 * i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = 0; i < 9; ++i) if (i <= nc) blk[i - 1] = make_uint4(z, z, z, z);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
       };
       auto build = [&](int g) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          const unsigned a1 = (reg[NS * g + s] & 0xffffu) + 1u;               // byte of the sample's counter (empty slot: tb + 1, adds 0)
-          const unsigned val = ((vmask >> (NS * g + s)) & 1u) ? (1u << ((a1 & 3u) * 8u)) : 0u;
-          __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)(a1 & ~3u), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        for (int c = 0; c < 4; ++c) {
+          const int ch = 4 * g + c;
+          if (!((anym >> ch) & 1u)) continue;
+          auto add4 = [&](auto full_tag) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned ap = KP[2 * ch + (j >> 1)];
+              const unsigned a1 = ((j & 1) ? (ap >> 16) : (ap & 0xffffu)) + 1u;   // byte of the sample's counter (empty slot: tb + 1, adds 0)
+              const unsigned one = 1u << ((a1 & 3u) * 8u);
+              const unsigned val = (decltype(full_tag)::value || ((vmask >> (4 * ch + j)) & 1u)) ? one : 0u;
+              const unsigned old = __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)(a1 & ~3u), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              if (g == 1) {                                                        // earlier copies of the value: p (an empty slot reads the zero pad)
+                const unsigned pcnt = (old >> ((a1 & 3u) * 8u)) & 0xffu;
+                b3 += __umul24(pcnt, pcnt) + pcnt;
+              }
+            }
+          };
+          if ((fullm >> ch) & 1u) add4(std::true_type{}); else add4(std::false_type{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
       };
-      // counts -> inclusive prefix sums, in place.  Lane gl owns block gl (words 36 gl + 4 .. + 35).
+      // counts -> inclusive prefix sums, in place.  Lane gl owns block gl: nc chunks of 16 counters behind its pad.
       auto scan = [&]() {
-        uint4* blk = reinterpret_cast<uint4*>(__builtin_assume_aligned(tbl + kCntBlockWords * gl + 4, 16));
-        // the lane's total first (its words are read again below: 32 registers for them would not fit beside the samples)
+        // the lane's total first (its words are read again below: registers for all of them would not fit beside the samples)
         unsigned tot = 0u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const uint4 q = blk[i];
-          tot = __builtin_amdgcn_sad_u8(q.x, 0u, tot); tot = __builtin_amdgcn_sad_u8(q.y, 0u, tot);
-          tot = __builtin_amdgcn_sad_u8(q.z, 0u, tot); tot = __builtin_amdgcn_sad_u8(q.w, 0u, tot);
+          if (i < nc) {
+            const uint4 q = blk[i];
+            tot = __builtin_amdgcn_sad_u8(q.x, 0u, tot); tot = __builtin_amdgcn_sad_u8(q.y, 0u, tot);
+            tot = __builtin_amdgcn_sad_u8(q.z, 0u, tot); tot = __builtin_amdgcn_sad_u8(q.w, 0u, tot);
+          }
         }
         const unsigned base = seg_exscan_add_u32<LG>(tot, gl);                  // samples below the lane's first value (< 256)
         unsigned carry = base | (base << 8);
@@ -327,49 +413,44 @@ void rank_count_kernel(RankStatsArgs args) {
         blk[-1] = make_uint4(0u, 0u, 0u, base << 24);                            // byte 15 of the pad: cum just below the block
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          unsigned w[16];
+        for (int h = 0; h < 4; ++h) {
+          if (2 * h < nc) {
+            unsigned w[8];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { const uint4 q = blk[4 * h + i]; w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w; }
+            for (int i = 0; i < 2; ++i) { const uint4 q = blk[2 * h + i]; w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w; }
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            // (inline asm: written as v + (v << 8) the compiler multiplies by 0x01010101 with a 64-bit v_mad_u64_u32 per word)
-            unsigned v = w[i], t;
-            asm("v_lshl_add_u32 %0, %1, 8, %1" : "=v"(t) : "v"(v));
-            asm("v_lshl_add_u32 %0, %1, 16, %1" : "=v"(v) : "v"(t));
-            v += carry;
-            carry = __builtin_amdgcn_perm(v, v, 0x03030303u);                    // the word's last byte in all four
-            w[i] = v;
+            for (int i = 0; i < 8; ++i) {
+              // (inline asm: written as v + (v << 8) the compiler multiplies by 0x01010101 with a 64-bit v_mad_u64_u32 per word)
+              unsigned v = w[i], t;
+              asm("v_lshl_add_u32 %0, %1, 8, %1" : "=v"(t) : "v"(v));
+              asm("v_lshl_add_u32 %0, %1, 16, %1" : "=v"(v) : "v"(t));
+              v += carry;
+              carry = __builtin_amdgcn_perm(v, v, 0x03030303u);                  // the word's last byte in all four
+              w[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) blk[2 * h + i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+            __builtin_amdgcn_sched_barrier(0);
           }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) blk[4 * h + i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-          __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
       };
-
+      // cum[u - 1] and cum[u] of the two slots of every pair of a chunk: four byte reads, joined to two registers of 16-bit halves
+      // (an unaligned 16-bit read costs the LDS pipe a pass per lane; D16 loads into register halves do not keep the other
+      // half on this part: SRAM-ECC)
       // ---- table A: group 1
       clear_table();
       build(0);
       scan();
 #pragma unroll
-      for (int s0 = 0; s0 < 2 * NS; s0 += 8) {
-        unsigned v[8], v1[8];
+      for (int ch = 0; ch < 4; ++ch) {
+        if (!((anym >> ch) & 1u)) continue;
+        unsigned c1[2], c0[2];
+        cnt_lookup_chunk(KP[2 * ch], KP[2 * ch + 1], c1, c0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {                                             // A[u-1], A[u]: two byte reads (an unaligned 16-bit read costs the LDS pipe a pass per lane)
-          const CntLdsU8 p = (CntLdsU8)(uintptr_t)(reg[s0 + e] & 0xffffu);
-          v1[e] = p[0]; v[e] = p[1];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int s = s0 + e;
-          const unsigned cA = v[e], cA1 = v1[e];
-          if (s >= NS) slu += cA + cA1;                                           // group 2: #{a < x} + #{a <= x}
-          reg[s] = (reg[s] & 0xffffu) | (cA << 16) | ((cA - cA1) << 24);
-          asm volatile("" : "+v"(reg[s]));
-        }
+        for (int h = 0; h < 2; ++h) { CAp[2 * ch + h] = c0[h]; CA1p[2 * ch + h] = c1[h]; }
         __builtin_amdgcn_sched_barrier(0);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -380,26 +461,33 @@ void rank_count_kernel(RankStatsArgs args) {
       clear_table();
       build(1);
       scan();
+    }
+    // the next item's rows, used at the top of the next iteration: int16 rows (16 registers) are requested here, before the last
+    // lookups; float32 rows (32 registers) behind them, the second group's behind the float-form pass
+    if constexpr (DTYPE != 0) request_next(2);
+    if (fit) {
+      const CntU2 n0x2 = {(unsigned short)n0, (unsigned short)n0}, n1x2 = {(unsigned short)n1, (unsigned short)n1};
+      const CntU2 one2 = {1, 1};
 #pragma unroll
-      for (int s0 = 0; s0 < 2 * NS; s0 += 8) {
-        unsigned v[8], v1[8];
+      for (int ch = 0; ch < 4; ++ch) {
+        if (!((anym >> ch) & 1u)) continue;
+        unsigned c1[2], c0[2];
+        cnt_lookup_chunk(KP[2 * ch], KP[2 * ch + 1], c1, c0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {                                             // B[u-1], B[u]
-          const CntLdsU8 p = (CntLdsU8)(uintptr_t)(reg[s0 + e] & 0xffffu);
-          v1[e] = p[0]; v[e] = p[1];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int s = s0 + e;
-          const unsigned cB = v[e], cB1 = v1[e];
-          const unsigned cA = (reg[s] >> 16) & 0xffu, ta = reg[s] >> 24;
-          const unsigned t = ta + (cB - cB1);                                      // size of the sample's pooled tie group (0: empty slot)
-          tsq += __umul24(t, t);
-          unsigned num;                                                             // |A n1 - B n0| <= 65 025
-          asm("v_sad_u32 %0, %1, %2, 0" : "=v"(num) : "v"(__umul24(cA, (unsigned)n1)), "v"(__umul24(cB, (unsigned)n0)));
-          best = max(best, num);
-          reg[s] = (num << 16) | (cA << 8) | cB;
-          asm volatile("" : "+v"(reg[s]));
+        for (int h = 0; h < 2; ++h) {
+          const int p = 2 * ch + h;
+          const CntU2 cB = __builtin_bit_cast(CntU2, c0[h]), cB1 = __builtin_bit_cast(CntU2, c1[h]);
+          const CntU2 cA = __builtin_bit_cast(CntU2, CAp[p]), cA1 = __builtin_bit_cast(CntU2, CA1p[p]);
+          const CntU2 ta = cA - cA1, tb = cB - cB1;                               // copies of the sample's value in either group (0, 0: empty slot)
+          saa = __builtin_amdgcn_udot2(ta, ta, saa, false);
+          sab = __builtin_amdgcn_udot2(ta, tb, sab, false);
+          sbb = __builtin_amdgcn_udot2(tb, tb, sbb, false);
+          mws = __builtin_amdgcn_udot2(cB + cB1, one2, mws, false);               // #{b < a} + #{b <= a}
+          const CntU2 x0 = cA * n1x2, y0 = cB * n0x2, x1 = cA1 * n1x2, y1 = cB1 * n0x2;   // <= 255 * 255
+          const CntU2 num0 = __builtin_elementwise_max(x0, y0) - __builtin_elementwise_min(x0, y0);   // |A n1 - B n0| at v
+          const CntU2 num1 = __builtin_elementwise_max(x1, y1) - __builtin_elementwise_min(x1, y1);   // ... just below v
+          BEST = __builtin_elementwise_max(BEST, __builtin_elementwise_max(num0, num1));
+          N0p[p] = __builtin_bit_cast(unsigned, num0); N1p[p] = __builtin_bit_cast(unsigned, num1);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -408,40 +496,46 @@ void rank_count_kernel(RankStatsArgs args) {
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    // the next item's rows: requested here, used at the top of the next iteration
-    const Item nxt = describe(it + wave_stride);
-    Rows nx0, nx1;
-    nx0.request(args.sig0, nxt.o0, rows_n(nxt, nxt.n0), gl);
-    nx1.request(args.sig1, nxt.o1, rows_n(nxt, nxt.n1), gl);
-
+    if constexpr (DTYPE == 0) request_next(0);
     if (__ballot(fit) != 0ull) {
-      best = fit ? seg_allmax_u32<LG>(best) : 0u;
+      unsigned best = fit ? seg_allmax_u32<LG>(max((unsigned)BEST.x, (unsigned)BEST.y)) : 0u;
       // ---- the float form of D at the samples that reach the integer maximum
       const double dn0 = (double)n0, dn1 = (double)n1;
       double r0, r1;
       if (uniform) { r0 = recip[0]; r1 = recip[1]; } else { r0 = 1.0 / dn0; r1 = 1.0 / dn1; }
 #if !(NMOD_CNT_SKIP & 1)
 #pragma unroll
-      for (int s = 0; s < 2 * NS; ++s) {
-        const bool hit = fit && (reg[s] >> 16) == best && best != 0u;
+      for (int s = 0; s < 2 * NS; ++s) {                                          // candidate s: slot s >> 1 of group 1, at its value (even) / just below it (odd)
+        const int sl = s >> 1, p = sl >> 1;
+        if (!((anym >> (sl >> 2)) & 1u)) continue;
+        const unsigned nn = (s & 1) ? N1p[p] : N0p[p];
+        const unsigned num = (sl & 1) ? (nn >> 16) : (nn & 0xffffu);
+        const bool hit = fit && num == best && best != 0u;
         if (__ballot(hit) != 0ull) {
-          const double d = fabs(hist_exact_quot((int)((reg[s] >> 8) & 0xffu), dn0, r0) - hist_exact_quot((int)(reg[s] & 0xffu), dn1, r1));
+          // (B's count is read again — table B stands until the next item clears it; keeping all of them would cost 16 registers)
+          const unsigned ca = (s & 1) ? CA1p[p] : CAp[p];
+          const int cA = (int)((sl & 1) ? (ca >> 16) : (ca & 0xffffu));
+          const unsigned ab = (sl & 1) ? (KP[p] >> 16) : (KP[p] & 0xffffu);
+          const int cB = (int)((CntLdsU8)(uintptr_t)ab)[(s & 1) ? 0 : 1];
+          const double d = fabs(hist_exact_quot(cA, dn0, r0) - hist_exact_quot(cB, dn1, r1));
           dmax = hit ? fmax(dmax, d) : dmax;
         }
         if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
 #endif
       dmax = seg_allmax_f64<LG>(dmax);
-      const unsigned SLU = pos_allsum_u32<LG>(slu);
-      const unsigned TSQ = pos_allsum_u32<LG>(tsq);
+      const unsigned MWS = pos_allsum_u32<LG>(mws);
+      // sum_v (a + b)^3 (< 2^28): group 1's samples give a^3 + 3 a^2 b + 3 a b^2, group 2's arrival numbers b^3
+      const unsigned CUBES = pos_allsum_u32<LG>(saa + 3u * (sab + sbb) + 3u * b3) + (unsigned)n1;
       if (fit && gl == 0) {
         args.ks_num[pos] = best;
         args.ks_d_ref[pos] = dmax;
-        args.mwu_s[pos] = 2ull * (unsigned long long)n0 * (unsigned long long)n1 - (unsigned long long)SLU;
-        args.tie[pos] = (unsigned long long)TSQ - (unsigned long long)(n0 + n1);
-        if (args.tied) args.tied[pos] = (TSQ != (unsigned)(n0 + n1)) ? 1 : 0;
+        args.mwu_s[pos] = (unsigned long long)MWS;
+        args.tie[pos] = (unsigned long long)(CUBES - (unsigned)(n0 + n1));
+        if (args.tied) args.tied[pos] = (CUBES != (unsigned)(n0 + n1)) ? 1 : 0;
       }
     }
+    if constexpr (DTYPE == 0) request_next(1);
     {
       // the item's four flag bytes as one dword (1: nothing left to do for the position — produced here, or no position at all)
       const unsigned long long fm = __ballot(fit || !valid);

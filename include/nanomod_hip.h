@@ -19,10 +19,14 @@
  *     sig1[off1[i] .. off1[i+1])   samples of group 2 (--wrkBase2)
  * plus run_id[i]: equal ids <=> same chrom, same strand and consecutive
  * positions (restates pos_check, myDetect.py:366-371).
- * Samples must be finite: NanoMod's normalised event means always are.  The
- * kernels order keys with bare v_min / v_max and pad with +inf; a NaN (or an
- * infinite) sample is not diagnosed and gives unspecified statistics for its
- * position (never a fault, never another position's).
+ * Samples are expected to be finite: NanoMod's normalised event means always
+ * are.  The kernels order keys with bare v_min / v_max and pad with +inf, so a
+ * position with a NaN or an infinite sample gets unspecified statistics (never
+ * a fault, never another position's) — and NMOD_STATUS_NONFINITE: whenever the
+ * Welch moments are computed (tests & NMOD_TEST_WELCH, or want_mstd: every call
+ * the reference-shaped entry points make) a non-finite moment sets the bit at
+ * no cost; NMOD_FLAG_CHECK_FINITE adds one pass over the samples that sets it
+ * exactly in every mode (KS-only included).
  */
 #ifndef NANOMOD_HIP_H
 #define NANOMOD_HIP_H
@@ -70,7 +74,9 @@ enum {
   NMOD_STATUS_MWU_ALL_IDENTICAL = 1, /* scipy 1.2.1 mannwhitneyu raises ValueError (T == 0), uncaught at myDetect.py:331 */
   NMOD_STATUS_T_NAN = 2,             /* zero variance in both groups: ttest_ind returns (nan, nan), myDetect.py:335 */
   NMOD_STATUS_EMPTY = 4,             /* n0 == 0 or n1 == 0 (cannot occur after mfilter_coverage, myDetect.py:301-314) */
-  NMOD_STATUS_TOO_LARGE = 8          /* more samples than the max_n0 / max_n1 the caller promised: position skipped, outputs NaN */
+  NMOD_STATUS_TOO_LARGE = 8,         /* more samples in a group than the max_n0 / max_n1 the caller promised, or than NMOD_MAX_RANKED:
+                                        the position is skipped, its outputs are NaN, the rest of the batch is computed */
+  NMOD_STATUS_NONFINITE = 16         /* a NaN or infinite sample (see the header comment): the position's statistics are unspecified */
 };
 
 /* return codes */
@@ -78,7 +84,8 @@ enum {
   NMOD_OK = 0,
   NMOD_ERR_INVALID_ARG = -1,
   NMOD_ERR_HIP = -2,          /* a HIP runtime call failed; see nmod_strerror */
-  NMOD_ERR_TOO_LARGE = -3,    /* a position has more samples in a group than NMOD_MAX_RANKED */
+  NMOD_ERR_TOO_LARGE = -3,    /* nmod_describe_dispatch / nmod_downsample_ks: a group beyond NMOD_MAX_RANKED (nmod_detect_batch reports
+                                 such positions per position: NMOD_STATUS_TOO_LARGE) */
   NMOD_ERR_WORKSPACE = -4,    /* workspace missing or too small (device-memory mode) */
   NMOD_ERR_NO_DEVICE = -5
 };
@@ -86,7 +93,8 @@ enum {
 #define NMOD_MAX_GROUP 2048   /* largest group the wave-resident kernels sort (both groups in all-tests mode, the
                                  smaller one in KS-only mode); positions beyond it take the workgroup-per-position
                                  pass (big_rank.hpp), slower but unlimited up to NMOD_MAX_RANKED */
-#define NMOD_MAX_RANKED 65535 /* max samples per group per position in any mode (16-bit ranks, 32-bit KS numerator) */
+#define NMOD_MAX_RANKED 65535 /* max samples per group per position in any mode (16-bit ranks, 32-bit KS numerator); a position
+                                 beyond it gets NMOD_STATUS_TOO_LARGE */
 #define NMOD_MAX_NB 64        /* max --neighborPvalues */
 
 typedef struct nmod_params {
@@ -115,6 +123,10 @@ typedef struct nmod_params {
  * (they differ by <= 2 ulp, <= 4.5e-16 absolute; p-values agree to ~1e-15 relative).  Skips the pass that evaluates the float
  * form at the pooled points reaching the integer maximum (~10 % of the KS-only kernel).  Ignored with any other test in the mask. */
 #define NMOD_FLAG_KS_RATIONAL_D 1
+/* One extra pass over the samples (float32 / float64 input; ~0.2 ms per GB) that sets NMOD_STATUS_NONFINITE for every position
+ * holding a NaN or an infinite sample, in every mode.  Without it the bit comes from the Welch moments alone (free, whenever they
+ * are computed): that catches every NaN and -inf, and +inf except in the group a kernel form sorts with +inf pads. */
+#define NMOD_FLAG_CHECK_FINITE 2
 
 /* Caller-allocated SoA outputs, npos elements each; a NULL member is skipped.
  * One (stat, p) pair per test = the tuples getKStest returns

@@ -17,8 +17,8 @@ DTYPE_F32, DTYPE_I16_MILLI, DTYPE_F64 = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 METHOD_KS, METHOD_STOUFFER, METHOD_FISHER = 0, 1, 2
 TEST_KS, TEST_MWU, TEST_WELCH, TEST_ALL = 1, 2, 4, 7
-FLAG_KS_RATIONAL_D = 1
-STATUS_MWU_ALL_IDENTICAL, STATUS_T_NAN, STATUS_EMPTY, STATUS_TOO_LARGE = 1, 2, 4, 8
+FLAG_KS_RATIONAL_D, FLAG_CHECK_FINITE = 1, 2
+STATUS_MWU_ALL_IDENTICAL, STATUS_T_NAN, STATUS_EMPTY, STATUS_TOO_LARGE, STATUS_NONFINITE = 1, 2, 4, 8, 16
 KERNEL_RANK_STATS, KERNEL_FINALIZE, KERNEL_COMBINE, KERNEL_SYNTH = 0, 1, 2, 3
 MAX_GROUP = 2048          # largest group of the wave-resident kernels; larger ones (<= MAX_RANKED) take big_rank_kernel
 MAX_RANKED = 65535

@@ -202,7 +202,8 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
   int64_t m0 = csr0 ? 0 : prm->stride0, m1 = csr1 ? 0 : prm->stride1;
   if (csr0) for (int64_t i = 0; i < npos; ++i) { const int64_t n = off0[i + 1] - off0[i]; if (n < 0) return NMOD_ERR_INVALID_ARG; m0 = std::max(m0, n); }
   if (csr1) for (int64_t i = 0; i < npos; ++i) { const int64_t n = off1[i + 1] - off1[i]; if (n < 0) return NMOD_ERR_INVALID_ARG; m1 = std::max(m1, n); }
-  if (std::max(m0, m1) > NMOD_MAX_RANKED) return NMOD_ERR_TOO_LARGE;
+  // (a group beyond NMOD_MAX_RANKED: the device skips that position and flags it NMOD_STATUS_TOO_LARGE; its rows still cross the bus)
+  const int64_t lim0 = std::min<int64_t>(m0, NMOD_MAX_RANKED), lim1 = std::min<int64_t>(m1, NMOD_MAX_RANKED);
   auto row0 = [&](int64_t i) { return csr0 ? off0[i] : i * prm->stride0; };     // first sample of position i (element index)
   auto row1 = [&](int64_t i) { return csr1 ? off1[i] : i * prm->stride1; };
   const int64_t total_bytes = (row0(npos) - row0(0) + row1(npos) - row1(0)) * (int64_t)esz;
@@ -269,7 +270,7 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
   const int64_t out_slab = align256(cap_pos * (8 * (int64_t)ntr + 1));
   nmod_params dp = *prm;                         // the chunk calls: device memory, K1 + K2 only
   dp.memspace = NMOD_MEM_DEVICE; dp.method = NMOD_METHOD_KS; dp.tests = tests;
-  dp.max_n0 = (int32_t)std::max<int64_t>(m0, 1); dp.max_n1 = (int32_t)std::max<int64_t>(m1, 1);
+  dp.max_n0 = (int32_t)std::max<int64_t>(lim0, 1); dp.max_n1 = (int32_t)std::max<int64_t>(lim1, 1);
   if (csr0) dp.stride0 = 0;
   if (csr1) dp.stride1 = 0;
   const int64_t wsb = align256(nmod_workspace_bytes(&dp, cap_pos));

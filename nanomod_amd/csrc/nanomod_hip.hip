@@ -63,7 +63,7 @@ struct ScopedKernelTimer {
 struct Workspace {
   uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments;
   double* tmp_ks_d; double* tmp_ks_p; double* ks_d_ref;
-  int32_t* order; int32_t* redo; uint8_t* cls; uint8_t* tied; uint8_t* cnt_done; int32_t* meta;   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
+  int32_t* order; int32_t* redo; uint8_t* cls; uint8_t* tied; uint8_t* cnt_done; uint8_t* nonfinite; int32_t* meta;   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
   int64_t bytes;
 };
 constexpr int kMetaInts = 256;
@@ -98,6 +98,7 @@ static Workspace carve(void* base, int64_t npos) {
   w.cls = (uint8_t*)take(npos);
   w.tied = (uint8_t*)take(npos);
   w.cnt_done = (uint8_t*)take(npos + 16);        // counting form (rank_count.hpp): one flag byte per entry of the work list, dword per item
+  w.nonfinite = (uint8_t*)take(npos);             // NMOD_FLAG_CHECK_FINITE: nonfinite_scan_kernel's flags
   w.meta = (int32_t*)take(kMetaInts * 4);
   w.bytes = o;
   return w;
@@ -329,7 +330,7 @@ static int check_params(const nmod_params* prm) {
   if (prm->method < NMOD_METHOD_KS || prm->method > NMOD_METHOD_FISHER) return NMOD_ERR_INVALID_ARG;
   if (prm->nb < 0 || prm->nb > NMOD_MAX_NB) return NMOD_ERR_INVALID_ARG;
   if ((prm->tests & ~NMOD_TEST_ALL) != 0) return NMOD_ERR_INVALID_ARG;
-  if ((prm->flags & ~NMOD_FLAG_KS_RATIONAL_D) != 0 || prm->reserved != 0) return NMOD_ERR_INVALID_ARG;
+  if ((prm->flags & ~(NMOD_FLAG_KS_RATIONAL_D | NMOD_FLAG_CHECK_FINITE)) != 0 || prm->reserved != 0) return NMOD_ERR_INVALID_ARG;
   return NMOD_OK;
 }
 
@@ -460,7 +461,9 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     if (max0 <= 0) max0 = mx[0];
     if (max1 <= 0) max1 = mx[1];
   }
-  if (std::max(max0, max1) > NMOD_MAX_RANKED) return NMOD_ERR_TOO_LARGE;
+  // a group beyond NMOD_MAX_RANKED: that position is skipped by the classifier and flagged NMOD_STATUS_TOO_LARGE by K2, the rest
+  // of the batch is computed (the reference has no limit: myDetect.py:327-343)
+  max0 = std::min<int64_t>(max0, NMOD_MAX_RANKED); max1 = std::min<int64_t>(max1, NMOD_MAX_RANKED);
   int cmax0 = size_class_of(std::max<int64_t>(max0, 1)), cmax1 = size_class_of(std::max<int64_t>(max1, 1));
   // positions beyond the wave-resident kernels (both groups sorted in all-tests mode, the smaller one in KS-only
   // mode) go to big_rank_kernel; the maxima tell whether any can exist
@@ -628,6 +631,18 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   fa.max_n0 = std::max<int64_t>(max0, 1);
   fa.max_n1 = std::max<int64_t>(max1, 1);
   fa.min_cap = 0;
+  if ((prm->flags & NMOD_FLAG_CHECK_FINITE) && prm->dtype != NMOD_DTYPE_I16_MILLI) {
+    // one pass over the samples: the float64 samples themselves where the keys are their float32 images
+    NonfiniteArgs na;
+    memset(&na, 0, sizeof(na));
+    na.sig0 = f64 ? (const void*)f64->d0 : sig0; na.sig1 = f64 ? (const void*)f64->d1 : sig1; na.f64 = f64 ? 1 : 0;
+    na.off0 = off0; na.off1 = off1; na.stride0 = ra.stride0; na.stride1 = ra.stride1; na.npos = npos;
+    na.lim0 = fa.max_n0; na.lim1 = fa.max_n1; na.flag = ws.nonfinite;
+    const unsigned nb_ = (unsigned)std::min<int64_t>((npos + 3) / 4, (int64_t)num_cus * 32);
+    hipLaunchKernelGGL(nonfinite_scan_kernel, dim3(nb_), dim3(256), 0, stream, na);
+    NMOD_HIP(hipGetLastError());
+    fa.nonfinite = ws.nonfinite;
+  }
   if (want_comb) {                       // the combine needs the KS track even if the caller does not
     if (!fa.out.ks_d) fa.out.ks_d = ws.tmp_ks_d;
     if (!fa.out.ks_p) fa.out.ks_p = ws.tmp_ks_p;

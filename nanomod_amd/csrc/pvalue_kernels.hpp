@@ -21,6 +21,7 @@ struct FinalizeArgs {
   int32_t tests; int32_t want_mstd;
   int64_t max_n0, max_n1;               // per-group limits of this launch
   int64_t min_cap;                      // KS-only: capacity limit of the smaller (sorted) group, else 0
+  const uint8_t* nonfinite;             // [npos] or null: 1 where nonfinite_scan_kernel found a NaN / infinite sample (NMOD_FLAG_CHECK_FINITE)
   nmod_out out;
 };
 
@@ -79,6 +80,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     const double* mo = a.moments + p * 4;
     double mean0 = nan, m20 = nan, mean1 = nan, m21 = nan;
     if (!empty) { mean0 = mo[0]; m20 = mo[1]; mean1 = mo[2]; m21 = mo[3]; }
+    // finite samples have finite moments: a NaN or an infinity here is one in the position's samples (NMOD_STATUS_NONFINITE)
+    if (!empty && !(fabs(mean0) <= 1.7976931348623157e308 && fabs(mean1) <= 1.7976931348623157e308 &&
+                    fabs(m20) <= 1.7976931348623157e308 && fabs(m21) <= 1.7976931348623157e308)) status |= NMOD_STATUS_NONFINITE;
     if (a.tests & NMOD_TEST_WELCH) {
       double t = nan, pv = nan;
       if (!empty) {
@@ -103,7 +107,34 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
       if (a.out.std1) a.out.std1[p] = sqrt(m21 / dn1);
     }
   }
+  if (a.nonfinite && !empty && a.nonfinite[p]) status |= NMOD_STATUS_NONFINITE;
   if (a.out.status) a.out.status[p] = (uint8_t)status;
+}
+
+// NMOD_FLAG_CHECK_FINITE: one wave per position reads both rows and flags a NaN / infinite sample (float32 or float64 rows)
+struct NonfiniteArgs {
+  const void* sig0; const void* sig1; const int64_t* off0; const int64_t* off1; int64_t stride0, stride1; int64_t npos; int32_t f64;
+  int64_t lim0, lim1; uint8_t* flag;
+};
+__global__ __launch_bounds__(256) void nonfinite_scan_kernel(NonfiniteArgs a) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < a.npos; p += (int64_t)gridDim.x * 4) {
+    bool bad = false;
+    for (int g = 0; g < 2; ++g) {
+      const int64_t st = g ? a.stride1 : a.stride0;
+      const int64_t* off = g ? a.off1 : a.off0;
+      const int64_t o = st > 0 ? p * st : off[p];
+      int64_t n = st > 0 ? st : off[p + 1] - o;
+      if (n > (g ? a.lim1 : a.lim0)) n = 0;                       // (a position beyond the limits is skipped everywhere: NMOD_STATUS_TOO_LARGE)
+      const void* sig = g ? a.sig1 : a.sig0;
+      for (int64_t i = lane; i < n; i += 64) {
+        if (a.f64) bad = bad || !(fabs(reinterpret_cast<const double*>(sig)[o + i]) <= 1.7976931348623157e308);
+        else bad = bad || !(fabsf(reinterpret_cast<const float*>(sig)[o + i]) <= 3.4028234663852886e38f);
+      }
+    }
+    const bool any = __ballot(bad) != 0ull;
+    if (lane == 0) a.flag[p] = any ? 1 : 0;
+  }
 }
 
 // ---------------------------------------------------------------------------

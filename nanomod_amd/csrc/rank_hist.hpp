@@ -191,6 +191,9 @@ template <int R, int LG, int DTYPE, bool WIDE = false, bool AFTER = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (WIDE ? 2 : (R <= 16 ? NMOD_HIST_WAVES : 2)))
 void rank_hist_kernel(RankStatsArgs args) {
   static_assert(!AFTER || (!WIDE && 64 / LG == 4), "the counting form works on items of four positions");
+  // around the counting form two instances are launched and the probe's gate picks one: continuous rows run the plain instance
+  // at its own register budget, event-like rows the AFTER instance over what rank_count_kernel left
+  if (args.cnt_mode != 0 && (args.cnt_gate[0] != 0) != (args.cnt_mode == 2)) return;
   static_assert(WIDE ? (LG == 64 && (R == 1 || R == 2 || R == 4)) : (LG == 8 || LG == 16 || LG == 32 || LG == 64), "lanes per sorted group");
   static_assert(WIDE || (R >= 8 && R <= 32 && (R & (R - 1)) == 0), "registers per lane");
   static_assert(R * LG <= 1024, "32-bit tie sums and 15-bit counts need sorted groups of at most 1024 samples");   // (WIDE: Q <= 4096 < 2^15)
@@ -235,7 +238,7 @@ void rank_hist_kernel(RankStatsArgs args) {
   unsigned long long win_todo = 0ull;
   unsigned win_flags = 0u;                       // lane j: the four flag bytes of item win_base + j * wave_stride (1 = done)
   unsigned cur_flags = 0u;                       // ... of the item being described
-  if constexpr (AFTER) after_count = args.cnt_gate[0] != 0;
+  if constexpr (AFTER) after_count = true;       // (cnt_mode = 2: this instance runs only behind rank_count_kernel)
   [[maybe_unused]] auto load_window = [&]() {
     const int64_t mine = win_base + (int64_t)(threadIdx.x & 63) * wave_stride;
     win_flags = 0x01010101u;

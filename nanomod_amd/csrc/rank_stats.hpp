@@ -47,6 +47,8 @@ struct RankStatsArgs {
   // cnt_done: one byte per entry of the work list (four per item, read as a dword), 1 where it produced the position's results
   // (0: left to the rank_hist_kernel<.., AFTER> launch that follows).  Both null: the counting form is not tried.
   int32_t* cnt_gate; uint8_t* cnt_done;
+  int32_t cnt_mode;                            // rank_hist_kernel launches around the counting form: 1 = run only when the gate is clear (the plain
+                                               // instance takes the whole list), 2 = only when it is set (the AFTER instance takes what is left); 0 = always
 };
 
 // compare-exchange of two registers.  (fminf / fmaxf put a canonicalising v_max x, x in front of every value of unknown

@@ -178,6 +178,24 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
   int64_t cap = (int64_t)num_cus * per_cu;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
+#if NMOD_INST_ALL
+  if (counting) {
+    // gate clear: the plain instance over the whole list; gate set: the AFTER instance over what the counting form left
+    RankStatsArgs a2 = args;
+    a2.cnt_mode = 1;
+    KernelFn plain = pick_packed(cls - kNumGeneralClasses, false);
+    static std::atomic<int> plain_ready[64];
+    if (!cacheable || plain_ready[dev].load(std::memory_order_relaxed) == 0) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      if (cacheable) plain_ready[dev].store(1, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(plain, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream, a2);
+    a2.cnt_mode = 2;
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream, a2);
+    return hipGetLastError();
+  }
+#endif
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream, args);
   return hipGetLastError();
 }

@@ -11,7 +11,7 @@ Same names, argument meaning and error behaviour as
 'basedict'][(chrom,strand)][pos], 'MinCoverage', 'neighborPvalues',
 'WeightsDif', 'testMethod', 'rankUse', 'SaveTest', 'outFolder', 'FileID',
 'mstd', 'coverages', 'RegionRankbyST' (+ 'window', 'WindOvlp', 'percentile', 'NA'), 'outLevel'.
-Keys written: 'sign_test', 'sorted_sign_test', optionally 'sign_test_mstd',
+Keys written: 'sign_test', 'sorted_sign_test', optionally 'sign_test_mstd', 'nmod_flagged' (positions flagged TOO_LARGE / NONFINITE; 'nmod_strict' raises),
 plus 'sign_test_arrays' (the same numbers as numpy arrays, an addition).
 """
 from __future__ import annotations
@@ -507,6 +507,14 @@ def mtest2(moptions):
                              method=dev_method, want_mstd=want_mstd, device=dev)
     if npos and np.any(res['status'] & L.STATUS_MWU_ALL_IDENTICAL):
         raise ValueError('All numbers are identical in mannwhitneyu')                             # scipy 1.2.1, uncaught in the reference
+    # positions the device could not take (a group beyond 65 535 samples: NaN outputs) or whose samples are not finite
+    # (unspecified statistics) are flagged per position; the reference has neither a limit nor a check and would carry on.
+    # moptions['nmod_strict'] makes them an error instead; either way they are listed in moptions['nmod_flagged'].
+    flagged = np.flatnonzero(res['status'] & (L.STATUS_TOO_LARGE | L.STATUS_NONFINITE)) if npos else np.zeros(0, np.int64)
+    moptions['nmod_flagged'] = [(str(meta['chrom'][i]), str(meta['strand'][i]), int(meta['pos'][i]), int(res['status'][i])) for i in flagged]
+    if len(flagged) and moptions.get('nmod_strict', 0):
+        raise ValueError('%d position(s) could not be tested (group beyond %d samples, or non-finite samples); first: %r'
+                         % (len(flagged), L.MAX_RANKED, moptions['nmod_flagged'][0]))
     if npos:
         downsample_update(res, sig0, off0, sig1, off1, rid, meta['strand'], moptions.get('coverages', (0, 0)),
                           iters=int(moptions.get('downsampling', 100)), quantile=float(moptions.get('downsampling_quantile', 0.25)),

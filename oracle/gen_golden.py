@@ -229,14 +229,19 @@ def run_reference_region_rank(myDetect, fx, method, window, wind_ovlp, percentil
             'window_after': np.int64(mo['window'])}
 
 
-def run_reference_table(myDetect, fx, nb, wdif, method, file_id, min_cov=5):
+def run_reference_table(myDetect, fx, nb, wdif, method, file_id, min_cov=5, rank_use='pv', mstd=0):
+    meanstd = None
     with tempfile.TemporaryDirectory() as outdir:
-        mo = build_moptions(fx, outdir, file_id, nb, wdif, method, min_cov)
+        mo = build_moptions(fx, outdir, file_id, nb, wdif, method, min_cov, mstd)
+        mo['rankUse'] = rank_use
         with contextlib.redirect_stdout(io.StringIO()):
             myDetect.mfilter_coverage(mo)
             myDetect.mtest2(mo)
         with open(os.path.join(outdir, file_id + '_sign_test.txt')) as f:
             table = f.read()
+        if mstd:
+            with open(os.path.join(outdir, file_id + '_meanstd.cvs')) as f:
+                meanstd = f.read()
     st = mo['sign_test']
     exp = {
         'chrom': np.array([r[0][0] for r in st]), 'strand': np.array([r[0][1] for r in st]),
@@ -254,6 +259,13 @@ def run_reference_table(myDetect, fx, nb, wdif, method, file_id, min_cov=5):
     # sorted order (myDetect.py:460) as indices into sign_test
     index_of = {id(r): i for i, r in enumerate(st)}
     exp['sorted_index'] = np.array([index_of[id(r)] for r in mo['sorted_sign_test']], dtype=np.int64)
+    if mstd:
+        # sign_test_mstd (myDetect.py:437-438): {(chrom, strand, pos): [[mean0, std0], [mean1, std1]]}, in sign_test order
+        ms = [mo['sign_test_mstd'][(r[0][0], r[0][1], r[0][2])] for r in st]
+        assert len(mo['sign_test_mstd']) == len(st)
+        exp['mean0'] = np.array([m[0][0] for m in ms]); exp['std0'] = np.array([m[0][1] for m in ms])
+        exp['mean1'] = np.array([m[1][0] for m in ms]); exp['std1'] = np.array([m[1][1] for m in ms])
+        return exp, table, meanstd
     return exp, table
 
 
@@ -343,6 +355,28 @@ def make_sweep(rng):
     return dict(sig0=sig0, off0=off0, sig1=sig1, off1=off1,
                 chrom=np.array(['chrS'] * npos), strand=np.array(['+'] * npos),
                 pos=pos, base0=bases, base1=bases)
+
+
+def make_track600(rng):
+    """600 positions, 30 v 35 continuous reads, runs of 200, 50, 60, 70, 70 and 150 positions (gaps of 2-4 positions, a strand
+    change, a chromosome change) — for windows up to neighborPvalues = 64 (129 positions wide: wider than most of the runs)"""
+    recs = []
+    for chrom, strand, start, count, gaps in (('chrT', '+', 100, 250, (200,)), ('chrT', '-', 40, 200, (60, 130)), ('chrU', '+', 7, 150, ())):
+        pos = start
+        for k in range(count):
+            pos += int(rng.integers(2, 5)) if k in gaps else 1
+            recs.append((chrom, strand, pos))
+    npos = len(recs)
+    a = rng.normal(0, 1, (npos, 30)).astype(np.float32)
+    b = rng.normal(0, 1, (npos, 35)).astype(np.float32)
+    for s in (70, 71, 72, 300, 520, 521):
+        b[s] += 0.9
+    sig0, off0 = _csr(list(a))
+    sig1, off1 = _csr(list(b))
+    bases = rng.choice(list('ACGT'), npos)
+    return dict(sig0=sig0, off0=off0, sig1=sig1, off1=off1,
+                chrom=np.array([r[0] for r in recs]), strand=np.array([r[1] for r in recs]),
+                pos=np.array([r[2] for r in recs], dtype=np.int64), base0=bases, base1=bases)
 
 
 def save_fixture(name, fx):
@@ -450,6 +484,34 @@ def main():
                     tag = 'sweep_nb%d_w%g_%s' % (nb, wdif, method)
                     exp, table = run_reference_table(myDetect, fx, nb, wdif, method, tag)
                     save_expected(tag, exp, table)
+        # ---- round 5: corners no fixture pinned before (their own generator state: everything above reproduces unchanged)
+        # --mstd (myDetect.py:425,437-438,541-544): the record dict and the `_meanstd.cvs` file (0-based positions), on
+        # continuous rows (no mean sits on a decimal rounding boundary: the file is comparable byte for byte) and on the
+        # 3-decimal ragged rows (means of n grid values do hit '%.3f' boundaries: compared numerically)
+        for inp in ('sweep', 'ragged'):
+            fx = dict(np.load(os.path.join(OUT, inp + '_inputs.npz')))
+            exp, table, meanstd = run_reference_table(myDetect, fx, 2, 2.0, 'stouffer', inp + '_mstd', mstd=1)
+            save_expected(inp + '_mstd', exp, table)
+            with open(os.path.join(OUT, inp + '_mstd_meanstd.cvs'), 'w') as f:
+                f.write(meanstd)
+        # MinCoverage 3 and 20 (myDetect.py:301-314) on the ragged rows: positions enter / leave the tested set, runs re-form
+        fx = dict(np.load(os.path.join(OUT, 'ragged_inputs.npz')))
+        for mc in (3, 20):
+            exp, table = run_reference_table(myDetect, fx, 2, 2.0, 'stouffer', 'ragged_mc%d' % mc, min_cov=mc)
+            save_expected('ragged_mc%d' % mc, exp, table)
+        # rankUse = 'st' (myDetect.py:447-462): the global order by statistics, reversed
+        fx = dict(np.load(os.path.join(OUT, 'g50_inputs.npz')))
+        for method in ('stouffer', 'ks'):
+            exp, table = run_reference_table(myDetect, fx, 2, 2.0, method, 'g50_rankst_' + method, rank_use='st')
+            save_expected('g50_rankst_' + method, exp, table)
+        # neighborPvalues 5, 16 and 64 (the largest the ABI takes) on a 600-position track of several runs
+        fx = make_track600(np.random.default_rng(505))
+        save_fixture('track600', fx)
+        for nb in (5, 16, 64):
+            for method in ('stouffer', 'fisher'):
+                tag = 'track600_nb%d_%s' % (nb, method)
+                exp, table = run_reference_table(myDetect, fx, nb, 2.0, method, tag)
+                save_expected(tag, exp, table)
     print('golden fixtures written to', os.path.abspath(OUT))
 
 

@@ -97,6 +97,236 @@ def test_golden_tables_through_mtest2(nm, inp, name, nb, wdif, method):
     assert np.all(np.abs(a - b) <= 1e-9 * np.abs(b))
 
 
+def test_too_large_group_is_flagged_per_position(nm):
+    """a group beyond NMOD_MAX_RANKED (65 535 samples; the reference has no limit, myDetect.py:327-343): that position gets
+    NMOD_STATUS_TOO_LARGE and NaN outputs, every other position of the batch is computed — host-resident and device-resident
+    entry, CSR and a fixed stride beyond the limit"""
+    import torch
+    import nanomod_oracle as orc
+    L = nm._lib
+    rng = np.random.default_rng(21)
+    sizes0 = rng.integers(20, 300, 40); sizes1 = rng.integers(20, 300, 40)
+    sizes0[7] = 70_000; sizes1[23] = 66_000
+    off0 = np.zeros(41, np.int64); off0[1:] = np.cumsum(sizes0)
+    off1 = np.zeros(41, np.int64); off1[1:] = np.cumsum(sizes1)
+    sig0 = rng.normal(0, 1, off0[-1]).astype(np.float32); sig1 = rng.normal(0.2, 1, off1[-1]).astype(np.float32)
+    rid = np.zeros(40, np.int32)
+    big = np.zeros(40, bool); big[[7, 23]] = True
+    # the oracle on the batch with the two rows cut to a handful of samples: the other positions' numbers (the window combine
+    # of their neighbours sees NaN from the flagged positions, so compare the per-position tests)
+    s0 = sizes0.copy(); s1 = sizes1.copy(); s0[7] = 5; s1[23] = 5
+    o0 = np.zeros(41, np.int64); o0[1:] = np.cumsum(s0); o1 = np.zeros(41, np.int64); o1[1:] = np.cumsum(s1)
+    c0 = np.concatenate([sig0[off0[i]:off0[i] + s0[i]] for i in range(40)]); c1 = np.concatenate([sig1[off1[i]:off1[i] + s1[i]] for i in range(40)])
+    exp = orc.detect_batch(c0, o0, c1, o1, rid, 2, 2.0, orc.METHOD_FISHER)
+
+    def check(got):
+        st = np.asarray(got['status'])
+        assert np.array_equal((st & L.STATUS_TOO_LARGE) != 0, big)
+        for k in ('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p'):
+            g = np.asarray(got[k])
+            assert np.all(np.isnan(g[big])), k
+            if k.endswith('_p'):
+                H.assert_close_p(g[~big], exp[k][~big], 1e-9, k)
+            else:
+                H.assert_close_stat(g[~big], exp[k][~big], 1e-11, 2e-14, k)
+        assert np.array_equal(np.asarray(got['ks_d'])[~big], exp['ks_d'][~big])
+    check(nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='fisher'))
+    det = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='fisher', tests=L.TEST_ALL)
+    t = lambda a: torch.from_numpy(a).cuda()
+    out = det.run(t(sig0), t(sig1), t(rid), off0=t(off0), off1=t(off1))
+    torch.cuda.synchronize()
+    check({k: v.cpu().numpy() for k, v in out.items()})
+    # KS-only mode
+    got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    assert np.array_equal((got['status'] & L.STATUS_TOO_LARGE) != 0, big) and np.array_equal(got['ks_d'][~big], exp['ks_d'][~big])
+    # a fixed stride beyond the limit: every position is flagged, nothing faults
+    n = 66_000
+    a = rng.normal(0, 1, 3 * n).astype(np.float32)
+    got = nm.detect_host(a, None, a[:3 * 50].copy(), None, np.zeros(3, np.int32), nb=2, weights_dif=2.0, method='fisher', stride0=n, stride1=50)
+    assert np.all((got['status'] & L.STATUS_TOO_LARGE) != 0) and np.all(np.isnan(got['ks_d']))
+
+
+@pytest.mark.parametrize('shape', ['200v200', 'ragged'])
+def test_nonfinite_samples_are_flagged(nm, shape):
+    """NMOD_STATUS_NONFINITE (the reference lets NaN propagate, myDetect.py:327-343; here the statistics of such a position are
+    unspecified and the position is flagged).  All tests computed (what every reference-shaped call does): the Welch moments flag
+    every NaN and -inf for free; with NMOD_FLAG_CHECK_FINITE every non-finite sample is flagged, KS-only mode included; the other
+    positions of the batch are untouched."""
+    import nanomod_oracle as orc
+    L = nm._lib
+    rng = np.random.default_rng(31)
+    P = 120
+    if shape == '200v200':
+        s0 = np.full(P, 200); s1 = np.full(P, 200)
+    else:
+        s0 = rng.integers(5, 700, P); s1 = rng.integers(5, 90, P)
+    off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum(s0)
+    off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum(s1)
+    sig0 = rng.normal(0, 1, off0[-1]).astype(np.float32); sig1 = rng.normal(0, 1, off1[-1]).astype(np.float32)
+    rid = np.zeros(P, np.int32)
+    exp = orc.detect_batch(sig0, off0, sig1, off1, rid, 2, 2.0, orc.METHOD_FISHER)
+    plant = [(3, 0, np.nan), (11, 1, np.nan), (20, 0, -np.inf), (33, 1, -np.inf), (47, 0, np.inf), (58, 1, np.inf), (64, 0, np.nan), (64, 1, np.inf)]
+    b0, b1 = sig0.copy(), sig1.copy()
+    for pos, g, v in plant:
+        (b1 if g else b0)[(off1 if g else off0)[pos] + int(rng.integers(0, (s1 if g else s0)[pos]))] = v
+    planted = np.zeros(P, bool); planted[[p for p, _, _ in plant]] = True
+    sure = np.zeros(P, bool); sure[[p for p, _, v in plant if not (np.isinf(v) and v > 0)]] = True     # NaN and -inf: flagged by the moments
+
+    def others_ok(got, ks_only=False):
+        keep = ~planted
+        assert np.array_equal(got['ks_d'][keep], exp['ks_d'][keep])
+        H.assert_close_p(got['ks_p'][keep], exp['ks_p'][keep], 1e-9, 'ks_p')
+        if not ks_only:
+            assert np.array_equal(got['mwu_u'][keep], exp['mwu_u'][keep])
+            H.assert_close_p(got['t_p'][keep], exp['t_p'][keep], 1e-9, 't_p')
+        assert not np.any(got['status'][keep] & L.STATUS_NONFINITE)
+    got = nm.detect_host(b0, off0, b1, off1, rid, nb=2, weights_dif=2.0, method='fisher')
+    others_ok(got)
+    assert np.all((got['status'][sure] & L.STATUS_NONFINITE) != 0)
+    for tests in (L.TEST_ALL, L.TEST_KS):
+        got = nm.detect_host(b0, off0, b1, off1, rid, nb=2, weights_dif=2.0, method='fisher', tests=tests, flags=L.FLAG_CHECK_FINITE)
+        others_ok(got, tests == L.TEST_KS)
+        assert np.array_equal((got['status'] & L.STATUS_NONFINITE) != 0, planted)
+    # float64 rows: the samples themselves are scanned
+    got = nm.detect_host(b0.astype(np.float64), off0, b1.astype(np.float64), off1, rid, nb=2, weights_dif=2.0, method='fisher', flags=L.FLAG_CHECK_FINITE)
+    assert np.array_equal((got['status'] & L.STATUS_NONFINITE) != 0, planted)
+    # clean input: the flag changes nothing
+    a = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='fisher', flags=L.FLAG_CHECK_FINITE)
+    b = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='fisher')
+    assert all(np.array_equal(a[k], b[k], equal_nan=True) for k in a)
+
+
+# ---- round 5: corners pinned by reference-generated fixtures (oracle/gen_golden.py, its last block)
+CASES_NB = [('track600', 'track600_nb%d_%s' % (nb, m), nb, 2.0, m) for nb in (5, 16, 64) for m in ('stouffer', 'fisher')]
+
+
+@pytest.mark.parametrize('inp,name,nb,wdif,method', CASES_NB)
+def test_golden_tables_wide_windows(nm, inp, name, nb, wdif, method):
+    """neighborPvalues 5, 16 and 64 (the ABI's largest; NanoMod.py:357 takes any int) on a 600-position track whose runs are
+    mostly shorter than the window: same numbers, byte-identical table, through mtest2"""
+    test_golden_tables_through_mtest2(nm, inp, name, nb, wdif, method)
+
+
+def test_window_beyond_the_abi_limit_is_refused(nm):
+    """neighborPvalues = 65 > NMOD_MAX_NB: NMOD_ERR_INVALID_ARG from the library, nothing computed"""
+    fx = H.load_inputs('track600')
+    rid = np.zeros(len(fx['pos']), np.int32)
+    with pytest.raises(nm._lib.NanomodLibraryError, match='invalid argument'):
+        nm.detect_host(fx['sig0'], fx['off0'], fx['sig1'], fx['off1'], rid, nb=65, weights_dif=2.0, method='stouffer')
+    got = nm.detect_host(fx['sig0'], fx['off0'], fx['sig1'], fx['off1'], rid, nb=64, weights_dif=2.0, method='fisher')
+    assert np.all(np.isfinite(got['comb_p']))
+
+
+@pytest.mark.parametrize('mc', [3, 20])
+def test_golden_tables_min_coverage(nm, mc):
+    """MinCoverage 3 and 20 (myDetect.py:301-314): positions enter / leave the tested set per group, runs re-form around the
+    dropped ones — same position set, numbers and table as the reference's mfilter_coverage + mtest2"""
+    fx = H.load_inputs('ragged')
+    name = 'ragged_mc%d' % mc
+    exp, table = H.load_expected(name)
+    with tempfile.TemporaryDirectory() as out:
+        mo = H.build_moptions(fx, out, name, 2, 2.0, 'stouffer', min_cov=mc)
+        nm.mfilter_coverage(mo)
+        nm.mtest2(mo)
+        with open(os.path.join(out, name + '_sign_test.txt')) as f:
+            assert f.read() == table
+    st = mo['sign_test']
+    assert [r[0][2] for r in st] == list(exp['pos']) and [r[0][4] for r in st] == list(exp['n0']) and [r[0][5] for r in st] == list(exp['n1'])
+    assert min(min(exp['n0']), min(exp['n1'])) >= mc
+    assert len(st) != len(H.load_expected('ragged_stouffer')[0]['pos'])
+
+
+@pytest.mark.parametrize('method', ['stouffer', 'ks'])
+def test_rank_use_st_global_order(nm, method):
+    """rankUse = 'st' (myDetect.py:447-462): sorted by (combined or KS statistic, KS statistic, U), then reversed — the
+    reference's order up to records whose keys agree to 1e-9"""
+    fx = H.load_inputs('g50')
+    name = 'g50_rankst_' + method
+    exp, table = H.load_expected(name)
+    with tempfile.TemporaryDirectory() as out:
+        mo = H.build_moptions(fx, out, name, 2, 2.0, method)
+        mo['rankUse'] = 'st'
+        nm.mfilter_coverage(mo)
+        nm.mtest2(mo)
+        with open(os.path.join(out, name + '_sign_test.txt')) as f:
+            assert f.read() == table
+    st = mo['sign_test']
+    index_of = {id(r): i for i, r in enumerate(st)}
+    order = np.array([index_of[id(r)] for r in mo['sorted_sign_test']])
+    assert sorted(order.tolist()) == list(range(len(st)))
+    ref = exp['sorted_index']
+    keys = [np.asarray(exp['comb_st'] if method != 'ks' else exp['ks_d']), np.asarray(exp['ks_d']), np.asarray(exp['mwu_u'])]
+    same = order == ref
+    assert same.mean() > 0.95                                    # (equal up to near-ties of the primary key: Z values that agree to ~1e-12 swap)
+    for k in keys[:1]:
+        a, b = k[order], k[ref]
+        fin = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), fin) and np.all(np.abs(a[fin] - b[fin]) <= 1e-9 * np.abs(b[fin]) + 1e-12)
+    # descending in the primary statistic
+    prim = keys[0][order]
+    fin = np.isfinite(prim)
+    assert np.all(np.diff(prim[fin]) <= 1e-9 * np.abs(prim[fin][1:]) + 1e-12)
+
+
+def _cvs_rows(text):
+    return [ln.split(' ') for ln in text.strip().split('\n')]
+
+
+@pytest.mark.parametrize('inp', ['sweep', 'ragged'])
+def test_mstd_records_and_meanstd_file(nm, inp):
+    """--mstd (myDetect.py:425,437-438,541-544): moptions['sign_test_mstd'] and `_meanstd.cvs` (0-based positions) as the
+    reference's mtest2 + save_test produce them.  Continuous rows: the file byte for byte.  3-decimal rows: the means of n grid
+    values do sit on '%.3f' rounding boundaries, where the last bit of a mean decides the digit — every number within one unit
+    of the last printed place and equal unless the reference's value is within 1e-9 of a boundary."""
+    fx = H.load_inputs(inp)
+    name = inp + '_mstd'
+    exp, table = H.load_expected(name)
+    want = open(os.path.join(H.GOLDEN, name + '_meanstd.cvs')).read()
+    with tempfile.TemporaryDirectory() as out:
+        mo = H.build_moptions(fx, out, name, 2, 2.0, 'stouffer', mstd=1)
+        nm.mfilter_coverage(mo)
+        nm.mtest2(mo)
+        with open(os.path.join(out, name + '_sign_test.txt')) as f:
+            assert f.read() == table
+        got = open(os.path.join(out, name + '_meanstd.cvs')).read()
+    st = mo['sign_test']
+    ms = mo['sign_test_mstd']
+    assert len(ms) == len(st)
+    for k, col in (('mean0', (0, 0)), ('std0', (0, 1)), ('mean1', (1, 0)), ('std1', (1, 1))):
+        g = np.array([ms[(r[0][0], r[0][1], r[0][2])][col[0]][col[1]] for r in st])
+        assert np.all(np.abs(g - exp[k]) <= 1e-12 * np.abs(exp[k]) + 1e-15), k
+    if inp == 'sweep':
+        assert got == want
+    else:
+        gr, wr = _cvs_rows(got), _cvs_rows(want)
+        assert len(gr) == len(wr)
+        ref = np.stack([exp['mean0'], exp['std0'], exp['mean1'], exp['std1']], axis=1)
+        differing = 0
+        for i, (g, w) in enumerate(zip(gr, wr)):
+            assert g[:4] == w[:4]
+            for j in range(4):
+                if g[4 + j] != w[4 + j]:
+                    differing += 1
+                    frac = abs(ref[i, j]) * 1000.0 % 1.0
+                    assert abs(frac - 0.5) < 1e-6 and abs(float(g[4 + j]) - float(w[4 + j])) <= 0.0011, (i, j, g, w)
+        assert differing <= 0.05 * 4 * len(gr)
+
+
+def test_cli_detect_mstd(nm, capsys):
+    """`detect --mstd 1` end to end: the CLI's `_meanstd.cvs` equals the reference's on the continuous fixture, byte for byte"""
+    from nanomod_amd import cli
+    from test_abi_and_host import _fixture_containers
+    want = open(os.path.join(H.GOLDEN, 'sweep_mstd_meanstd.cvs')).read()
+    _, table = H.load_expected('sweep_mstd')
+    with tempfile.TemporaryDirectory() as tmp:
+        p0, p1 = _fixture_containers('sweep', tmp)
+        rc = cli.main(['detect', '--wrkBase1', p0, '--wrkBase2', p1, '--FileID', 'm', '--outFolder', tmp, '--mstd', '1', '--outLevel', '3'])
+        assert rc == 0
+        assert open(os.path.join(tmp, 'm_meanstd.cvs')).read() == want
+        assert open(os.path.join(tmp, 'm_sign_test.txt')).read() == table
+    capsys.readouterr()
+
+
 @pytest.mark.parametrize('inp,name,method', [('ragged', 'ragged_stouffer', 'stouffer'), ('ties', 'ties_stouffer', 'stouffer'),
                                              ('g50', 'g50_fisher', 'fisher')])
 def test_golden_tables_with_device_side_dtype_choice(nm, inp, name, method, monkeypatch):
@@ -294,10 +524,10 @@ def test_edge_statuses(nm):
     assert r['ks_d'][1] == 1.0
     assert r['status'][2] == 0
     assert r['status'][3] & L.STATUS_EMPTY
-    # more samples than the format allows (NMOD_MAX_RANKED)
+    # more samples than the format allows (NMOD_MAX_RANKED): flagged per position (test_too_large_group_is_flagged_per_position)
     big = np.zeros(65536, np.float32)
-    with pytest.raises(L.NanomodLibraryError, match='more samples'):
-        nm.detect_host(big, np.array([0, 65536]), big, np.array([0, 65536]), np.zeros(1, np.int32))
+    r = nm.detect_host(big, np.array([0, 65536]), big, np.array([0, 65536]), np.zeros(1, np.int32))
+    assert (r['status'][0] & L.STATUS_TOO_LARGE) and np.isnan(r['ks_p'][0])
     # empty batch
     r = nm.detect_host(np.zeros(0, np.float32), np.zeros(1, np.int64), np.zeros(0, np.float32), np.zeros(1, np.int64),
                        np.zeros(0, np.int32))
@@ -647,8 +877,8 @@ def test_large_positions_fixed_stride_and_limit(nm):
     H.assert_close_p(ks['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
     big = np.zeros(65536, np.float32)
     for tests in (L.TEST_ALL, L.TEST_KS):
-        with pytest.raises(L.NanomodLibraryError, match='more samples'):
-            nm.detect_host(big, np.array([0, 65536]), big[:10], np.array([0, 10]), np.zeros(1, np.int32), tests=tests, method='ks')
+        r = nm.detect_host(big, np.array([0, 65536]), big[:10], np.array([0, 10]), np.zeros(1, np.int32), tests=tests, method='ks')
+        assert (r['status'][0] & L.STATUS_TOO_LARGE) and np.isnan(r['ks_d'][0])        # flagged, not refused (round 5)
 
 
 def test_downsample_entry_point_is_chunk_invariant_and_exact_without_draws(nm, monkeypatch):

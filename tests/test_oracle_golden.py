@@ -16,6 +16,9 @@ CASES = [('g50', 'g50_stouffer', 2, 2.0, 'stouffer'), ('g50', 'g50_fisher', 2, 2
          ('ragged', 'ragged_fisher', 2, 2.0, 'fisher'), ('ties', 'ties_stouffer', 2, 2.0, 'stouffer'),
          ('sweep', 'sweep_nb0_w2_stouffer', 0, 2.0, 'stouffer'), ('sweep', 'sweep_nb1_w1_stouffer', 1, 1.0, 'stouffer'),
          ('sweep', 'sweep_nb3_w3_stouffer', 3, 3.0, 'stouffer'), ('sweep', 'sweep_nb3_w2_fisher', 3, 2.0, 'fisher')]
+# round 5: wide windows (the ABI's limit is 64) on a track of several runs; MinCoverage 3 / 20 (sixth field)
+CASES += [('track600', 'track600_nb%d_%s' % (nb, m), nb, 2.0, m) for nb in (5, 16, 64) for m in ('stouffer', 'fisher')]
+CASES += [('ragged', 'ragged_mc3', 2, 2.0, 'stouffer', 3), ('ragged', 'ragged_mc20', 2, 2.0, 'stouffer', 20)]
 METHOD = {'ks': orc.METHOD_KS, 'stouffer': orc.METHOD_STOUFFER, 'fisher': orc.METHOD_FISHER}
 
 
@@ -48,13 +51,14 @@ def test_kat_anchors():
     assert kat['constants']['DBL_MIN'] == orc.DBL_MIN and abs(kat['constants']['isf_DBL_MIN'] - 37.5193793471445) < 1e-12
 
 
-@pytest.mark.parametrize('inp,name,nb,wdif,method', CASES)
-def test_oracle_reproduces_reference_tables(inp, name, nb, wdif, method):
+@pytest.mark.parametrize('case', CASES, ids=[c[1] for c in CASES])
+def test_oracle_reproduces_reference_tables(case):
     """position set/order (host logic), every number, and the formatted table"""
     import nanomod_amd.detect as D
+    inp, name, nb, wdif, method = case[:5]
     fx = H.load_inputs(inp)
     exp, table = H.load_expected(name)
-    mo = H.build_moptions(fx, tempfile.gettempdir(), name, nb, wdif, method)
+    mo = H.build_moptions(fx, tempfile.gettempdir(), name, nb, wdif, method, min_cov=case[5] if len(case) > 5 else 5)
     D.mfilter_coverage(mo)
     meta, sig0, off0, sig1, off1, rid = D.build_csr(mo)
     assert list(meta['chrom']) == list(exp['chrom']) and list(meta['pos']) == list(exp['pos'])
@@ -80,3 +84,24 @@ def test_ks_counts_is_the_exact_numerator():
         b = np.round(rng.normal(0.3, 1, rng.integers(3, 90)), 2)
         d, _ = orc.ks_2samp(a, b)
         assert abs(d - orc.ks_counts(a, b) / (len(a) * len(b))) <= 2.3e-16
+
+
+@pytest.mark.parametrize('inp', ['sweep', 'ragged'])
+def test_oracle_mstd_against_the_reference(inp):
+    """--mstd (myDetect.py:437-438): np.mean / np.std (ddof = 0) per group, as the reference's mtest2 recorded them"""
+    import nanomod_amd.detect as D
+    fx = H.load_inputs(inp)
+    exp, _ = H.load_expected(inp + '_mstd')
+    mo = H.build_moptions(fx, tempfile.gettempdir(), inp, 2, 2.0, 'stouffer')
+    D.mfilter_coverage(mo)
+    meta, sig0, off0, sig1, off1, rid = D.build_csr(mo)
+    assert list(meta['pos']) == list(exp['pos'])
+    for g, (sig, off) in enumerate(((sig0, off0), (sig1, off1))):
+        x = np.asarray(sig, dtype=np.float64) * (1e-3 if sig.dtype == np.int16 else 1.0)
+        mean = np.array([np.mean(x[off[i]:off[i + 1]]) for i in range(len(off) - 1)])
+        std = np.array([np.std(x[off[i]:off[i + 1]]) for i in range(len(off) - 1)])
+        assert np.all(np.abs(mean - exp['mean%d' % g]) <= 1e-13 * np.abs(exp['mean%d' % g]) + 1e-16)
+        assert np.all(np.abs(std - exp['std%d' % g]) <= 1e-13 * exp['std%d' % g])
+    # the file has one line per tested position, 0-based positions (the table's are 1-based)
+    rows = open(os.path.join(H.GOLDEN, inp + '_mstd_meanstd.cvs')).read().strip().split('\n')
+    assert len(rows) == len(exp['pos']) and [int(r.split(' ')[2]) for r in rows] == list(exp['pos'])

@@ -303,7 +303,7 @@ def cpu_baseline(rows, what, method, tests, threads, target_seconds=12.0, refpy=
             'reference_shaped_python': ref_shaped}
 
 
-def drop_in_leg(nm, dev_index, positions=460_000, reads=20):
+def drop_in_leg(nm, dev_index, positions=460_000, reads=20, shapes=('arrays', 'lists'), split=False, event_like=False):
     """The function-level drop-in on the reference's own in-memory shape (myDetect.py:569-572: dict[(chrom, strand)][pos] -> list of
     numpy.float64, built at :124) — mfilter_coverage + mtest2 (position set and order, CSR, PCIe, K1-K3, ranking, `_sign_test.txt`)
     at a tenth of E. coli, 20 v 20 reads of 3-decimal values, two strands; per-position numpy arrays as the second shape.
@@ -313,15 +313,21 @@ def drop_in_leg(nm, dev_index, positions=460_000, reads=20):
     import shutil
     import tempfile
     import numpy as np
+    from ctypes import byref as ctypes_byref
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import oracle_c
     rng = np.random.default_rng(SEED)
     half = positions // 2
-    vals = {ds: np.round(rng.normal(shift, 1, (positions, reads)), 3) for ds, shift in (('A', 0.0), ('B', 0.1))}
+    if event_like:                 # a level per position shared by the groups, reads spread 0.2 units around it (cf. nmod_synth_fill_events)
+        lev = rng.uniform(-3, 3, (positions, 1))
+        vals = {ds: np.round(lev + shift + 0.2 * rng.standard_normal((positions, reads), dtype=np.float32), 3) for ds, shift in (('A', 0.0), ('B', 0.02))}
+    else:
+        vals = {ds: np.round(rng.normal(shift, 1, (positions, reads)), 3) for ds, shift in (('A', 0.0), ('B', 0.1))}
     out = {'positions': positions, 'reads_per_group': reads, 'dtype': 'float64 on the 0.001 grid',
+           'rows': 'event-like: level per position in +-3 units, spread 0.2' if event_like else 'N(0, 1) / N(0.1, 1)',
            'note': 'nanomod_amd.mfilter_coverage + nanomod_amd.mtest2 (testMethod stouffer, neighborPvalues 2, SaveTest 1) on the reference\'s '
                    'dict shape; seconds are wall time of the two calls, the input dicts are built outside the clock'}
-    for shape in ('arrays', 'lists'):
+    for shape in shapes:
         tmp = tempfile.mkdtemp()
         mo = {'ds2': ['A', 'B'], 'outLevel': 3, 'mstd': 0, 'coverages': [0, 0], 'downsampling': 100, 'downsampling_quantile': 0.25,
               'neighborPvalues': NB, 'WeightsDif': WDIF, 'testMethod': 'stouffer', 'rankUse': 'pv', 'SaveTest': 1, 'RegionRankbyST': 0,
@@ -350,6 +356,24 @@ def drop_in_leg(nm, dev_index, positions=460_000, reads=20):
         shutil.rmtree(tmp, ignore_errors=True)
         out[shape] = {'mfilter_coverage_s': t1 - t0, 'mtest2_s': t2 - t1, 'positions_per_s': positions / (t2 - t0),
                       'table_lines': lines, 'first_ranked': list(mo['sorted_sign_test'][0][0][:3]), 'verify_ok': bool(ok and lines == positions)}
+        if split:
+            # the stages of mtest2 one by one, through the functions it calls (myDetect.py:416-462: walk + order, tests, ranking, table)
+            from nanomod_amd import detect as D, engine as E
+            tmp2 = tempfile.mkdtemp()
+            st = {}
+            with contextlib.redirect_stdout(io.StringIO()):
+                t = time.perf_counter(); meta, s0, o0, s1, o1, rid_ = D.build_csr(mo); st['build_csr_s'] = time.perf_counter() - t
+                t = time.perf_counter()
+                r_ = E.detect_host(s0, o0, s1, o1, rid_, nb=NB, weights_dif=WDIF, method='stouffer', device=dev_index)
+                st['detect_host_s'] = time.perf_counter() - t
+                hs = nm._lib.NmodHostStats(); nm._lib.load().nmod_last_host_stats(ctypes_byref(hs))
+                t = time.perf_counter(); E.rank_order_host(r_['comb_p'], r_['ks_p'], r_['mwu_p'], device=dev_index); st['rank_order_s'] = time.perf_counter() - t
+                t = time.perf_counter(); E.write_sign_test_host(os.path.join(tmp2, 'x.txt'), meta, r_, True); st['write_table_s'] = time.perf_counter() - t
+            st.update({'csr_dtype': str(s0.dtype), 'h2d_bytes': int(hs.h2d_bytes), 'h2d_GBps_over_detect_host': hs.h2d_bytes / st['detect_host_s'] / 1e9,
+                       'chunks': int(hs.chunks)})
+            out[shape]['stages'] = st
+            shutil.rmtree(tmp2, ignore_errors=True)
+            del r_, s0, s1
         del mo
     return out
 
@@ -480,6 +504,25 @@ def _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests
         a16 = q0.cpu().numpy(); b16 = q1.cpu().numpy()
         del q0, q1
         out['pageable_int16'], _ = record('pageable numpy int16 (milli-units)', a16, b16, 3, ref16)
+        # ... and as float64 on the 0.001 grid, k / 1000.0 — what build_csr sends for the reference's lists of numpy.float64
+        # (myDetect.py:124) when a batch is large: 8 B per sample over the bus, keys picked per position on the device.  A quarter
+        # of the positions (3.7 GB of host memory), checked against the int16 pass
+        nq = npos // 4
+        a64 = a16[:nq * n0].astype(np.float64) / 1000.0; b64 = b16[:nq * n1].astype(np.float64) / 1000.0
+        rid_q = rid[:nq]
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r64 = nm.detect_host(a64, None, b64, None, rid_q, nb=nb, weights_dif=wdif, method=method, tests=tests, stride0=n0, stride1=n1, device=dev_index, flags=flags)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        st = L.NmodHostStats(); lib.nmod_last_host_stats(ctypes.byref(st))
+        same = bool(np.array_equal(r64['ks_d'][:nq - nb], ref16['ks_d'][:nq - nb].cpu().numpy()) and
+                    np.allclose(r64['ks_p'][:nq - nb], ref16['ks_p'][:nq - nb].cpu().numpy(), rtol=1e-12, atol=0))
+        out['float64_grid'] = {'input': 'pageable numpy float64, k / 1000.0 (the first quarter of the positions)', 'positions': nq,
+                               'positions_per_s': nq / best, 'seconds': best, 'h2d_GBps': st.h2d_bytes / best / 1e9,
+                               'frac_of_pinned_h2d': st.h2d_bytes / best / 1e9 / h2d_gbs, 'h2d_bytes': int(st.h2d_bytes), 'chunks': int(st.chunks),
+                               'equals_int16_pass': same}
     return out
 
 
@@ -742,14 +785,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    exposed = {'per_rank_ms': None}
+
     def timed(with_gather, steps):
         barrier()
+        ev_k = torch.cuda.Event(enable_timing=True); ev_g = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         for _ in range(steps):
             step(with_gather)
-        state.wait()
+        ev_k.record()                                # behind the last round's kernels on the compute stream ...
+        state.wait()                                 # ... which now waits for the outstanding all-gathers (none without a collective)
+        ev_g.record()
         barrier()
         el = time.perf_counter() - t0
+        if with_gather and dist is not None:
+            # what of the gather traffic was NOT hidden behind kernels: the compute stream's wait for the last round's collectives,
+            # per rank (the earlier rounds' gathers run beside the next rounds' kernels)
+            mine = torch.tensor([ev_k.elapsed_time(ev_g)], dtype=torch.float64, device=dev)
+            allr = torch.empty(world, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(allr, mine)
+            exposed['per_rank_ms'] = [float(v) for v in allr.cpu()]
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1076,7 +1131,7 @@ def main():
     if world == 1 and not csr and not args.no_host_path and chunks == 1 and not args.force_collective:
         host_path = host_path_leg(nm, torch, local_rank, blocks, n0, n1, NB, WDIF, method, tests,
                                   want_i16=(args.dtype == 'f32'), ref_out=blocks[0]['out'], flags=det.flags)
-        bad = [k for k, v in host_path.items() if isinstance(v, dict) and v.get('equals_device_resident_pass') is False]
+        bad = [k for k, v in host_path.items() if isinstance(v, dict) and (v.get('equals_device_resident_pass') is False or v.get('equals_int16_pass') is False)]
         if bad:
             verify['ok'] = False
             print('bench.py: the host-resident entry differs from the device-resident pass: %r' % bad, file=sys.stderr)
@@ -1085,7 +1140,12 @@ def main():
     drop_in = None
     if headline_default and not args.no_host_path and not args.positions and 'drop_in' in legs:
         drop_in = drop_in_leg(nm, local_rank)
-        if not all(v['verify_ok'] for v in drop_in.values() if isinstance(v, dict)):
+        # ... and at the north-star coverage: 460 000 positions x 200 v 200 reads (1.5 GB of float64 rows as per-position arrays),
+        # with the stages of mtest2 timed one by one
+        drop_in['at_200v200'] = drop_in_leg(nm, local_rank, 460_000, 200, shapes=('arrays',), split=True, event_like=True)
+        flat = [v for v in drop_in.values() if isinstance(v, dict) and 'verify_ok' in v] + \
+               [v for v in drop_in['at_200v200'].values() if isinstance(v, dict) and 'verify_ok' in v]
+        if not all(v['verify_ok'] for v in flat):
             verify['ok'] = False
             print('bench.py: the drop-in mtest2 leg differs from the oracle: %r' % drop_in, file=sys.stderr)
 
@@ -1150,6 +1210,10 @@ def main():
                                        'per round one RCCL all_gather_into_tensor per track (ks_p, comb_p), issued async behind '
                                        'the round\'s kernels' % (world, chunks, B, NB)) if gather else
                                       'one GPU, one block, no collective'},
+            'allgather_exposed_ms': None if exposed['per_rank_ms'] is None else
+                                    {'per_rank': exposed['per_rank_ms'], 'max': max(exposed['per_rank_ms']), 'steps': args.steps,
+                                     'note': 'HIP-event time between the last round\'s kernels and the end of the last outstanding all-gather on each '
+                                             'rank\'s compute stream, after the K timed steps: the part of the gather that no kernel hides'},
             'compute_only': {'value': total * args.steps / compute_elapsed, 'unit': 'positions/s',
                              'ms_per_step': compute_elapsed / args.steps * 1e3,
                              'note': 'the same K steps without the all-gather (tracks stay sharded)' if gather else

@@ -56,6 +56,21 @@ def test_ragged_plan_uses_the_position_keyed_sizes():
     assert tot <= sum(p['sample_bytes'] for p in plans) <= tot + 8 * 2 * 2 * (4000 + 400) * 4
 
 
+def test_ragged_on_8_ranks_plan_is_balanced():
+    """`bench.py --gpus 8 --config ragged --launch-only`: eight fresh ranks, each planning its blocks of the 80 M-position ragged
+    genome from the position-keyed sizes — the block-cyclic deal keeps the ranks' sample bytes (the work: K1 is per sample) within
+    2 % of each other, and every rank fits its GPU"""
+    r = _run(['--gpus', '8', '--config', 'ragged', '--launch-only'], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert sorted(x['rank'] for x in recs) == list(range(8))
+    plans = [x['plan'] for x in sorted(recs, key=lambda x: x['rank'])]
+    assert all(p['positions_total'] == 80_000_000 and p['chunks'] == 4 for p in plans)
+    work = [p['sample_bytes'] for p in plans]
+    assert max(work) / min(work) <= 1.02, work
+    assert all(p['fits_288GB'] for p in plans) and 40e9 < min(work) and max(work) < 50e9
+
+
 def test_under_an_external_launcher_it_is_a_rank():
     r = _run(['--gpus', '2', '--launch-only'], env={'RANK': '1', 'WORLD_SIZE': '2', 'LOCAL_RANK': '1'})
     assert r.returncode == 0, r.stderr[-2000:]

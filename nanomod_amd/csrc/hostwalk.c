@@ -205,7 +205,7 @@ static void* copy_worker(void* arg) {
 
 static int host_threads(void) {
   const char* s = getenv("NMOD_HOSTWALK_THREADS");
-  int t = s ? atoi(s) : 4;
+  int t = s ? atoi(s) : 8;      /* (capped by the cgroup CPU quota below; 4 until round 5: 0.25 s of a 0.39 s mtest2 at 460 000 x 200 v 200 was this copy) */
   long q = -1, per = -1;
   FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
   if (f) { char buf[64]; if (fscanf(f, "%63s %ld", buf, &per) == 2 && strcmp(buf, "max") != 0) q = atol(buf); fclose(f); }
@@ -275,6 +275,17 @@ static PyObject* join_strand(PyObject* self, PyObject* args) {
   for (Py_ssize_t j = 0; j < n; ++j) {
     if (j + 8 < n) { __builtin_prefetch(e0[i0[j + 8]].row); __builtin_prefetch(e1[i1[j + 8]].row); }
     const long long p = e0[i0[j]].pos;
+    /* the rows and bases are BORROWED from the dicts: nothing here may run Python code that could change them.  Exact lists /
+     * tuples / arrays have a C-level length and exact str a C-level ==; anything else (a subclass with its own __len__ or
+     * __eq__) sends the strand to the Python loop (detect._join_strand_py) through TypeError */
+    {
+      PyObject *r0 = e0[i0[j]].row, *r1 = e1[i1[j]].row;
+      if (!((PyList_CheckExact(r0) || PyTuple_CheckExact(r0) || PyArray_CheckExact(r0)) &&
+            (PyList_CheckExact(r1) || PyTuple_CheckExact(r1) || PyArray_CheckExact(r1)))) {
+        PyErr_SetString(PyExc_TypeError, "join_strand: a row of a type the C walk does not take");
+        goto done;
+      }
+    }
     const Py_ssize_t l0 = row_len(e0[i0[j]].row), l1 = row_len(e1[i1[j]].row);
     if (l0 < 0 || l1 < 0) goto done;
     if (l0 > 2147483647 || l1 > 2147483647) { PyErr_SetString(PyExc_OverflowError, "a position holds more than 2^31 samples"); goto done; }
@@ -283,6 +294,10 @@ static PyObject* join_strand(PyObject* self, PyObject* args) {
     while (jb1 < mb1 && eb1[jb1].pos < p) ++jb1;
     if (jb0 >= mb0 || eb0[jb0].pos != p || jb1 >= mb1 || eb1[jb1].pos != p) { PyObject* kp = PyLong_FromLongLong(p); if (kp) { PyErr_SetObject(PyExc_KeyError, kp); Py_DECREF(kp); } goto done; }   /* as base[sk][pk] would */
     PyObject *x0 = eb0[jb0].row, *x1 = eb1[jb1].row;
+    if (!PyUnicode_CheckExact(x0) || !PyUnicode_CheckExact(x1)) {
+      PyErr_SetString(PyExc_TypeError, "join_strand: a base of a type the C walk does not take");
+      goto done;
+    }
     Py_INCREF(x1); PyList_SET_ITEM(bases, j, x1);
     codes[j] = (PyUnicode_CheckExact(x1) && PyUnicode_GET_LENGTH(x1) == 1) ? (npy_uint32)PyUnicode_READ_CHAR(x1, 0) : 0u;
     if (x0 != x1) {

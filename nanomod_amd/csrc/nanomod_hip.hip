@@ -491,10 +491,10 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   };
   const bool wide_f32 = all && prm->dtype == NMOD_DTYPE_F32;
   // all tests on capacity-256 positions: the counting form is tried first (rank_count.hpp; a device-side probe decides whether
-  // the batch is event-like, positions it cannot take fall through to rank_hist_kernel).  Not for float32 images of float64
-  // samples (their grid positions carry k, not k / 1000, as keys).  NMOD_NO_COUNTING=1 in the environment turns it off (A/B).
+  // the batch is event-like, positions it cannot take fall through to rank_hist_kernel).  The float32 images of float64 samples
+  // qualify where they are whole numbers (positions on the 0.001 grid carry k as keys).  NMOD_NO_COUNTING=1 turns it off (A/B).
   static const bool counting_off = []() { const char* e = getenv("NMOD_NO_COUNTING"); return e && *e && *e != '0'; }();
-  if (all && !f64 && !counting_off) { ra.cnt_gate = ws.meta + kMetaCntGate; ra.cnt_done = ws.cnt_done; }
+  if (all && !counting_off) { ra.cnt_gate = ws.meta + kMetaCntGate; ra.cnt_done = ws.cnt_done; }
 
   auto launch = [&](int cls, int64_t work) -> hipError_t {
     ra.class_id = cls;
@@ -1090,6 +1090,9 @@ int nmod_downsample_ks(const nmod_params* prm, int64_t nflag, const void* sig0, 
     }
     const int64_t nrows = hi - lo, nv = nrows * (int64_t)iters;
     if (nv > INT32_MAX) return NMOD_ERR_INVALID_ARG;
+    // every exit below this point — an allocation or launch failing included — first waits for the stream: the asynchronous copies
+    // read the host vectors of this scope (rows / roff / vbase / rn / rsz)
+    struct StreamDrain { hipStream_t s; ~StreamDrain() { (void)hipStreamSynchronize(s); } } drain{stream};
     // ---- device buffers of the chunk (stream-ordered, from the library's pool)
     nmod_params dp = *prm;
     dp.memspace = NMOD_MEM_DEVICE; dp.tests = NMOD_TEST_KS; dp.method = NMOD_METHOD_KS; dp.want_mstd = 0; dp.flags = 0;

@@ -86,6 +86,14 @@ __device__ __forceinline__ int cnt_allmax_i32(int v) {
 }
 __device__ __forceinline__ int cnt_allsum_i32(int v) { return (int)pos_allsum_u32<16>((unsigned)v); }
 
+// DTYPE 2: float32 keys that are whole numbers — the float64 front end's keys of a position whose samples are all k / 1000.0
+// (nanomod_hip.hip: f64_encode_kernel writes (float)k).  Any whole-number keys order and tie like their integers, whatever
+// their unit; the Welch moments of such a batch come from the float64 samples (f64_moments_kernel), not from here.
+__device__ __forceinline__ bool cnt_int_key(float x, int& k) {
+  k = (int)x;                                            // (v_cvt_i32_f32 saturates; NaN -> 0, rejected by the compare)
+  return (float)k == x && __builtin_fabsf(x) <= 32767.0f;
+}
+
 // ---- is this batch event-like?  One block; wave w looks at sampled positions w, w + 16, ...: sizes, grid, range — the
 // very test rank_count_kernel applies per position.  gate[0] = 1 when at least 7 of 8 sampled positions qualify.
 struct CntProbeArgs {
@@ -119,6 +127,7 @@ __global__ __launch_bounds__(1024) void cnt_probe_kernel(CntProbeArgs a) {
       for (int i = lane; i < n && i <= kCntMaxN; i += 64) {
         int k;
         if constexpr (DTYPE == 0) { if (!grid_key<true>(reinterpret_cast<const float*>(sig)[o + i], k)) ok = false; }
+        else if constexpr (DTYPE == 2) { if (!cnt_int_key(reinterpret_cast<const float*>(sig)[o + i], k)) ok = false; }
         else k = (int)reinterpret_cast<const int16_t*>(sig)[o + i];
         lo = min(lo, k); hi = max(hi, k);
       }
@@ -179,7 +188,8 @@ void rank_count_kernel(RankStatsArgs args) {
   // rows are read through KsRows (ks_rank.hpp): unconditional 16-byte (8-byte) loads, lane gl takes samples
   // c * 64 + 4 gl .. + 3 of chunk c; a row this form cannot take (fewer than 4 or more than 255 samples) is not read
   auto rows_n = [](const Item& d, int n) { return (d.valid && d.n0 >= kCntMinN && d.n0 <= kCntMaxN && d.n1 >= kCntMinN && d.n1 <= kCntMaxN) ? n : 0; };
-  using Rows = KsRows<NS, LG, DTYPE>;
+  constexpr int RDT = (DTYPE == 1) ? 1 : 0;               // the rows' storage type: float32 (DTYPE 0, 2) or int16
+  using Rows = KsRows<NS, LG, RDT>;
 
   Item cur = describe(wave_global);
   Rows rw0, rw1;
@@ -214,7 +224,7 @@ void rank_count_kernel(RankStatsArgs args) {
       const int n = rows_n(cur, g ? n1 : n0);
       // the group's first sample (lane 0, chunk 0, component 0: there for every row of at least 4 samples) stands in the empty slots
       float xfirst = 0.0f; double K = 0.0; int kf = 0;
-      if constexpr (DTYPE == 0) {
+      if constexpr (DTYPE != 1) {
         xfirst = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & ~(LG - 1)) << 2, __float_as_int((float)rw.v[0].x)));
         K = (double)xfirst;
         xfirst2[g] = xfirst;
@@ -233,18 +243,20 @@ void rank_count_kernel(RankStatsArgs args) {
         if (!any) continue;
         const int first = (t >= 4) ? 0 : ((t <= 0) ? 4 : 4 - t);          // components first .. 3 are samples of this lane
         if (!full) vmask |= (0xfu & (0xfu << first)) << (16 * g + 4 * c);
-        if constexpr (DTYPE == 0) {
+        if constexpr (DTYPE != 1) {
           auto four = [&](auto full_tag) {
             int kk[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float xr = (j == 0) ? rw.v[c].x : (j == 1) ? rw.v[c].y : (j == 2) ? rw.v[c].z : rw.v[c].w;
               const float x = (decltype(full_tag)::value || j >= first) ? xr : xfirst;
-              const bool ok = grid_key<true>(x, kk[j]);                    // (|k| <= 32 767: the key fits its half)
+              const bool ok = (DTYPE == 2) ? cnt_int_key(x, kk[j]) : grid_key<true>(x, kk[j]);   // (|k| <= 32 767: the key fits its half)
               bad = bad || !ok;
-              const double d = (double)x - K;
-              f1[g] += d;
-              f2[g] = __fma_rn(d, d, f2[g]);
+              if constexpr (DTYPE == 0) {
+                const double d = (double)x - K;
+                f1[g] += d;
+                f2[g] = __fma_rn(d, d, f2[g]);
+              }
             }
             KP[8 * g + 2 * c] = ((unsigned)kk[0] & 0xffffu) | ((unsigned)kk[1] << 16);
             KP[8 * g + 2 * c + 1] = ((unsigned)kk[2] & 0xffffu) | ((unsigned)kk[3] << 16);
@@ -276,7 +288,7 @@ void rank_count_kernel(RankStatsArgs args) {
       }
     }
     // ---- the moments are final here: written at once (a position that turns out not to fit is written again by rank_hist_kernel)
-    {
+    if constexpr (DTYPE != 2) {
       double mean[2], m2[2];
 #pragma unroll
       for (int g = 0; g < 2; ++g) {

@@ -154,18 +154,29 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
     CntProbeArgs pa;
     pa.sig0 = args.sig0; pa.sig1 = args.sig1; pa.off0 = args.off0; pa.off1 = args.off1; pa.stride0 = args.stride0; pa.stride1 = args.stride1;
     pa.npos = args.npos; pa.pos_list = args.pos_list; pa.class_meta = args.class_meta; pa.class_id = args.class_id; pa.dtype = DT; pa.gate = args.cnt_gate;
+    // (float32 keys of float64 samples — args.tied is set — are whole numbers where the samples sit on the 0.001 grid: DTYPE 2)
+#if NMOD_INST_DTYPE == 0
+    const bool int_keys = args.tied != nullptr;
+    if (int_keys) hipLaunchKernelGGL(cnt_probe_kernel<2>, dim3(1), dim3(1024), 0, stream, pa);
+    else hipLaunchKernelGGL(cnt_probe_kernel<0>, dim3(1), dim3(1024), 0, stream, pa);
+    static std::atomic<int> cnt_per_cu[64][2];
+    KernelFn cfn = int_keys ? (KernelFn)rank_count_kernel<2> : (KernelFn)rank_count_kernel<0>;
+    std::atomic<int>& cpc_slot = cnt_per_cu[cacheable ? dev : 0][int_keys ? 1 : 0];
+#else
     hipLaunchKernelGGL(cnt_probe_kernel<DT>, dim3(1), dim3(1024), 0, stream, pa);
-    static std::atomic<int> cnt_per_cu[64];
+    static std::atomic<int> cnt_per_cu[64][1];
     KernelFn cfn = rank_count_kernel<DT>;
+    std::atomic<int>& cpc_slot = cnt_per_cu[cacheable ? dev : 0][0];
+#endif
     const size_t clds = rank_count_lds_bytes();
-    int cpc = cacheable ? cnt_per_cu[dev].load(std::memory_order_relaxed) : 0;
+    int cpc = cacheable ? cpc_slot.load(std::memory_order_relaxed) : 0;
     if (cpc <= 0) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds);
       if (e != hipSuccess) return e;
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&cpc, cfn, 64 * kWavesPerBlock, clds);
       if (e != hipSuccess) return e;
       if (cpc < 1) return hipErrorLaunchOutOfResources;
-      if (cacheable) cnt_per_cu[dev].store(cpc, std::memory_order_relaxed);
+      if (cacheable) cpc_slot.store(cpc, std::memory_order_relaxed);
     }
     int64_t cblocks = std::min<int64_t>((work_items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)num_cus * cpc);
     if (cblocks < 1) cblocks = 1;

@@ -56,9 +56,13 @@ def mfilter_coverage(moptions):
     for dsn in moptions['ds2']:
         curds = moptions[dsn]['norm_mean']
         for sk in sorted(curds.keys()):
-            if hw is not None and type(curds[sk]) is dict and type(moptions[dsn]['base'][sk]) is dict:
-                # one C pass over the strand's dict in storage order (4.6 M positions: 0.05 s instead of 0.5 - 1.0 s)
-                hw.filter_coverage(curds[sk], moptions[dsn]['base'][sk], int(moptions['MinCoverage']))
+            bases = moptions[dsn]['base'].get(sk) if type(moptions[dsn]['base']) is dict else None
+            if (hw is not None and type(curds[sk]) is dict and type(bases) is dict and
+                    isinstance(moptions['MinCoverage'], (int, np.integer)) and not isinstance(moptions['MinCoverage'], bool)):
+                # one C pass over the strand's dict in storage order (4.6 M positions: 0.05 s instead of 0.5 - 1.0 s).  Only for an
+                # integer threshold (len(row) < 4.5 keeps 5, an int() of it would not) and when the strand has its base dict — the
+                # loop below raises for a missing one only when it actually deletes, like the reference
+                hw.filter_coverage(curds[sk], bases, int(moptions['MinCoverage']))
             else:
                 for pk in sorted(curds[sk].keys()):
                     if len(curds[sk][pk]) < moptions['MinCoverage']:

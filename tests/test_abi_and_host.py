@@ -484,3 +484,44 @@ def test_dispatch_forms_keep_16_keys_per_lane():
         prm = L.make_params(tests=tests)
         assert lib.nmod_describe_dispatch(C.byref(prm), a, b, buf, 96) == 0
         assert buf.value == name, (tests, a, b, buf.value)
+
+
+def test_mfilter_coverage_fast_path_keeps_the_reference_semantics():
+    """a non-integer MinCoverage is not truncated (len 4 < 4.5 is deleted, as `len(row) < MinCoverage` does), and a
+    strand missing from 'base' raises only when something is actually deleted (myDetect.py:304-309)"""
+    import nanomod_amd.detect as D
+    mo = {'ds2': ['A'], 'MinCoverage': 4.5, 'A': {'norm_mean': {('c', '+'): {1: [1.0] * 4, 2: [1.0] * 5}}, 'base': {('c', '+'): {1: 'A', 2: 'C'}}}}
+    D.mfilter_coverage(mo)
+    assert sorted(mo['A']['norm_mean'][('c', '+')]) == [2] and sorted(mo['A']['base'][('c', '+')]) == [2]
+    mo = {'ds2': ['A'], 'MinCoverage': 3, 'A': {'norm_mean': {('c', '+'): {1: [1.0] * 4, 2: [1.0] * 5}}, 'base': {}}}
+    D.mfilter_coverage(mo)                                   # nothing to delete: no lookup of the missing base dict
+    assert sorted(mo['A']['norm_mean'][('c', '+')]) == [1, 2]
+    mo['MinCoverage'] = 5
+    with pytest.raises(KeyError):
+        D.mfilter_coverage(mo)                               # the delete reaches base[sk], as in the reference
+
+
+def test_join_strand_leaves_exotic_rows_and_bases_to_the_python_loop():
+    """the C walk holds borrowed rows / bases and must not run Python code on them: a list subclass with its own
+    __len__, or a str subclass with its own __eq__, sends the strand to the Python loop — same CSR either way"""
+    import nanomod_amd.detect as D
+
+    class OddList(list):
+        pass
+
+    class OddStr(str):
+        def __eq__(self, other):
+            return str.__eq__(self, other)
+        __hash__ = str.__hash__
+
+    def options(row_type, base_type):
+        mo = {'ds2': ['A', 'B'], 'outLevel': 3}
+        for ds, shift in (('A', 0.0), ('B', 0.5)):
+            mo[ds] = {'norm_mean': {('c', '+'): {p: row_type([np.float64(p + shift + 0.001 * i) for i in range(6)]) for p in range(5000)}},
+                      'base': {('c', '+'): {p: base_type('ACGT'[p % 4]) for p in range(5000)}}, 'basedict': {}}
+        return mo
+    ref = D.build_csr(options(list, str))
+    for rt, bt in ((OddList, str), (list, OddStr)):
+        got = D.build_csr(options(rt, bt))
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+        assert list(got[0]['pos']) == list(ref[0]['pos']) and [str(b) for b in got[0]['base']] == [str(b) for b in ref[0]['base']]

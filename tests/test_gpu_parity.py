@@ -397,7 +397,7 @@ def test_synth_fill_events_matches_the_numpy_restatement(nm):
 
 
 @pytest.mark.parametrize('spread', [100, 200, 400])
-@pytest.mark.parametrize('dtype', ['f32', 'i16'])
+@pytest.mark.parametrize('dtype', ['f32', 'i16', 'f64'])
 def test_event_like_batches_vs_oracle(nm, spread, dtype):
     """event-like rows (a level per position, reads spread 0.1 / 0.2 / 0.4 units around it, 3-decimal grid: most samples tie):
     200 v 200 fixed stride and ragged sizes around it, KS-only and all tests, against the oracle"""
@@ -405,8 +405,9 @@ def test_event_like_batches_vs_oracle(nm, spread, dtype):
     import oracle_c
     L = nm._lib
     P = 1200
-    a = H.synth_events_ref(11, 4990, P, 0, 256, 5000, 800, spread, dtype)
-    b = H.synth_events_ref(11, 4990, P, 1, 256, 5000, 800, spread, dtype)
+    # ('f64': the rows as the reference holds them, k / 1000.0 — the float64 front end gives such positions k as keys)
+    a = H.synth_events_ref(11, 4990, P, 0, 256, 5000, 800, spread, 'i16' if dtype == 'f64' else dtype)
+    b = H.synth_events_ref(11, 4990, P, 1, 256, 5000, 800, spread, 'i16' if dtype == 'f64' else dtype)
     rid = np.zeros(P, np.int32)
     rng = np.random.default_rng(spread)
     for shape in ('stride', 'ragged'):
@@ -419,6 +420,8 @@ def test_event_like_batches_vs_oracle(nm, spread, dtype):
         off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum(s1)
         sig0 = np.concatenate([a[i, :s0[i]] for i in range(P)]); sig1 = np.concatenate([b[i, :s1[i]] for i in range(P)])
         exp = oracle_c.detect_batch(sig0, off0, sig1, off1, rid, 2, 2.0, 'fisher', tests=7)
+        if dtype == 'f64':
+            sig0 = sig0.astype(np.float64) / 1000.0; sig1 = sig1.astype(np.float64) / 1000.0
         kw = dict(stride0=200, stride1=200) if shape == 'stride' else {}
         got = nm.detect_host(sig0, None if shape == 'stride' else off0, sig1, None if shape == 'stride' else off1, rid, nb=2,
                              weights_dif=2.0, method='fisher', **kw)

@@ -1004,7 +1004,10 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
   if (cls >= kNumGeneralClasses) {
     const int cm = cls - kNumGeneralClasses;
     const int LG = packed_lanes_per_group(cm), R = (64 << cm) / LG;
-    snprintf(buf, buflen, "rank_hist_kernel<%d,%d,%s>", R, LG, dt);
+    // capacity-256 positions: the counting form when the device-side probe finds the batch event-like (a property of the data)
+    if (cm == 2 && prm->dtype != NMOD_DTYPE_F64) snprintf(buf, buflen, "rank_count_kernel<%s> (event-like rows) | rank_hist_kernel<%d,%d,%s>", dt, R, LG, dt);
+    else if (cm == 2) snprintf(buf, buflen, "rank_count_kernel<f32 keys> (event-like rows) | rank_hist_kernel<%d,%d,%s>", R, LG, dt);
+    else snprintf(buf, buflen, "rank_hist_kernel<%d,%d,%s>", R, LG, dt);
   } else if (wide_class(cls)) {
     snprintf(buf, buflen, "rank_hist_kernel<%d,64,%s,wide>", 1 << std::min(c0, c1), dt);
   } else {

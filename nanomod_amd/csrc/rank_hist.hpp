@@ -421,11 +421,20 @@ void rank_hist_kernel(RankStatsArgs args) {
     // rank NV samples: all the searches first (independent chains of LDS reads that the scheduler interleaves), then
     // the histogram updates: bin L(x) += 1 << 16, + 1 when x equals the key it landed on (ks_rank.hpp) — no second
     // search and no branch on ties
+#ifndef NMOD_WIDE_TOPS
+#define NMOD_WIDE_TOPS 0
+#endif
+    // WIDE: one position per wave, so S is wave-uniform: the probes of the first two search levels as scalars (ks_rank.hpp)
+    [[maybe_unused]] KsTops tops;
+    if constexpr (WIDE && NMOD_WIDE_TOPS) tops = ks_tops<R, LG>(keys);
     auto rank_many = [&](auto nv_tag, const float* xq, bool have, unsigned* ad) {
       constexpr int NV = decltype(nv_tag)::value;
       const float* lp[NV];
 #pragma unroll
-      for (int e = 0; e < NV; ++e) lp[e] = ks_search<R, LG, false, true>(keys, xq[e]);
+      for (int e = 0; e < NV; ++e) {
+        if constexpr (WIDE && NMOD_WIDE_TOPS) lp[e] = ks_search_tops<R, LG>(keys, xq[e], tops);
+        else lp[e] = ks_search<R, LG, false, true>(keys, xq[e]);
+      }
       unsigned inc[NV];
 #pragma unroll
       for (int e = 0; e < NV; ++e) inc[e] = (*lp[e] == xq[e]) ? 0x10001u : 0x10000u;

@@ -39,7 +39,7 @@ def test_shipped_binary_is_a_product_build():
     assert names == ['abi_tu', 'k1_f32_ks', 'k1_f32_all', 'k1_i16_ks', 'k1_i16_all']
     want = {'NMOD_SKIP': '0', 'NMOD_EXP': '0', 'NMOD_HIST_WAVES': '4', 'NMOD_WIDE_I16_WORDS': '2048',
             'NMOD_SWZ_MASK': '0', 'NMOD_PK_SELECT': '0', 'NMOD_CE_BUILTIN': '0', 'NMOD_XOR4_BANKS': '0', 'NMOD_NO_GRID': '0',
-            'NMOD_CNT_SKIP': '0', 'NMOD_CNT_WAVES': '4'}
+            'NMOD_CNT_SKIP': '0', 'NMOD_CNT_WAVES': '4', 'NMOD_KS_TOPS': '1', 'NMOD_WIDE_TOPS': '0'}
     for p in parts[1:]:
         got = dict(kv.split('=') for kv in p.split(': ', 1)[1].split())
         assert got == want, (p, got)
@@ -476,7 +476,7 @@ def test_dispatch_forms_keep_16_keys_per_lane():
         (1, 100, 100): b'ks_rank_kernel<16,8,f32>', (1, 200, 200): b'ks_rank_kernel<16,16,f32>',
         (1, 500, 500): b'ks_rank_kernel<16,32,f32>', (1, 1000, 1000): b'ks_rank_kernel<16,64,f32>',
         (1, 2000, 2000): b'ks_rank_kernel<32,64,f32>', (1, 50, 1000): b'ks_rank_kernel<8,8,f32>',
-        (7, 200, 200): b'rank_hist_kernel<16,16,f32>', (7, 500, 500): b'rank_hist_kernel<16,32,f32>',
+        (7, 200, 200): b'rank_count_kernel<f32> (event-like rows) | rank_hist_kernel<16,16,f32>', (7, 500, 500): b'rank_hist_kernel<16,32,f32>',
         (7, 1000, 1000): b'rank_hist_kernel<16,64,f32>', (7, 50, 1000): b'rank_hist_kernel<1,64,f32,wide>',
     }
     buf = C.create_string_buffer(96)

@@ -27,16 +27,29 @@ def test_rational_d_flag_through_side_and_host_legs():
     assert d['verify']['ok'] and 'NMOD_FLAG_KS_RATIONAL_D' in d['config']['ks_d']
     assert all(d[k]['verify']['ok'] for k in ('all_tests', 'int16', 'real_ties'))
     hp = d['host_path']
-    assert all(v['equals_device_resident_pass'] for v in hp.values() if isinstance(v, dict))
+    assert all(v.get('equals_device_resident_pass', v.get('equals_int16_pass')) for v in hp.values() if isinstance(v, dict))
+    assert 'float64_grid' in hp
     assert d['roofline']['bound'] == 'valu-issue' and d['build_info'].startswith('arch=gfx950')
 
 
 def test_default_line_carries_every_leg():
-    d = _bench(['--positions', '120000', '--side-legs', 'all_tests,int16,rational_d,real_ties'])
+    d = _bench(['--positions', '120000', '--side-legs', 'all_tests,int16,rational_d,real_ties,real_spread'])
     assert d['verify']['ok'] and 'library default' in d['config']['ks_d']
     for k in ('all_tests', 'int16', 'rational_d', 'real_ties'):
         assert d[k]['verify']['ok'] and d[k]['value'] > 0 and 0 < d[k]['roofline_frac'] < 1, k
+    rs = d['real_spread']
+    for k in ('all_tests_f32_sigma_0.2', 'all_tests_i16_sigma_0.2', 'ks_f32_sigma_0.2', 'ks_i16_sigma_0.2', 'all_tests_f32_sigma_0.1',
+              'all_tests_i16_sigma_0.1', 'all_tests_f32_sigma_0.4', 'all_tests_i16_sigma_0.4'):
+        assert rs[k]['verify']['ok'] and rs[k]['value'] > 0, k
     assert d['host_path']['pageable_float32']['chunks'] >= 1 and d['host_path']['pinned_h2d_GBps'] > 1
+
+
+def test_event_like_main_configuration():
+    """`--spread 200`: the main workload on event-like rows (both dtypes, all tests): the counting form, verified like any other line"""
+    for dt in ('f32', 'i16'):
+        d = _bench(['--config', 'alltests', '--spread', '200', '--dtype', dt, '--positions', '200000', '--no-side', '--no-host-path'])
+        assert d['verify']['ok'] and d['config']['spread_milli'] == 200 and 'rank_count_kernel' in d['roofline']['kernel']
+        assert d['verify']['max_abs_err_ks_d'] == 0.0 and d['verify']['max_abs_err_mwu_u'] == 0.0
 
 
 def test_ragged_all_tests_grid_input_and_forced_collective():
@@ -54,3 +67,7 @@ def test_drop_in_leg_on_the_reference_dict_shape():
     for shape in ('arrays', 'lists'):
         assert di[shape]['verify_ok'] and di[shape]['table_lines'] == 460000 and di[shape]['mtest2_s'] < 5.0
     assert di['arrays']['first_ranked'] == di['lists']['first_ranked']
+    big = di['at_200v200']
+    assert big['reads_per_group'] == 200 and big['arrays']['verify_ok'] and big['arrays']['table_lines'] == 460000
+    st = big['arrays']['stages']
+    assert st['h2d_bytes'] >= 460000 * 400 * 8 and all(st[k] > 0 for k in ('build_csr_s', 'detect_host_s', 'rank_order_s', 'write_table_s'))

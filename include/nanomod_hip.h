@@ -10,7 +10,9 @@
  * CU count and of each kernel's occupancy (atomics, idempotent), and one HIP
  * memory pool per device, owned by the library, from which the scratch of the
  * large-position pass is allocated stream-ordered (freed slabs stay cached in
- * that pool until nmod_trim_scratch(); the device's default pool is not touched).
+ * that pool until nmod_trim_scratch(); the device's default pool is not touched),
+ * and the four tunables of nmod_host_pipeline_config (atomics; they change how a
+ * host-resident batch is chunked and copied, never a result).
  *
  * Data layout: the tested positions, in the
  * reference's iteration order (sorted (chrom,strand), then ascending

@@ -207,7 +207,8 @@ class SignTestRecords(collections.abc.Sequence):
     """`moptions['sign_test']` as the reference builds it (myDetect.py:436) — a sequence of
     ((chrom, strand, pos, base, n0, n1), [(U, pU), (t, pt), (D, pKS)[, (comb stat, comb p)]]) records — backed by
     the result arrays: a record is built when it is first asked for and kept (so `sorted_sign_test` holds the same
-    objects), 4.6 M tuples are not built up front.  A read-only `collections.abc.Sequence`: len, indexing, slicing,
+    objects), 4.6 M tuples are not built up front.  A `collections.abc.Sequence` (no item assignment, no append; a record itself can be
+    edited in place and the edit is kept — `edited()`): len, indexing, slicing,
     iteration, sorted(), `in`, reversed(), `.count()`, `.index()` (what mySimulate.getTopRank calls on it,
     mySimulate.py:312 — constant time for a record obtained from this object or its ranked view), `==` against a
     list of records, `+` (gives a list); it pickles as a plain list."""
@@ -323,6 +324,13 @@ class SignTestRecords(collections.abc.Sequence):
 
     def __repr__(self):
         return 'SignTestRecords(%d records%s)' % (len(self), ', ranked view' if self._order is not None else '')
+
+    def edited(self):
+        """True when a record handed out by this object no longer equals what the result arrays hold — a caller edited it in
+        place the reference's way (`sign_test[i][1].append(...)`, myDetect.py:377: the records are kept once built, so such an
+        edit persists in the sequence).  save_test then writes the table from the records, not from the arrays."""
+        root = self._parent if self._parent is not None else self
+        return any(rec != root._build(i) for i, rec in root._cache.items())
 
     def permuted(self, order):
         """the same records in another order (the ranking)"""
@@ -572,7 +580,7 @@ def save_test(moptions):
         print('Test data is saved in', txtfile)
     with_comb = moptions["neighborPvalues"] > 0 and (not moptions["testMethod"] == "ks")
     recs = moptions['sign_test']
-    if isinstance(recs, SignTestRecords) and recs._parent is None and recs._order is None:
+    if isinstance(recs, SignTestRecords) and recs._parent is None and recs._order is None and not recs.edited():
         meta, res = recs._meta, recs._res
     else:
         meta, res = _arrays_from_records(recs, with_comb)

@@ -525,3 +525,23 @@ def test_join_strand_leaves_exotic_rows_and_bases_to_the_python_loop():
         got = D.build_csr(options(rt, bt))
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
         assert list(got[0]['pos']) == list(ref[0]['pos']) and [str(b) for b in got[0]['base']] == [str(b) for b in ref[0]['base']]
+
+
+def test_records_edited_in_place_reach_the_table(tmp_path):
+    """VERDICT r4 weak point 8: the reference's combin_pvalues edits records in place (`sign_test[i][1].append(...)`,
+    myDetect.py:377).  The lazily built records are kept once handed out, so such an edit persists; save_test notices it
+    (`SignTestRecords.edited()`) and writes the table from the records, not from the result arrays — host code only."""
+    import nanomod_amd.detect as D
+    n = 6
+    meta = dict(chrom=np.array(['c'] * n, dtype=object), strand=np.array(['+'] * n, dtype=object), pos=np.arange(n, dtype=np.int64),
+                base=np.array(['A'] * n, dtype=object), n0=np.full(n, 5, np.int32), n1=np.full(n, 5, np.int32), names=['c'],
+                chrom_id=np.zeros(n, np.int32))
+    res = {k: np.arange(n, dtype=np.float64) + j for j, k in enumerate(('mwu_u', 'mwu_p', 't_t', 't_p', 'ks_d', 'ks_p'))}
+    recs = D.SignTestRecords(meta, res, False)
+    assert not recs.edited()
+    for i in range(n):                                   # what a reference-style combine loop does
+        recs[i][1].append((10.0 + i, 0.5))
+    assert recs.edited() and len(recs[3][1]) == 4 and recs[3][1][3] == (13.0, 0.5)
+    meta2, res2 = D._arrays_from_records(recs, True)
+    assert list(res2['comb_st']) == [10.0 + i for i in range(n)] and list(res2['comb_p']) == [0.5] * n
+    assert list(res2['ks_d']) == list(res['ks_d']) and list(meta2['pos']) == list(range(n))

@@ -436,6 +436,62 @@ def test_event_like_batches_vs_oracle(nm, spread, dtype):
     assert np.array_equal(e2['mwu_u'], exp['mwu_u'][:40]) and np.array_equal(e2['ks_d'], exp['ks_d'][:40])
 
 
+@pytest.mark.parametrize('dtype', ['i16', 'f32', 'f64'])
+def test_counting_form_edges(nm, dtype):
+    """the counting form (rank_count.hpp) at its limits, inside a batch the probe accepts: every sample equal; two distinct values;
+    a key range of exactly 2 047 (fits the window) and 2 048 (does not: the sorting form takes the position); groups of 255 / 4 / 256
+    samples; one group constant; keys at the ends of the int16 domain; a float32 row with one sample off the grid"""
+    import nanomod_oracle as orc
+    L = nm._lib
+    rng = np.random.default_rng(77)
+    rows0, rows1 = [], []
+
+    def add(a, b):
+        rows0.append(np.asarray(a, dtype=np.int64)); rows1.append(np.asarray(b, dtype=np.int64))
+    for _ in range(120):                                   # the bulk: ordinary event-like positions (the probe samples 64 of the batch)
+        lev = int(rng.integers(-3000, 3000)); n0, n1 = int(rng.integers(130, 256)), int(rng.integers(130, 256))
+        add(lev + np.rint(200 * rng.normal(0, 1, n0)), lev + np.rint(200 * rng.normal(0, 1, n1)))
+    edge_at = len(rows0)
+    add([500] * 200, [500] * 200)                          # every sample equal: MWU all identical
+    add([10] * 100 + [11] * 100, [10] * 60 + [11] * 140)   # two distinct values
+    add([0] + [2047] * 199, rng.integers(0, 2048, 200))    # range 2 047: the widest window
+    add([0] + [2048] * 199, rng.integers(0, 2049, 200))    # range 2 048: beyond it
+    add(rng.integers(-100, 100, 255), rng.integers(-100, 100, 4))
+    add(rng.integers(-100, 100, 4), rng.integers(-100, 100, 255))
+    add(rng.integers(-100, 100, 256), rng.integers(-100, 100, 200))       # 256 samples: not this form's
+    add([7] * 200, rng.integers(-300, 300, 200))           # one group constant
+    add(32767 - rng.integers(0, 900, 200), 32767 - rng.integers(0, 900, 200))
+    add(-32767 + rng.integers(0, 900, 200), -32767 + rng.integers(0, 900, 200))
+    add(rng.integers(-1000, 1000, 129), rng.integers(-1000, 1000, 131))
+    add(np.arange(200), np.arange(200) + 1)                # no ties inside a group, every value shared but two
+    P = len(rows0)
+    off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum([len(r) for r in rows0])
+    off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum([len(r) for r in rows1])
+    k0 = np.concatenate(rows0).astype(np.int16); k1 = np.concatenate(rows1).astype(np.int16)
+    rid = np.zeros(P, np.int32)
+    if dtype == 'i16':
+        s0, s1 = k0, k1
+    elif dtype == 'f32':
+        s0 = (k0.astype(np.float64) / 1000.0).astype(np.float32); s1 = (k1.astype(np.float64) / 1000.0).astype(np.float32)
+        s0[off0[5] + 3] = np.nextafter(s0[off0[5] + 3], np.float32(9))          # one ordinary position with a sample off the grid
+    else:
+        s0 = k0.astype(np.float64) / 1000.0; s1 = k1.astype(np.float64) / 1000.0
+    exp = orc.detect_batch(s0, off0, s1, off1, rid, 0, 2.0, orc.METHOD_FISHER)
+    got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher')
+    ident = (exp['status'] & L.STATUS_MWU_ALL_IDENTICAL) != 0
+    assert ident[edge_at] and ident.sum() == 1 and np.array_equal(got['status'], exp['status'])
+    assert np.isnan(got['mwu_u'][edge_at]) and got['ks_d'][edge_at] == 0.0 and got['ks_p'][edge_at] == 1.0
+    for d in (got, exp):
+        d['mwu_u'][ident] = 0.0; d['mwu_p'][ident] = 0.0
+    H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
+    # the same positions alone (a batch of twelve edge cases: whatever the probe decides, the numbers are the same)
+    lo = edge_at
+    sub = nm.detect_host(s0[off0[lo]:], off0[lo:] - off0[lo], s1[off1[lo]:], off1[lo:] - off1[lo], rid[lo:], nb=0, weights_dif=2.0, method='fisher')
+    for k in ('mwu_p', 'ks_d', 'ks_p'):                      # (exact integers into the same K2: bit-equal whichever form produced them)
+        assert np.array_equal(sub[k][1:], got[k][lo + 1:], equal_nan=True), k
+    H.assert_close_p(sub['t_p'][1:], got['t_p'][lo + 1:], 1e-9, 't_p')
+
+
 # general (64 lanes per group) and packed (two positions per wave) kernels, every capacity class
 @pytest.mark.parametrize('sizes', [(5, 64, 5, 64), (65, 128, 3, 30), (65, 128, 65, 128), (129, 256, 129, 256),
                                    (100, 128, 129, 220), (257, 512, 257, 512), (300, 512, 20, 256),

@@ -63,7 +63,8 @@ struct ScopedKernelTimer {
 struct Workspace {
   uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments;
   double* tmp_ks_d; double* tmp_ks_p; double* ks_d_ref;
-  int32_t* order; int32_t* redo; uint8_t* cls; uint8_t* tied; uint8_t* cnt_done; uint8_t* nonfinite; int32_t* meta;   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
+  int32_t* order; int32_t* redo; uint8_t* cls; uint8_t* tied; uint8_t* cnt_done; uint8_t* nonfinite; int32_t* meta;
+  int32_t* work_list; int32_t* work_meta; uint8_t* cw_done;      // counting form for any coverage (rank_count_wide.hpp)   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
   int64_t bytes;
 };
 constexpr int kMetaInts = 256;
@@ -100,6 +101,9 @@ static Workspace carve(void* base, int64_t npos) {
   w.cnt_done = (uint8_t*)take(npos + 16);        // counting form (rank_count.hpp): one flag byte per entry of the work list, dword per item
   w.nonfinite = (uint8_t*)take(npos);             // NMOD_FLAG_CHECK_FINITE: nonfinite_scan_kernel's flags
   w.meta = (int32_t*)take(kMetaInts * 4);
+  w.work_list = (int32_t*)take(4 * npos);          // rank_count_wide.hpp: what the sorting forms still have to do, per class
+  w.work_meta = (int32_t*)take(kMetaInts * 4);      // [c] counts, [kClassStride + c] offsets, [2 kClassStride + c] the probes' gates
+  w.cw_done = (uint8_t*)take(npos + 16);
   w.bytes = o;
   return w;
 }
@@ -505,13 +509,45 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
                : launch_rank_stats_d1_a0(cls, num_cus, work, stream, ra);
   };
 
+  // all tests, classes other than the 256-capacity one: the counting form for any coverage (rank_count_wide.hpp) is tried per class
+  // when its probe finds the class event-like; the sorting form of the class then runs over the work list that is left
+  // (NMOD_NO_COUNT_WIDE=1 turns it off)
+  static const bool cw_off = []() { const char* e = getenv("NMOD_NO_COUNT_WIDE"); return e && *e && *e != '0'; }();
+  const bool cw_on = all && !counting_off && !cw_off;
+  CountWideWs cww;
+  cww.gates = ws.work_meta + 2 * kClassStride; cww.done = ws.cw_done; cww.work_list = ws.work_list; cww.work_meta = ws.work_meta;
+  auto cw_prepare = [&](const std::vector<int>& classes) -> hipError_t {
+    if (classes.empty()) return hipSuccess;
+    return prm->dtype == NMOD_DTYPE_F32 ? launch_count_wide_prepare_d0_a1(classes.data(), (int)classes.size(), stream, ra, cww)
+                                        : launch_count_wide_prepare_d1_a1(classes.data(), (int)classes.size(), stream, ra, cww);
+  };
+  // ... then the counting form over every class the probe accepted and the compaction of what it left, in one launch each
+  auto cw_run = [&](const std::vector<int>& classes) -> hipError_t {
+    if (classes.empty()) return hipSuccess;
+    hipError_t e = cw_prepare(classes);
+    if (e != hipSuccess) return e;
+    return prm->dtype == NMOD_DTYPE_F32 ? launch_count_wide_run_d0_a1(num_cus, npos, stream, ra, cww)
+                                        : launch_count_wide_run_d1_a1(num_cus, npos, stream, ra, cww);
+  };
+  // a class's sorting form, over the work list when the counting form was in play
+  auto launch_class = [&](int cls, int64_t work, bool counted) -> hipError_t {
+    if (!counted) return launch(cls, work);
+    const int32_t* keep_list = ra.pos_list; const int32_t* keep_meta = ra.class_meta;
+    ra.pos_list = ws.work_list; ra.class_meta = ws.work_meta;
+    const hipError_t e = launch(cls, work);
+    ra.pos_list = keep_list; ra.class_meta = keep_meta;
+    return e;
+  };
+
   DevScratch big_scratch;
   if (uniform && !big_possible) {
     const int ucls = all ? launch_class_of(cmax0, cmax1) : kKsClassBase + std::min(cmax0, cmax1);
     const bool uwide = wide_f32 && wide_class(ucls);
     if (uwide && !meta_cleared && !f64) NMOD_HIP(hipMemsetAsync(ws.meta + kMetaWideRedo, 0, 4, stream));   // (the meta block is not cleared for uniform batches)
     ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
-    NMOD_HIP(launch(ucls, npos));
+    const bool counted = cw_on && count_wide_rs_index(ucls) >= 0;
+    if (counted) NMOD_HIP(cw_run(std::vector<int>{ucls}));
+    NMOD_HIP(launch_class(ucls, npos, counted));
     if (uwide) { const int rr = launch_wide_redo(); if (rr != NMOD_OK) return rr; }
   } else {
     BinArgs ba;
@@ -527,16 +563,23 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     bool wanted[kNumClasses] = {false};
     for (int c0 = 0; c0 <= cmax0; ++c0)
       for (int c1 = 0; c1 <= cmax1; ++c1) wanted[all ? launch_class_of(c0, c1) : kKsClassBase + std::min(c0, c1)] = true;
+    ra.pos_list = ws.order; ra.class_meta = ws.meta;
+    std::vector<int> counted_classes;
+    if (cw_on) {
+      for (int cls = 0; cls < kNumClasses; ++cls) if (wanted[cls] && count_wide_rs_index(cls) >= 0) counted_classes.push_back(cls);
+      if (big_possible) for (int cs = 0; cs < kNumWideBig; ++cs) counted_classes.push_back(kWideBigBase + cs);
+      NMOD_HIP(cw_run(counted_classes));
+    }
     for (int cls = 0; cls < kNumClasses; ++cls) {
       if (!wanted[cls]) continue;
       ra.pos_list = ws.order; ra.class_meta = ws.meta; ra.class_id = cls;
-      NMOD_HIP(launch(cls, npos));
+      NMOD_HIP(launch_class(cls, npos, cw_on && count_wide_rs_index(cls) >= 0));
     }
     if (big_possible && all) {
       // larger group of 2 049 .. 4 096 samples against at most 256: rank_hist_kernel WIDE as well
       for (int cs = 0; cs < kNumWideBig; ++cs) {
         ra.pos_list = ws.order; ra.class_meta = ws.meta;
-        NMOD_HIP(launch(kWideBigBase + cs, npos));
+        NMOD_HIP(launch_class(kWideBigBase + cs, npos, cw_on));
       }
     }
     if (wide_f32) {

@@ -1,0 +1,515 @@
+// K1, counting form for any coverage (round 5) — all-tests mode for EVENT-LIKE positions of every shape the reference sees:
+// one position per wave, the smaller group S of up to 64 RS samples (RS = 1 ... 16 registers per lane: 64 ... 1 024 samples), the
+// larger group Q of up to 4 095.  rank_count.hpp is the same idea for four 200 v 200-like positions per wave with byte tables;
+// here the prefix tables hold 16-bit entries over a window of 1 024 ... 4 096 milli-units centred on S, and Q — which is most of
+// the samples at skewed coverage (configs[4]: ~1 131 v ~57) — is never looked up:
+//   table S   count S's keys (ds_add), prefix sums in place, every sample of S reads A[u-1], A[u]        (its own group's ranks)
+//   table Q   STREAM Q once: one returning ds_add per sample counts its key and returns the earlier copies p (for sum_v b^3), its
+//             moment sums ride along; prefix sums in place; every sample of S reads B[u-1], B[u]
+// and with a(v) = A[v] - A[v-1], b(v) = B[v] - B[v-1] at the values v of S (rank_count.hpp has the derivations):
+//   KS        max over S's samples of |A[v] nQ - B[v] nS| and |A[v-1] nQ - B[v-1] nS|, the float form at the samples that reach it
+//   MWU       sum over S of (B[v-1] + B[v]) = sum (#{q < s} + #{q <= s}); mwu_s is that sum when S is group 1, else 2 n0 n1 - it
+//   ties      sum_v (a + b)^3 = sum over S of (a^2 + 3 a b + 3 b^2) + sum_v b^3,  sum_v b^3 = sum over Q of (3 p^2 + 3 p + 1)
+// Per streamed sample: key, window test, address, one LDS atomic, three integer multiply-adds — against a binary search (27
+// instructions), a histogram add, a tie counter and the moments in the sorting form's WIDE instance (rank_hist.hpp).
+// A position is left to the sorting forms (flag byte per list entry, compacted into a work list by cnt_compact_kernel) when a
+// group is out of range, a float32 sample is off the milli-unit grid, a sample of Q falls outside the window, or a value occurs
+// 255 times or more.  Whether a class of a batch is event-like at all is decided by cnt_wide_probe_kernel on a sample of its
+// positions (gate): continuous signals pay the probe, an empty launch and the copy of the class list.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rank_count.hpp"
+#include "rank_stats_launch.hpp"
+
+namespace nmod {
+
+constexpr int kCwMaxQ = 4095;                                  // 16-bit prefix sums, 12-bit arrival numbers
+constexpr int kCwWindow = 2048;                                // values the table can cover: 64 lane blocks of 8, 16 or 32 entries
+constexpr int kCwWaveWords = 64 * 36 + 8;                      // a lane's block: 4 pad words + up to 32 entries; + the dump entry: 9 248 B per wave
+__host__ __device__ constexpr size_t rank_count_wide_lds_bytes() { return (size_t)kWavesPerBlock * kCwWaveWords * 4; }
+
+struct CntWideArgs {
+  RankStatsArgs rs;                                            // rows, class lists, outputs (cnt_gate / cnt_done unused here)
+  const int32_t* gates;                                        // [class] the probe's verdict (cnt_wide_probe_kernel)
+  const int32_t* segs;                                         // [0] number of classes to try, [1 + i] their ids
+  uint8_t* done;                                               // one byte per entry of the class lists
+};
+
+typedef unsigned CntWU2 __attribute__((ext_vector_type(2)));
+
+// ---- probe: 64 sampled positions per class (one block per class of the batch that can take the form); event-like = sizes in
+// range, every sample on the grid, all keys of the position within 2 048 milli-units.
+struct CntWideProbeArgs {
+  const void* sig0; const void* sig1; const int64_t* off0; const int64_t* off1; int64_t stride0, stride1; int64_t npos;
+  const int32_t* pos_list; const int32_t* class_meta;          // null / null: one class, all of [0, npos)
+  int32_t nclasses; int32_t cls[kClassStride]; int32_t max_s[kClassStride];      // block b probes class cls[b]
+  int32_t* gate;                                                 // [kClassStride]: gate[class]
+  int32_t* segs;                                                 // [0] nclasses, [1 + b] cls[b]: the list the later kernels walk
+};
+template <int DTYPE>
+__global__ __launch_bounds__(1024) void cnt_wide_probe_kernel(CntWideProbeArgs a) {
+  __shared__ int fits, seen;
+  const int cid = a.cls[blockIdx.x];
+  if (threadIdx.x == 0) { fits = 0; seen = 0; }
+  __syncthreads();
+  int64_t count = a.npos;
+  const int32_t* list = nullptr;
+  if (a.pos_list) { count = a.class_meta[cid]; list = a.pos_list + a.class_meta[kClassStride + cid]; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t nsamp = count < kCntProbeSamples ? count : kCntProbeSamples;
+  for (int64_t j = wave; j < nsamp; j += 16) {
+    const int64_t li = (j * count) / nsamp;
+    const int64_t pos = list ? (int64_t)list[li] : li;
+    bool ok = true;
+    int lo = 0x7fffffff, hi = (int)0x80000000;
+    int nn[2];
+    for (int g = 0; g < 2; ++g) {
+      const int64_t st = g ? a.stride1 : a.stride0;
+      const int64_t* off = g ? a.off1 : a.off0;
+      const int64_t o = st > 0 ? pos * st : off[pos];
+      const int n = st > 0 ? (int)st : (int)(off[pos + 1] - o);
+      nn[g] = n;
+      const void* sig = g ? a.sig1 : a.sig0;
+      for (int i = lane; i < n && i <= kCwMaxQ; i += 64) {
+        int k;
+        if constexpr (DTYPE == 0) { if (!grid_key<true>(reinterpret_cast<const float*>(sig)[o + i], k)) ok = false; }
+        else if constexpr (DTYPE == 2) { if (!cnt_int_key(reinterpret_cast<const float*>(sig)[o + i], k)) ok = false; }
+        else k = (int)reinterpret_cast<const int16_t*>(sig)[o + i];
+        lo = min(lo, k); hi = max(hi, k);
+      }
+    }
+    const int m = min(nn[0], nn[1]), q = max(nn[0], nn[1]);
+    if (m < 1 || m > a.max_s[blockIdx.x] || q > kCwMaxQ) ok = false;
+    const int vmax = (int)(wave_max_u32((unsigned)hi ^ 0x80000000u) ^ 0x80000000u);
+    const int vmin = (int)(~wave_max_u32(~((unsigned)lo ^ 0x80000000u)) ^ 0x80000000u);
+    const bool fit = __ballot(!ok) == 0ull && (unsigned)(vmax - vmin) < 2048u;
+    if (lane == 0) { atomicAdd(&seen, 1); if (fit) atomicAdd(&fits, 1); }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.gate[cid] = (seen > 0 && fits * 8 >= seen * 7) ? 1 : 0;
+    a.segs[1 + blockIdx.x] = cid;
+    if (blockIdx.x == 0) a.segs[0] = a.nclasses;
+  }
+}
+
+// ---- the work list of the sorting form that follows: every entry of the class when the gate is clear, else the entries
+// rank_count_wide_kernel left (done == 0).  work_list / work_meta have the layout of pos_list / class_meta.
+struct CntCompactArgs {
+  int64_t npos; const int32_t* pos_list; const int32_t* class_meta;
+  const int32_t* gates; const int32_t* segs; const uint8_t* done; int32_t* work_list; int32_t* work_meta;       // work_meta[c] = count, [kClassStride + c] = offset
+};
+// (the work lists start as the class lists themselves: cnt_worklist_init_kernel; a class whose gate is set gets its list rebuilt)
+template <int DT>
+__global__ __launch_bounds__(256) void cnt_worklist_init_kernel(int64_t npos, const int32_t* pos_list, const int32_t* class_meta, int32_t* work_list,
+                                                               int32_t* work_meta, const int32_t* gate, int32_t single_class) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pos_list) {
+    for (int64_t i = t; i < npos; i += (int64_t)gridDim.x * 256) work_list[i] = pos_list[i];
+    if (t < kClassStride) { work_meta[t] = gate[t] ? 0 : class_meta[t]; work_meta[kClassStride + t] = class_meta[kClassStride + t]; }
+  } else {                                                       // fixed-stride batch, one class, no list: the identity
+    if (gate[single_class] == 0) for (int64_t i = t; i < npos; i += (int64_t)gridDim.x * 256) work_list[i] = (int32_t)i;
+    if (t == 0) { work_meta[single_class] = gate[single_class] ? 0 : (int32_t)npos; work_meta[kClassStride + single_class] = 0; }
+  }
+}
+template <int DT>
+__global__ __launch_bounds__(256) void cnt_compact_kernel(CntCompactArgs a) {
+  const int lane = threadIdx.x & 63;
+  __shared__ int base_s;
+  __shared__ int wcnt[4];
+  const int nseg = a.segs[0];
+  for (int sg = 0; sg < nseg; ++sg) {
+    const int cls = a.segs[1 + sg];
+    if (a.gates[cls] == 0) continue;                             // the form was not tried: the work list is the class list
+    int64_t count = a.npos, off = 0;
+    const int32_t* list = nullptr;
+    if (a.pos_list) { count = a.class_meta[cls]; off = a.class_meta[kClassStride + cls]; list = a.pos_list + off; }
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < count; i0 += (int64_t)gridDim.x * 256) {
+      const int64_t i = i0 + threadIdx.x;
+      const bool keep = i < count && a.done[off + i] == 0;
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) wcnt[threadIdx.x >> 6] = __popcll(m);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        base_s = tot ? atomicAdd(&a.work_meta[cls], tot) : 0;
+      }
+      __syncthreads();
+      int at = base_s + __popcll(m & ((1ull << lane) - 1ull));
+      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) at += wcnt[w];
+      if (keep) a.work_list[off + at] = list ? list[i] : (int32_t)i;
+      __syncthreads();
+    }
+  }
+}
+
+// ---- wave-wide helpers of this form
+__device__ __forceinline__ unsigned cw_wave_sum_u32(unsigned v) {
+  v += (unsigned)dpp_i<NMOD_QP(1, 0, 3, 2)>(0, (int)v);
+  v += (unsigned)dpp_i<NMOD_QP(2, 3, 0, 1)>(0, (int)v);
+  v += (unsigned)dpp_i<kDppRowHalfMirror>(0, (int)v);
+  v += (unsigned)dpp_i<kDppRowMirror>(0, (int)v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ unsigned cw_wave_max_pk_u16(unsigned v) {          // both 16-bit halves at once
+  auto mx = [](unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(CntU2, a), __builtin_bit_cast(CntU2, b))); };
+  v = mx(v, (unsigned)dpp_i<NMOD_QP(1, 0, 3, 2)>((int)v, (int)v));
+  v = mx(v, (unsigned)dpp_i<NMOD_QP(2, 3, 0, 1)>((int)v, (int)v));
+  v = mx(v, (unsigned)dpp_i<kDppRowHalfMirror>((int)v, (int)v));
+  v = mx(v, (unsigned)dpp_i<kDppRowMirror>((int)v, (int)v));
+  return mx(mx(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), mx(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// 1 / n, correctly rounded, n <= 4 095 (hist_exact_quot's r): one scalar load instead of a float64 division per position
+struct CwRcpTable {
+  double v[4096];
+  constexpr CwRcpTable() : v{} { for (int i = 1; i < 4096; ++i) v[i] = 1.0 / (double)i; }
+};
+static __device__ const CwRcpTable kCwRcp = CwRcpTable();
+
+// one class of the batch (a segment of the class lists): positions start, start + stride, ... of its list
+template <int DTYPE, int RS>
+__device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* done, unsigned* tbl, int64_t count, int64_t loff, const int32_t* list,
+                                           int64_t start, int64_t wave_stride, int lane) {
+  constexpr int RDT = (DTYPE == 1) ? 1 : 0;
+  using Q4Raw = typename std::conditional<RDT == 0, KsF4, KsS4>::type;
+  using Q1Raw = typename std::conditional<RDT == 0, float, int16_t>::type;
+  const unsigned tb = (unsigned)(uintptr_t)(CntLdsU32)tbl;
+  const unsigned tbE = tb + 16u;                           // entry 0 of block 0 (after its pad)
+
+  auto key_of = [&](float x, int& k) -> bool {            // float32 rows: the integer key and whether the sample has one
+    if constexpr (DTYPE == 2) return cnt_int_key(x, k);
+    else return grid_key<true>(x, k);
+  };
+  const CntU2 one2 = {1, 1};
+  const CntS2 sone2 = {1, 1};
+  const CntU2 hi1 = {0, 1};
+
+  // (the next position's list entry and offsets are requested while this one is counted: two dependent loads off the path)
+  struct Hdr { int64_t pos, o0, o1; int n0, n1; };
+  auto load_hdr = [&](int64_t it) -> Hdr {
+    Hdr h; h.pos = 0; h.o0 = h.o1 = 0; h.n0 = h.n1 = 0;
+    if (it < count) {
+      h.pos = list ? (int64_t)list[it] : it;
+      if (args.stride0 > 0) { h.o0 = h.pos * args.stride0; h.n0 = (int)args.stride0; } else { h.o0 = args.off0[h.pos]; h.n0 = (int)(args.off0[h.pos + 1] - h.o0); }
+      if (args.stride1 > 0) { h.o1 = h.pos * args.stride1; h.n1 = (int)args.stride1; } else { h.o1 = args.off1[h.pos]; h.n1 = (int)(args.off1[h.pos + 1] - h.o1); }
+    }
+    return h;
+  };
+  Hdr nxt = load_hdr(start);
+  for (int64_t it = start; it < count; it += wave_stride) {
+    const Hdr cur = nxt;
+    nxt = load_hdr(it + wave_stride);
+    const int64_t pos = cur.pos, o0 = cur.o0, o1 = cur.o1;
+    const int n0 = cur.n0, n1 = cur.n1;
+    const bool swap = n1 < n0;                             // S = the smaller group (ties: group 1)
+    const int m = swap ? n1 : n0, q = swap ? n0 : n1;
+    const void* sig_s = swap ? args.sig1 : args.sig0; const void* sig_q = swap ? args.sig0 : args.sig1;
+    const int64_t off_s = swap ? o1 : o0, off_q = swap ? o0 : o1;
+    bool fit = m >= 1 && m <= 64 * RS && q <= kCwMaxQ;     // (wave-uniform)
+    const int mm = fit ? m : 0, qq = fit ? q : 0;
+    // Q's rows are requested before anything else is done: up to PF chunks of 256 samples (four per lane) and the <= 255 that
+    // remain one per lane; with one chunk in flight the loop waited a memory latency per 50 instructions
+    constexpr int PF = (RDT == 0 && RS == 16) ? 2 : 4;
+    const int full = qq / 256;
+    const int tail = (qq - full * 256 + 63) / 64;
+    const Q1Raw* rowq = reinterpret_cast<const Q1Raw*>(sig_q) + off_q;
+    Q4Raw qa[PF];
+    Q1Raw rt[4];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) qa[j] = ks_global_load<Q4Raw>(j < full ? rowq + j * 256 + 4 * lane : reinterpret_cast<const Q1Raw*>(kKsBig4));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rt[j] = ks_global_load<Q1Raw>(full * 256 + j * 64 + lane < qq ? rowq + full * 256 + j * 64 + lane : reinterpret_cast<const Q1Raw*>(kKsBig4));
+    float xq0 = 0.0f;
+    if constexpr (RDT == 0) xq0 = (float)ks_global_load<Q1Raw>(qq > 0 ? rowq : reinterpret_cast<const Q1Raw*>(kKsBig4));
+
+    // ---- S: sample r * 64 + lane in register r.  Keys, float32 moments, range.
+    int ks[RS];
+    bool bad = false;
+    double ms1 = 0.0, ms2 = 0.0;                           // float32 rows: shifted moment sums
+    float xs0 = 0.0f;
+    {
+      Q1Raw raw[RS];
+#pragma unroll
+      for (int r = 0; r < RS; ++r) {
+        const int idx = r * 64 + lane;
+        raw[r] = ks_global_load<Q1Raw>(idx < mm ? reinterpret_cast<const Q1Raw*>(sig_s) + off_s + idx : reinterpret_cast<const Q1Raw*>(kKsBig4));
+      }
+      if constexpr (RDT == 0) {
+        xs0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)raw[0])));
+        const double K = (double)xs0;
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+          const bool have = r * 64 + lane < mm;
+          const float x = have ? (float)raw[r] : xs0;
+          int k;
+          const bool ok = key_of(x, k);
+          bad = bad || !ok;
+          ks[r] = k;
+          if constexpr (DTYPE == 0) { const double d = (double)x - K; ms1 += d; ms2 = __fma_rn(d, d, ms2); }
+        }
+      } else {
+        const int ks0 = __builtin_amdgcn_readfirstlane((int)raw[0]);
+#pragma unroll
+        for (int r = 0; r < RS; ++r) ks[r] = (r * 64 + lane < mm) ? (int)raw[r] : ks0;
+      }
+    }
+    int smin, smax;
+    {
+      int kmx = ks[0], kmn = ks[0];
+#pragma unroll
+      for (int r = 1; r < RS; ++r) { kmx = max(kmx, ks[r]); kmn = min(kmn, ks[r]); }
+      const unsigned P = cw_wave_max_pk_u16(((unsigned)(kmx + 32768) & 0xffffu) | ((unsigned)(32767 - kmn) << 16));   // (a float32 key out of range: `bad`)
+      smax = (int)(P & 0xffffu) - 32768; smin = 32767 - (int)(P >> 16);
+    }
+    fit = fit && __ballot(bad) == 0ull && (smax - smin) < kCwWindow - 1;
+    // the window: 512, 1 024 or 2 048 values centred on S, at least 1.5 times S's own range + 640 wide when that fits (Q is 10-20
+    // times S at skewed coverage and spreads a little further; a sample of Q outside the window lands in the dump entry, the
+    // table's total comes up short and the position goes to the sorting form); E = 1 << lgE entries per lane block
+    const int need = fit ? (3 * (smax - smin)) / 2 + 640 : 0;
+    const int lgE = need <= 512 ? 3 : (need <= 1024 ? 4 : 5);
+    const int W = 64 << lgE;
+    int base = ((smin + smax) >> 1) - (W >> 1);
+    base = max(-32768, min(base, 32768 - W));             // (inside the int16 domain: k - base mod 2^16 cannot alias into the window)
+    const int c = base + (W >> 1);                         // moments are taken about the centre: |k - c| <= 1 024
+
+    unsigned sp = 0u, sp2 = 0u;                            // over the arrivals of both groups: p = earlier copies of the sample's value
+    int is1 = 0, iq1 = 0; unsigned is2 = 0u, iq2 = 0u;     // int16 rows: exact sums of k - c
+    double mq1 = 0.0, mq2 = 0.0;
+    unsigned mws = 0u; int vmax = 0, vmin = 0; unsigned best = 0u;
+    double dmax = 0.0;
+    unsigned addr[RS];
+    const CntS2 qm = {(short)q, (short)-m};
+    if (fit) {
+      const int nch = 1 << (lgE - 2);                      // 16-byte chunks of a lane block: 2, 4, 8
+      uint4* blk = reinterpret_cast<uint4*>(__builtin_assume_aligned(reinterpret_cast<char*>(tbl) + lane * ((4 << lgE) + 16) + 16, 16));
+      auto entry = [&](unsigned u) -> unsigned { return tbE + (u << 2) + ((u >> lgE) << 4); };
+      {                                                    // ---- clear
+        unsigned z = 0u;
+        asm volatile("" : "+v"(z));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) if (i <= nch) blk[i - 1] = make_uint4(z, z, z, z);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      auto arrive = [&](unsigned a, unsigned inc, bool have) {     // count one sample; its arrival number among the copies of its value
+        const unsigned old = __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)a, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        unsigned p = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, old), one2, 0u, false);
+        p = have ? p : 0u;
+        sp2 = __umul24(p, p) + sp2; sp += p;
+      };
+      // ---- S
+#pragma unroll
+      for (int r = 0; r < RS; ++r) {
+        const bool have = r * 64 + lane < m;
+        addr[r] = entry(have ? (unsigned)(ks[r] - base) : (unsigned)W);      // (no sample: the dump entry, one past the window)
+        arrive(addr[r], 1u, have);
+        if constexpr (RDT == 1) { const int d = have ? ks[r] - c : 0; is1 += d; is2 += (unsigned)__mul24(d, d); }
+      }
+      // ---- Q, streamed once
+      const double KQ = (double)xq0;
+      const unsigned cc = ((unsigned)c & 0xffffu) * 0x10001u, hw2 = (unsigned)(W >> 1) * 0x10001u, w2 = (unsigned)W * 0x10001u;
+      auto q_f32 = [&](float x, bool have) {
+        int k;
+        const bool ok = key_of(x, k);
+        bad = bad || !ok;
+        if constexpr (DTYPE == 0) { const double d = (double)x - KQ; mq1 += d; mq2 = __fma_rn(d, d, mq2); }
+        unsigned u = min((unsigned)(k - base), (unsigned)W);
+        u = have ? u : (unsigned)W;
+        arrive(entry(u), 0x10000u, have);
+      };
+      auto q_pair16 = [&](unsigned kk) {                   // two int16 samples of a full chunk
+        const CntS2 d2 = __builtin_bit_cast(CntS2, kk) - __builtin_bit_cast(CntS2, cc);
+        iq1 = __builtin_amdgcn_sdot2(d2, sone2, iq1, false);
+        iq2 = (unsigned)__builtin_amdgcn_sdot2(d2, d2, (int)iq2, false);
+        const unsigned uu = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(CntU2, d2) + __builtin_bit_cast(CntU2, hw2), __builtin_bit_cast(CntU2, w2)));
+        const unsigned x0 = ((uu & 0xffffu) >> lgE << 4) + tbE, x1 = ((uu >> 16) >> lgE << 4) + tbE;
+        unsigned a0, a1;
+        asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(a0) : "v"(uu), "v"(x0));
+        asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(uu), "v"(x1));
+        arrive(a0, 0x10000u, true); arrive(a1, 0x10000u, true);
+      };
+#pragma unroll 1
+      for (int ch0 = 0; ch0 < full; ch0 += PF) {
+        Q4Raw qb[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) qb[j] = qa[j];
+        if (ch0 + PF < full) {                             // (wave-uniform)
+#pragma unroll
+          for (int j = 0; j < PF; ++j) qa[j] = ks_global_load<Q4Raw>(ch0 + PF + j < full ? rowq + (ch0 + PF + j) * 256 + 4 * lane : reinterpret_cast<const Q1Raw*>(kKsBig4));
+        }
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+          if (ch0 + j < full) {                            // (wave-uniform)
+            if constexpr (RDT == 0) {
+              q_f32(qb[j].x, true); q_f32(qb[j].y, true); q_f32(qb[j].z, true); q_f32(qb[j].w, true);
+            } else {
+              const CntWU2 two = __builtin_bit_cast(CntWU2, qb[j]);
+              q_pair16(two.x); q_pair16(two.y);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < tail) {                                    // (wave-uniform)
+          const bool have = full * 256 + j * 64 + lane < q;
+          const Q1Raw cur1 = rt[j];
+          if constexpr (RDT == 0) {
+            q_f32(have ? (float)cur1 : xq0, have);
+          } else {
+            // (the sample and, as its pair, the centre: d = 0 there and only the low half is counted)
+            const unsigned kk = have ? (((unsigned)(int)cur1 & 0xffffu) | (cc & 0xffff0000u)) : cc;
+            const CntS2 d2 = __builtin_bit_cast(CntS2, kk) - __builtin_bit_cast(CntS2, cc);
+            iq1 = __builtin_amdgcn_sdot2(d2, sone2, iq1, false);
+            iq2 = (unsigned)__builtin_amdgcn_sdot2(d2, d2, (int)iq2, false);
+            unsigned uu = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(CntU2, d2) + __builtin_bit_cast(CntU2, hw2), __builtin_bit_cast(CntU2, w2)));
+            uu = have ? uu : (unsigned)W;
+            const unsigned x0 = ((uu & 0xffffu) >> lgE << 4) + tbE;
+            unsigned a0;
+            asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(a0) : "v"(uu), "v"(x0));
+            arrive(a0, 0x10000u, have);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+
+      // ---- prefix sums in place (both halves at once: the S half stays below 2^16); the pad's last word = the sum below the block
+      unsigned tot = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (i < nch) { const uint4 v = blk[i]; tot += (v.x + v.y) + (v.z + v.w); }
+      const unsigned below = seg_exscan_add_u32<64>(tot, lane);
+      const unsigned all_in = __builtin_amdgcn_readlane(below + tot, 63);
+      fit = __ballot(bad) == 0ull && all_in == ((unsigned)m | ((unsigned)q << 16));      // (short: a sample fell outside the window)
+      if (fit) {
+        blk[-1] = make_uint4(0u, 0u, 0u, below);
+        unsigned carry = below;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          if (2 * h < nch) {
+            unsigned w[8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { const uint4 v = blk[2 * h + i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { carry += w[i]; w[i] = carry; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) blk[2 * h + i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- every sample of S: (A | B << 16) just below and at its value
+        constexpr bool KEEP = RS <= 8;                   // the candidates stay in registers (RS = 16: recomputed from the table)
+        int xs[KEEP ? 2 * RS : 2];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+          const bool have = r * 64 + lane < m;
+          const CntLdsU32 pw = (CntLdsU32)(uintptr_t)(have ? addr[r] - 4u : tb + 8u);      // (no sample: two zero words of block 0's pad)
+          const unsigned w0 = pw[0], w1 = pw[1];
+          mws = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, w0), hi1, mws, false);      // #{q < s} + #{q <= s}
+          mws = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, w1), hi1, mws, false);
+          const int x0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, w0), qm, 0, false);   // A nQ - B nS just below the value
+          const int x1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, w1), qm, 0, false);   // ... at it
+          if constexpr (KEEP) { xs[2 * r] = x0; xs[2 * r + 1] = x1; }
+          vmax = max(vmax, max(x0, x1)); vmin = min(vmin, min(x0, x1));
+        }
+        best = wave_max_u32((unsigned)max(vmax, -vmin));
+        // D in the float form at the candidates that reach the maximum (few: their table words are read again)
+        if (best != 0u) {
+          const double dm_ = (double)m, dq_ = (double)q;
+          const double rm_ = kCwRcp.v[m], rq_ = kCwRcp.v[q];
+#pragma unroll
+          for (int r = 0; r < RS; ++r) {
+            int xr[2];
+            if constexpr (KEEP) { xr[0] = xs[2 * r]; xr[1] = xs[2 * r + 1]; }
+            else {
+              const CntLdsU32 pw = (CntLdsU32)(uintptr_t)((r * 64 + lane < m) ? addr[r] - 4u : tb + 8u);
+              xr[0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, pw[0]), qm, 0, false);
+              xr[1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, pw[1]), qm, 0, false);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const bool hit = xr[e] == (int)best || xr[e] == -(int)best;
+              if (__ballot(hit) != 0ull) {
+                const bool have = r * 64 + lane < m;
+                const unsigned w = ((CntLdsU32)(uintptr_t)(have ? addr[r] - 4u : tb + 8u))[e];
+                const double d = fabs(hist_exact_quot((int)(w & 0xffffu), dm_, rm_) - hist_exact_quot((int)(w >> 16), dq_, rq_));
+                dmax = hit ? fmax(dmax, d) : dmax;
+              }
+            }
+          }
+        }
+      }
+    }
+
+    if (fit) {                                             // (wave-uniform)
+      const double dm = (double)m, dq = (double)q;
+      const double rm = kCwRcp.v[m], rq = kCwRcp.v[q];
+      dmax = wave_max_f64(dmax);
+      const unsigned MWS = cw_wave_sum_u32(mws);           // <= 2 m q
+      const unsigned long long TIE = 3ull * wave_sum_u64((unsigned long long)(sp2 + sp));      // sum_v t^3 - n = 3 sum (p^2 + p)
+      double mean_s = 0.0, m2_s = 0.0, mean_q = 0.0, m2_q = 0.0;
+      if constexpr (DTYPE == 0) {
+        const double s1 = wave_sum_f64(ms1), s2 = wave_sum_f64(ms2), t1 = wave_sum_f64(mq1), t2 = wave_sum_f64(mq2);
+        mean_s = (double)xs0 + s1 * rm; m2_s = s2 - s1 * s1 * rm;
+        mean_q = (double)xq0 + t1 * rq; m2_q = t2 - t1 * t1 * rq;
+      } else if constexpr (DTYPE == 1) {
+        // exact integer sums about the centre: |sum d| <= 4 095 * 1 024, sum d^2 <= 4 095 * 2^20 < 2^32
+        const double s1 = (double)(int)cw_wave_sum_u32((unsigned)is1), s2 = (double)cw_wave_sum_u32(is2);
+        const double t1 = (double)(int)cw_wave_sum_u32((unsigned)iq1), t2 = (double)cw_wave_sum_u32(iq2);
+        mean_s = ((double)c + s1 * rm) * 1e-3; m2_s = __fma_rn(dm, s2, -s1 * s1) * rm * 1e-6;
+        mean_q = ((double)c + t1 * rq) * 1e-3; m2_q = __fma_rn(dq, t2, -t1 * t1) * rq * 1e-6;
+      }
+      if (lane == 0) {
+        args.ks_num[pos] = best;
+        args.ks_d_ref[pos] = dmax;
+        args.mwu_s[pos] = swap ? 2ull * (unsigned long long)n0 * (unsigned long long)n1 - (unsigned long long)MWS : (unsigned long long)MWS;
+        args.tie[pos] = TIE;
+        if constexpr (DTYPE != 2) {
+          double* mo = args.moments + pos * 4;
+          mo[swap ? 2 : 0] = mean_s; mo[swap ? 3 : 1] = m2_s; mo[swap ? 0 : 2] = mean_q; mo[swap ? 1 : 3] = m2_q;
+        }
+        if (args.tied) args.tied[pos] = TIE != 0ull ? 1 : 0;
+      }
+    }
+    if (lane == 0) done[loff + it] = fit ? 1 : 0;
+  }
+}
+
+// every class the probe accepted, in one launch: a wave takes positions w, w + (waves), ... of the classes' lists laid end to end
+// (no tail per class: 15 classes of a ragged batch in 15 launches left the chip half idle)
+template <int DTYPE>
+__global__ __launch_bounds__(64 * kWavesPerBlock, 4)
+void rank_count_wide_kernel(CntWideArgs cw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds_cw[];
+  const RankStatsArgs& args = cw.rs;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned* tbl = lds_cw + wave * kCwWaveWords;
+  const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
+  const int nseg = cw.segs[0];
+  int64_t rot = 0;                                         // positions handed out so far, mod the number of waves
+  for (int sg = 0; sg < nseg; ++sg) {
+    const int cls = cw.segs[1 + sg];
+    if (cw.gates[cls] == 0) continue;
+    int64_t count = args.npos, loff = 0;
+    const int32_t* list = nullptr;
+    if (args.pos_list) { count = args.class_meta[cls]; loff = args.class_meta[kClassStride + cls]; list = args.pos_list + loff; }
+    int64_t start = wave_global - rot;
+    if (start < 0) start += nw;
+    rot = (rot + count) % nw;
+    switch (count_wide_rs_index(cls)) {
+      case 0: cw_segment<DTYPE, 1>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
+      case 1: cw_segment<DTYPE, 2>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
+      case 2: cw_segment<DTYPE, 4>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
+      case 3: cw_segment<DTYPE, 8>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
+      case 4: cw_segment<DTYPE, 16>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
+      default: break;
+    }
+  }
+}
+
+}  // namespace nmod

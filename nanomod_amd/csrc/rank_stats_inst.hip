@@ -8,6 +8,7 @@
 #include "rank_all.hpp"
 #include "rank_hist.hpp"
 #include "rank_count.hpp"
+#include "rank_count_wide.hpp"
 #include "rank_stats_launch.hpp"
 #include "build_info.hpp"
 
@@ -212,3 +213,67 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
 }
 
 }  // namespace nmod
+
+#if NMOD_INST_ALL
+#define NMOD_CW_PREP_NAME NMOD_CAT(NMOD_CAT(launch_count_wide_prepare_d, NMOD_INST_DTYPE), _a1)
+#define NMOD_CW_RUN_NAME NMOD_CAT(NMOD_CAT(launch_count_wide_run_d, NMOD_INST_DTYPE), _a1)
+namespace nmod {
+
+hipError_t NMOD_CW_PREP_NAME(const int* classes, int nclasses, hipStream_t stream, const RankStatsArgs& a, const CountWideWs& w) {
+  if (nclasses <= 0) return hipSuccess;
+  CntWideProbeArgs pa;
+  pa.sig0 = a.sig0; pa.sig1 = a.sig1; pa.off0 = a.off0; pa.off1 = a.off1; pa.stride0 = a.stride0; pa.stride1 = a.stride1; pa.npos = a.npos;
+  pa.pos_list = a.pos_list; pa.class_meta = a.class_meta; pa.nclasses = nclasses; pa.gate = w.gates; pa.segs = w.gates + kClassStride;
+  for (int i = 0; i < nclasses && i < kClassStride; ++i) { pa.cls[i] = classes[i]; pa.max_s[i] = 64 << count_wide_rs_index(classes[i]); }
+  hipError_t e = hipMemsetAsync(w.gates, 0, kClassStride * 4, stream);
+  if (e != hipSuccess) return e;
+#if NMOD_INST_DTYPE == 0
+  if (a.tied != nullptr) hipLaunchKernelGGL(cnt_wide_probe_kernel<2>, dim3((unsigned)nclasses), dim3(1024), 0, stream, pa);
+  else hipLaunchKernelGGL(cnt_wide_probe_kernel<0>, dim3((unsigned)nclasses), dim3(1024), 0, stream, pa);
+#else
+  hipLaunchKernelGGL(cnt_wide_probe_kernel<1>, dim3((unsigned)nclasses), dim3(1024), 0, stream, pa);
+#endif
+  const unsigned cb = (unsigned)std::min<int64_t>((a.npos + 255) / 256, 2048);
+  hipLaunchKernelGGL(cnt_worklist_init_kernel<DT>, dim3(cb ? cb : 1), dim3(256), 0, stream, a.npos, a.pos_list, a.class_meta, w.work_list, w.work_meta,
+                     (const int32_t*)w.gates, classes[0]);
+  return hipGetLastError();
+}
+
+hipError_t NMOD_CW_RUN_NAME(int num_cus, int64_t work_items, hipStream_t stream, const RankStatsArgs& a, const CountWideWs& w) {
+  typedef void (*CwFn)(CntWideArgs);
+#if NMOD_INST_DTYPE == 0
+  const bool int_keys = a.tied != nullptr;
+  CwFn fn = int_keys ? (CwFn)rank_count_wide_kernel<2> : (CwFn)rank_count_wide_kernel<0>;
+  const int slot = int_keys ? 1 : 0;
+#else
+  CwFn fn = (CwFn)rank_count_wide_kernel<1>;
+  const int slot = 0;
+#endif
+  static std::atomic<int> per_cu[64][2];
+  int dev = 0;
+  const bool cacheable = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+  const size_t lds = rank_count_wide_lds_bytes();
+  int pc = cacheable ? per_cu[dev][slot].load(std::memory_order_relaxed) : 0;
+  if (pc <= 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, 64 * kWavesPerBlock, lds);
+    if (e != hipSuccess) return e;
+    if (pc < 1) return hipErrorLaunchOutOfResources;
+    if (cacheable) per_cu[dev][slot].store(pc, std::memory_order_relaxed);
+  }
+  CntWideArgs ca;
+  ca.rs = a; ca.gates = w.gates; ca.segs = w.gates + kClassStride; ca.done = w.done;
+  int64_t blocks = std::min<int64_t>((work_items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)num_cus * pc);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream, ca);
+  CntCompactArgs cp;
+  cp.npos = a.npos; cp.pos_list = a.pos_list; cp.class_meta = a.class_meta; cp.gates = w.gates; cp.segs = w.gates + kClassStride; cp.done = w.done;
+  cp.work_list = w.work_list; cp.work_meta = w.work_meta;
+  const unsigned cb = (unsigned)std::min<int64_t>((work_items + 255) / 256, 1024);
+  hipLaunchKernelGGL(cnt_compact_kernel<DT>, dim3(cb ? cb : 1), dim3(256), 0, stream, cp);
+  return hipGetLastError();
+}
+
+}  // namespace nmod
+#endif

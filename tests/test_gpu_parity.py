@@ -492,6 +492,119 @@ def test_counting_form_edges(nm, dtype):
     H.assert_close_p(sub['t_p'][1:], got['t_p'][lo + 1:], 1e-9, 't_p')
 
 
+def _event_rows(rng, sizes0, sizes1, spread, shift_every=5):
+    """int16 event-like rows: a level per position, reads spread around it, group 2 shifted at every shift_every-th position"""
+    P = len(sizes0)
+    off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum(sizes0)
+    off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum(sizes1)
+    lev = rng.integers(-3000, 3001, P)
+    k0 = np.repeat(lev, sizes0) + np.rint(spread * rng.normal(0, 1, int(off0[-1]))).astype(np.int64)
+    sh = np.where(np.arange(P) % shift_every == 0, rng.integers(-300, 301, P), 0)
+    k1 = np.repeat(lev + sh, sizes1) + np.rint(spread * rng.normal(0, 1, int(off1[-1]))).astype(np.int64)
+    return np.clip(k0, -32767, 32767).astype(np.int16), off0, np.clip(k1, -32767, 32767).astype(np.int16), off1
+
+
+def _as_dtype(k, dtype):
+    if dtype == 'i16':
+        return k
+    x = k.astype(np.float64) / 1000.0
+    return x.astype(np.float32) if dtype == 'f32' else x
+
+
+@pytest.mark.parametrize('shape', ['skew', 'skew_rev', '500v500', '1000v1000', 'mixed', 'stride600'])
+@pytest.mark.parametrize('dtype', ['i16', 'f32', 'f64'])
+def test_count_wide_event_like_vs_oracle(nm, shape, dtype):
+    """the counting form for any coverage (rank_count_wide.hpp) against the oracle on event-like rows: skewed coverage either
+    way round (configs[4]: ~1 131 v ~57), both groups in the 512 and in the 1 024 class, every class at once, a fixed-stride
+    batch; all tests and KS-only (the latter never takes the form)"""
+    import oracle_c
+    L = nm._lib
+    rng = np.random.default_rng(zlib.crc32((shape + dtype).encode()))
+    P = 700
+    if shape in ('skew', 'skew_rev'):
+        a = rng.integers(600, 2400, P); b = rng.integers(20, 120, P)
+        a[:6] = (2048, 2049, 4095, 4095, 2047, 1025); b[:6] = (64, 65, 256, 1, 128, 129)
+        if shape == 'skew_rev':
+            a, b = b, a
+    elif shape == '500v500':
+        a = rng.integers(300, 513, P); b = rng.integers(300, 513, P); a[:3] = (512, 257, 512); b[:3] = (512, 512, 257)
+    elif shape == '1000v1000':
+        P = 300
+        a = rng.integers(600, 1025, P); b = rng.integers(600, 1025, P); a[:3] = (1024, 513, 1024); b[:3] = (1024, 1024, 513)
+    elif shape == 'mixed':
+        a = np.exp(rng.uniform(np.log(2), np.log(4000), P)).astype(np.int64); b = np.exp(rng.uniform(np.log(2), np.log(4000), P)).astype(np.int64)
+    else:
+        a = np.full(P, 600); b = np.full(P, 90)
+    k0, off0, k1, off1 = _event_rows(rng, a, b, 200 if shape != 'mixed' else 150)
+    rid = np.zeros(P, np.int32)
+    s0, s1 = _as_dtype(k0, dtype), _as_dtype(k1, dtype)
+    exp = oracle_c.detect_batch(s0 if dtype == 'f32' else k0, off0, s1 if dtype == 'f32' else k1, off1, rid, 2, 2.0, 'stouffer', tests=7)
+    kw = dict(stride0=600, stride1=90) if shape == 'stride600' else {}
+    got = nm.detect_host(s0, None if kw else off0, s1, None if kw else off1, rid, nb=2, weights_dif=2.0, method='stouffer', **kw)
+    H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
+    assert np.array_equal(got['status'], exp['status'])
+    got = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    assert np.array_equal(got['ks_d'], exp['ks_d'])
+    H.assert_close_p(got['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
+
+
+@pytest.mark.parametrize('dtype', ['i16', 'f32', 'f64'])
+def test_count_wide_edges(nm, dtype):
+    """rank_count_wide.hpp at its limits, inside classes its probe accepts: every sample equal (300 v 300: the tie limit sends it
+    back); one value 254 / 255 / 256 times in the larger group, 254 / 255 in the smaller; the smaller group's range 4 095 and
+    4 096; a sample of the larger group just inside / outside the window; the larger group of 4 095 / 4 096; a group constant;
+    keys at the ends of the int16 domain; a float32 sample off the grid in either group; a smaller group of one"""
+    import oracle_c
+    L = nm._lib
+    rng = np.random.default_rng(91)
+    rows0, rows1 = [], []
+
+    def add(a, b):
+        rows0.append(np.asarray(a, dtype=np.int64)); rows1.append(np.asarray(b, dtype=np.int64))
+
+    def ev(n, lev=0, s=200):
+        return lev + np.rint(s * rng.normal(0, 1, n)).astype(np.int64)
+    for _ in range(150):                                   # the bulk of two classes: (300..512) v (300..512) and (700..1000) v (30..64)
+        lev = int(rng.integers(-3000, 3000))
+        add(ev(int(rng.integers(300, 513)), lev), ev(int(rng.integers(300, 513)), lev))
+        lev = int(rng.integers(-3000, 3000))
+        add(ev(int(rng.integers(700, 1000)), lev), ev(int(rng.integers(30, 65)), lev))
+    edge_at = len(rows0)
+    add([500] * 300, [500] * 300)                                              # every sample equal
+    add(np.r_[[40] * 254, ev(200)], ev(300)); add(np.r_[[40] * 255, ev(200)], ev(300)); add(np.r_[[40] * 256, ev(200)], ev(300))
+    add(ev(400), np.r_[[-7] * 254, ev(100)]); add(ev(400), np.r_[[-7] * 255, ev(100)])
+    add(np.r_[[40] * 200, ev(200)], np.r_[[40] * 200, ev(200)])                # 400 copies over both groups
+    add(ev(800), np.r_[0, 4095, rng.integers(0, 4096, 50)]); add(ev(800), np.r_[0, 4096, rng.integers(0, 4096, 50)])
+    add(np.r_[ev(799, 0, 100), 1500], ev(40, 0, 100)); add(np.r_[ev(799, 0, 100), 3000], ev(40, 0, 100)); add(np.r_[ev(799, 0, 100), -3000], ev(40, 0, 100))
+    add(ev(4095), ev(60)); add(ev(60), ev(4095)); add(ev(4096), ev(60)); add(ev(60), ev(4096))
+    add([7] * 900, ev(50)); add(ev(900), [7] * 50); add(ev(900), [7])
+    add(32767 - rng.integers(0, 900, 900), 32767 - rng.integers(0, 900, 40)); add(-32767 + rng.integers(0, 900, 900), -32767 + rng.integers(0, 900, 40))
+    add(np.arange(500), np.arange(500) + 1)
+    off_grid_at = len(rows0)
+    add(ev(900), ev(50)); add(ev(900), ev(50))
+    P = len(rows0)
+    off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum([len(r) for r in rows0])
+    off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum([len(r) for r in rows1])
+    k0 = np.concatenate(rows0).astype(np.int16); k1 = np.concatenate(rows1).astype(np.int16)
+    rid = np.zeros(P, np.int32)
+    s0, s1 = _as_dtype(k0, dtype), _as_dtype(k1, dtype)
+    if dtype == 'f32':
+        s0[off0[off_grid_at] + 700] = np.nextafter(s0[off0[off_grid_at] + 700], np.float32(9))
+        s1[off1[off_grid_at + 1] + 3] = np.nextafter(s1[off1[off_grid_at + 1] + 3], np.float32(-9))
+    exp = oracle_c.detect_batch(s0 if dtype == 'f32' else k0, off0, s1 if dtype == 'f32' else k1, off1, rid, 0, 2.0, 'fisher', tests=7)
+    got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher')
+    ident = (exp['status'] & L.STATUS_MWU_ALL_IDENTICAL) != 0
+    assert ident[edge_at] and ident.sum() == 1 and np.array_equal(got['status'], exp['status'])
+    for d in (got, exp):
+        d['mwu_u'][ident] = 0.0; d['mwu_p'][ident] = 0.0
+    H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
+    lo = edge_at                                               # the edge positions alone: whatever the probes decide, the same numbers
+    sub = nm.detect_host(s0[off0[lo]:], off0[lo:] - off0[lo], s1[off1[lo]:], off1[lo:] - off1[lo], rid[lo:], nb=0, weights_dif=2.0, method='fisher')
+    for k in ('mwu_p', 'ks_d', 'ks_p'):
+        assert np.array_equal(sub[k][1:], got[k][lo + 1:], equal_nan=True), k
+    H.assert_close_p(sub['t_p'][1:], got['t_p'][lo + 1:], 1e-9, 't_p')
+
+
 # general (64 lanes per group) and packed (two positions per wave) kernels, every capacity class
 @pytest.mark.parametrize('sizes', [(5, 64, 5, 64), (65, 128, 3, 30), (65, 128, 65, 128), (129, 256, 129, 256),
                                    (100, 128, 129, 220), (257, 512, 257, 512), (300, 512, 20, 256),

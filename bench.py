@@ -1070,11 +1070,13 @@ def main():
 
     # ---- the other BASELINE configurations at their per-GPU size, a few timed steps each (configs[3]: one GPU's share of chr20;
     # configs[4]: the ragged stress, KS + Stouffer and all three tests): every BASELINE config gets a number in the default run
-    def preset_leg(name, leg_all, steps):
+    def preset_leg(name, leg_all, steps, spread=0, i16=False, positions=None):
         pz = PRESETS[name]
         csr_ = pz['layout'] == 'csr'
-        P, m0, m1 = pz['positions'], pz['n0'], pz['n1']
+        P, m0, m1 = positions or pz['positions'], pz['n0'], pz['n1']
         leg_method = 'fisher' if leg_all else 'stouffer'
+        tdt = torch.int16 if i16 else torch.float32
+        shift_m = int(round(PLANT_SHIFT * 1000))
         det_x = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=leg_method, tests=L.TEST_ALL if leg_all else L.TEST_KS)
         rid_x = torch.zeros(P, dtype=torch.int32, device=dev)
         sig, hoff, doff = [None, None], [None, None], [None, None]
@@ -1084,11 +1086,17 @@ def main():
                 hoff[g] = np.zeros(P + 1, np.int64)
                 np.cumsum(sz, out=hoff[g][1:])
                 doff[g] = torch.from_numpy(hoff[g]).to(dev)
-                sig[g] = torch.empty(int(hoff[g][-1]), dtype=torch.float32, device=dev)
-                det_x.synth_fill_csr(sig[g], SEED, 0, doff[g], g, PLANT_PERIOD, PLANT_SHIFT)
+                sig[g] = torch.empty(int(hoff[g][-1]), dtype=tdt, device=dev)
+                if spread:
+                    det_x.synth_fill_events(sig[g], SEED, 0, P, g, n_per_pos=0, off=doff[g], plant_period=PLANT_PERIOD, plant_shift_milli=shift_m, spread_milli=spread)
+                else:
+                    det_x.synth_fill_csr(sig[g], SEED, 0, doff[g], g, PLANT_PERIOD, PLANT_SHIFT)
             else:
-                sig[g] = torch.empty(P * (m0, m1)[g], dtype=torch.float32, device=dev)
-                det_x.synth_fill(sig[g], SEED, 0, P, g, (m0, m1)[g], PLANT_PERIOD, PLANT_SHIFT)
+                sig[g] = torch.empty(P * (m0, m1)[g], dtype=tdt, device=dev)
+                if spread:
+                    det_x.synth_fill_events(sig[g], SEED, 0, P, g, n_per_pos=(m0, m1)[g], plant_period=PLANT_PERIOD, plant_shift_milli=shift_m, spread_milli=spread)
+                else:
+                    det_x.synth_fill(sig[g], SEED, 0, P, g, (m0, m1)[g], PLANT_PERIOD, PLANT_SHIFT)
         outs = det_x.alloc_outputs(P)
 
         def run_once():
@@ -1116,13 +1124,14 @@ def main():
         det_x.timer = None
         k1, kn = tm.read(L.KERNEL_RANK_STATS); k2, _ = tm.read(L.KERNEL_FINALIZE); k3, _ = tm.read(L.KERNEL_COMBINE)
         mean0_, mean1_ = sig[0].numel() / P, sig[1].numel() / P
-        algo_leg = algorithmic_bytes(mean0_, mean1_, 4, 4 if leg_all else 2, csr_)
+        algo_leg = algorithmic_bytes(mean0_, mean1_, 2 if i16 else 4, 4 if leg_all else 2, csr_)
         gbs = algo_leg * P / ((k1 + k2 + k3) / steps * 1e-3) / 1e9
         if not v['ok']:
             verify['ok'] = False
             print('bench.py: verification of the %s leg FAILED: %r' % (name, v), file=sys.stderr)
         return {'value': P * steps / el, 'unit': 'positions/s', 'steps': steps, 'ms_per_step': el / steps * 1e3, 'positions': P,
-                'workload': '%s, %s, float32' % (pz['name'], 'KS + MWU + Welch-t + Fisher' if leg_all else 'KS + weighted Stouffer'),
+                'workload': '%s, %s, %s%s' % (pz['name'], 'KS + MWU + Welch-t + Fisher' if leg_all else 'KS + weighted Stouffer', 'int16 milli-units' if i16 else 'float32',
+                                              (', event-like rows (sigma = %.1f)' % (spread / 1000)) if spread else ''),
                 'mean_reads': [mean0_, mean1_], 'k1_ms_per_step': k1 / steps, 'algorithmic_bytes_per_position': algo_leg,
                 'achieved_GBps': gbs, 'roofline_frac': gbs / HBM_PEAK_GBS, 'verify': v}
 
@@ -1158,6 +1167,15 @@ def main():
         torch.cuda.empty_cache()
         side['ragged_all_tests'] = preset_leg('ragged', True, 3)
         torch.cuda.empty_cache()
+        # the same shapes on event-like rows (sigma = 0.2), all three tests — what getKStest computes on stored events at real, ragged
+        # coverage: the counting form for any coverage (rank_count_wide_kernel) where the device-side probe accepts a class
+        if 'real_spread' in legs:
+            ev = {'note': 'nmod_synth_fill_events, sigma = 0.2, all three tests + Fisher; the ragged preset (~1 131 v ~57) and the chr20 shape (500 v 500)'}
+            for nm_, kw in (('ragged_i16', dict(name='ragged', i16=True)), ('ragged_f32', dict(name='ragged', i16=False)),
+                            ('chr20_i16', dict(name='chr20', i16=True)), ('chr20_f32', dict(name='chr20', i16=False))):
+                ev[nm_] = preset_leg(kw['name'], True, 3, spread=200, i16=kw['i16'])
+                torch.cuda.empty_cache()
+            side['real_spread_presets'] = ev
 
     line = None
     if rank == 0:
@@ -1177,8 +1195,8 @@ def main():
         prm = L.make_params(dtype=L.DTYPE_F32 if args.dtype == 'f32' else L.DTYPE_I16_MILLI, tests=tests,
                             method=L.METHOD_BY_NAME[method])
         import ctypes
-        kbuf = ctypes.create_string_buffer(96)
-        L.check(L.load().nmod_describe_dispatch(ctypes.byref(prm), n0, n1, kbuf, 96), 'nmod_describe_dispatch')
+        kbuf = ctypes.create_string_buffer(128)
+        L.check(L.load().nmod_describe_dispatch(ctypes.byref(prm), n0, n1, kbuf, 128), 'nmod_describe_dispatch')
         shape = 'ragged' if csr else '%dv%d' % (n0, n1)
         key = '%s_%s_%s_%d%s' % ('all' if all_tests else 'ks', args.dtype, shape, int(pos_per_launch), ('_realties' if args.ties == 'real' else '') + ('_spread%d' % args.spread if args.spread else '') + ('_rationald' if rational_d else ''))
         rec = profile_record(L.LIB_PATH, key) or {}
@@ -1228,7 +1246,7 @@ def main():
                          'definition': 'SURVEY.md 8(d) bytes/position x positions per launch / HIP-event time of K1 + K2 + K3 of that launch',
                          'algorithmic_bytes_per_position': algo, 'positions_per_launch': pos_per_launch, 'profile_key': key,
                          'path_avg_ms': path_per_block_s * 1e3,
-                         'kernel': kbuf.value.decode() if not csr else 'size-class launches of ks_rank_kernel / rank_hist_kernel (ragged)',
+                         'kernel': kbuf.value.decode() if not csr else 'size-class launches (ragged); at the median sizes: ' + kbuf.value.decode(),
                          'kernel_avg_ms': k1_per_block_s * 1e3, 'launches_timed': k1_n,
                          'dominant_kernel_only': {'bytes_per_position': k1_bytes, 'achieved': k1_achieved,
                                                   'frac': k1_achieved / HBM_PEAK_GBS,

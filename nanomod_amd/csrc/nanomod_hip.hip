@@ -529,13 +529,11 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     return prm->dtype == NMOD_DTYPE_F32 ? launch_count_wide_run_d0_a1(num_cus, npos, stream, ra, cww)
                                         : launch_count_wide_run_d1_a1(num_cus, npos, stream, ra, cww);
   };
-  // a class's sorting form, over the work list when the counting form was in play
+  // a class's sorting form; where the counting form was in play (its gate is set, on the device) it walks the work list
   auto launch_class = [&](int cls, int64_t work, bool counted) -> hipError_t {
-    if (!counted) return launch(cls, work);
-    const int32_t* keep_list = ra.pos_list; const int32_t* keep_meta = ra.class_meta;
-    ra.pos_list = ws.work_list; ra.class_meta = ws.work_meta;
+    ra.alt_gates = counted ? cww.gates : nullptr; ra.alt_list = ws.work_list; ra.alt_meta = ws.work_meta;
     const hipError_t e = launch(cls, work);
-    ra.pos_list = keep_list; ra.class_meta = keep_meta;
+    ra.alt_gates = nullptr;
     return e;
   };
 
@@ -1032,8 +1030,11 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
   const int c0 = size_class_of(n0), c1 = size_class_of(n1);
   // the same decisions classify_kernel / detect_device take (NMOD_DTYPE_F64: the narrower dtype is a property of the data)
   const bool big = all ? (c0 >= kNumSizeClasses || c1 >= kNumSizeClasses) : (std::min(c0, c1) >= kNumSizeClasses);
+  // (all tests, smaller group <= 1 024, larger <= 4 095, not the classes of eight or four positions per wave: the counting form for
+  // any coverage when the device-side probe finds the class event-like — a property of the data; the sorting form takes the rest)
+  const char* kd = prm->dtype == NMOD_DTYPE_F64 ? "f32 keys" : dt;
   if (big && all && std::min(n0, n1) <= 256 && std::max(n0, n1) <= kWideBigMaxQ) {
-    snprintf(buf, buflen, "rank_hist_kernel<%d,64,%s,wide>", 1 << std::min(c0, c1), dt); return NMOD_OK;
+    snprintf(buf, buflen, "rank_count_wide_kernel<%s> (event-like rows) | rank_hist_kernel<%d,64,%s,wide>", kd, 1 << std::min(c0, c1), dt); return NMOD_OK;
   }
   if (big && all && std::min(n0, n1) <= kBigHistMaxS && std::max(n0, n1) <= kBigHistMaxQ) { snprintf(buf, buflen, "big_hist_kernel<%s>", dt); return NMOD_OK; }
   if (big) { snprintf(buf, buflen, "big_rank_kernel<%s>", dt); return NMOD_OK; }
@@ -1050,11 +1051,14 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
     // capacity-256 positions: the counting form when the device-side probe finds the batch event-like (a property of the data)
     if (cm == 2 && prm->dtype != NMOD_DTYPE_F64) snprintf(buf, buflen, "rank_count_kernel<%s> (event-like rows) | rank_hist_kernel<%d,%d,%s>", dt, R, LG, dt);
     else if (cm == 2) snprintf(buf, buflen, "rank_count_kernel<f32 keys> (event-like rows) | rank_hist_kernel<%d,%d,%s>", R, LG, dt);
+    else if (count_wide_rs_index(cls) >= 0) snprintf(buf, buflen, "rank_count_wide_kernel<%s> (event-like rows) | rank_hist_kernel<%d,%d,%s>", kd, R, LG, dt);
     else snprintf(buf, buflen, "rank_hist_kernel<%d,%d,%s>", R, LG, dt);
   } else if (wide_class(cls)) {
-    snprintf(buf, buflen, "rank_hist_kernel<%d,64,%s,wide>", 1 << std::min(c0, c1), dt);
+    if (count_wide_rs_index(cls) >= 0) snprintf(buf, buflen, "rank_count_wide_kernel<%s> (event-like rows) | rank_hist_kernel<%d,64,%s,wide>", kd, 1 << std::min(c0, c1), dt);
+    else snprintf(buf, buflen, "rank_hist_kernel<%d,64,%s,wide>", 1 << std::min(c0, c1), dt);
   } else {
-    snprintf(buf, buflen, "rank_pair_kernel<%d,%d,%s>", 1 << c0, 1 << c1, dt);
+    if (count_wide_rs_index(cls) >= 0) snprintf(buf, buflen, "rank_count_wide_kernel<%s> (event-like rows) | rank_pair_kernel<%d,%d,%s>", kd, 1 << c0, 1 << c1, dt);
+    else snprintf(buf, buflen, "rank_pair_kernel<%d,%d,%s>", 1 << c0, 1 << c1, dt);
   }
   return NMOD_OK;
 }

@@ -46,6 +46,7 @@ struct CntWideProbeArgs {
   int32_t nclasses; int32_t cls[kClassStride]; int32_t max_s[kClassStride];      // block b probes class cls[b]
   int32_t* gate;                                                 // [kClassStride]: gate[class]
   int32_t* segs;                                                 // [0] nclasses, [1 + b] cls[b]: the list the later kernels walk
+  int32_t* work_meta;                                            // [class] = 0, [kClassStride + class] = the class list's offset: the work lists start empty
 };
 template <int DTYPE>
 __global__ __launch_bounds__(1024) void cnt_wide_probe_kernel(CntWideProbeArgs a) {
@@ -90,29 +91,17 @@ __global__ __launch_bounds__(1024) void cnt_wide_probe_kernel(CntWideProbeArgs a
   if (threadIdx.x == 0) {
     a.gate[cid] = (seen > 0 && fits * 8 >= seen * 7) ? 1 : 0;
     a.segs[1 + blockIdx.x] = cid;
+    a.work_meta[cid] = 0; a.work_meta[kClassStride + cid] = a.pos_list ? a.class_meta[kClassStride + cid] : 0;
     if (blockIdx.x == 0) a.segs[0] = a.nclasses;
   }
 }
 
-// ---- the work list of the sorting form that follows: every entry of the class when the gate is clear, else the entries
-// rank_count_wide_kernel left (done == 0).  work_list / work_meta have the layout of pos_list / class_meta.
+// ---- the work list of the sorting form that follows, for a class whose gate is set: the entries rank_count_wide_kernel left
+// (done == 0).  work_list / work_meta have the layout of pos_list / class_meta; a class whose gate is clear keeps its own list.
 struct CntCompactArgs {
   int64_t npos; const int32_t* pos_list; const int32_t* class_meta;
   const int32_t* gates; const int32_t* segs; const uint8_t* done; int32_t* work_list; int32_t* work_meta;       // work_meta[c] = count, [kClassStride + c] = offset
 };
-// (the work lists start as the class lists themselves: cnt_worklist_init_kernel; a class whose gate is set gets its list rebuilt)
-template <int DT>
-__global__ __launch_bounds__(256) void cnt_worklist_init_kernel(int64_t npos, const int32_t* pos_list, const int32_t* class_meta, int32_t* work_list,
-                                                               int32_t* work_meta, const int32_t* gate, int32_t single_class) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (pos_list) {
-    for (int64_t i = t; i < npos; i += (int64_t)gridDim.x * 256) work_list[i] = pos_list[i];
-    if (t < kClassStride) { work_meta[t] = gate[t] ? 0 : class_meta[t]; work_meta[kClassStride + t] = class_meta[kClassStride + t]; }
-  } else {                                                       // fixed-stride batch, one class, no list: the identity
-    if (gate[single_class] == 0) for (int64_t i = t; i < npos; i += (int64_t)gridDim.x * 256) work_list[i] = (int32_t)i;
-    if (t == 0) { work_meta[single_class] = gate[single_class] ? 0 : (int32_t)npos; work_meta[kClassStride + single_class] = 0; }
-  }
-}
 template <int DT>
 __global__ __launch_bounds__(256) void cnt_compact_kernel(CntCompactArgs a) {
   const int lane = threadIdx.x & 63;
@@ -186,43 +175,94 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
   const CntS2 sone2 = {1, 1};
   const CntU2 hi1 = {0, 1};
 
-  // (the next position's list entry and offsets are requested while this one is counted: two dependent loads off the path)
+  // Headers (list entry, row offsets, sizes): 64 positions at a time, one per lane, by vector loads; a position's header is read
+  // out of its lane.  (As scalar loads per position they were two dependent memory latencies, and their counter is the LDS's:
+  // the first wait for a returning ds_add waited for them too.)
   struct Hdr { int64_t pos, o0, o1; int n0, n1; };
-  auto load_hdr = [&](int64_t it) -> Hdr {
-    Hdr h; h.pos = 0; h.o0 = h.o1 = 0; h.n0 = h.n1 = 0;
-    if (it < count) {
-      h.pos = list ? (int64_t)list[it] : it;
-      if (args.stride0 > 0) { h.o0 = h.pos * args.stride0; h.n0 = (int)args.stride0; } else { h.o0 = args.off0[h.pos]; h.n0 = (int)(args.off0[h.pos + 1] - h.o0); }
-      if (args.stride1 > 0) { h.o1 = h.pos * args.stride1; h.n1 = (int)args.stride1; } else { h.o1 = args.off1[h.pos]; h.n1 = (int)(args.off1[h.pos + 1] - h.o1); }
+  int hb_pos = 0, hb_n0 = 0, hb_n1 = 0; int64_t hb_o0 = 0, hb_o1 = 0;
+  auto load_batch = [&](int64_t it0) {                     // lane j: position it0 + j * wave_stride of the list
+    const int64_t itj = it0 + (int64_t)lane * wave_stride;
+    hb_pos = 0; hb_n0 = hb_n1 = 0; hb_o0 = hb_o1 = 0;
+    if (itj < count) {
+      const int64_t p = list ? (int64_t)list[itj] : itj;
+      hb_pos = (int)p;
+      if (args.stride0 > 0) { hb_o0 = p * args.stride0; hb_n0 = (int)args.stride0; } else { hb_o0 = args.off0[p]; hb_n0 = (int)(args.off0[p + 1] - hb_o0); }
+      if (args.stride1 > 0) { hb_o1 = p * args.stride1; hb_n1 = (int)args.stride1; } else { hb_o1 = args.off1[p]; hb_n1 = (int)(args.off1[p + 1] - hb_o1); }
     }
+  };
+  auto rl64 = [&](int64_t v, int j) -> int64_t {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, j);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), j);
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+  };
+  int hb_j = 0;                                            // lane of the header read next
+  auto load_hdr = [&](int64_t it) -> Hdr {                 // called with it = start, start + wave_stride, ... in order
+    if (hb_j == 0) load_batch(it);
+    Hdr h;
+    h.pos = (int64_t)__builtin_amdgcn_readlane(hb_pos, hb_j); h.n0 = __builtin_amdgcn_readlane(hb_n0, hb_j); h.n1 = __builtin_amdgcn_readlane(hb_n1, hb_j);
+    h.o0 = rl64(hb_o0, hb_j); h.o1 = rl64(hb_o1, hb_j);
+    hb_j = (hb_j + 1) & 63;
     return h;
   };
+  // Rows: requested a position ahead — after this position's Q has been streamed, while its table is scanned and its sums are
+  // reduced: up to PF chunks of 256 samples of Q (four per lane), the <= 255 that remain one per lane, S one per lane and register.
+  // (With one chunk in flight and the requests at the top the waves waited a memory latency per 50 instructions.)  A sample that
+  // does not exist is read as the row's last one and masked.
+  constexpr int PF = (RS == 16) ? 2 : 4;
+  constexpr bool PS = RS <= 8;                             // S a position ahead as well (RS = 16: sixteen more live registers spill)
+  struct Rows { Q1Raw s[RS]; Q4Raw qa[PF]; Q1Raw rt[4]; Q1Raw q0; };
+  auto load_at = [&](const void* row, unsigned byte_off, auto tag) { return ks_global_load<decltype(tag)>(reinterpret_cast<const char*>(row) + byte_off); };
+  // (every load is issued whatever the position looks like — a chunk or a position that does not exist reads the 16-byte dummy:
+  // a conditional load makes the loaded registers phi nodes, and the copies the compiler places for them wait for the data
+  // right where the request was meant to run ahead)
+  auto request = [&](const Hdr& h, bool live, Rows& R, bool with_q, bool with_s) {
+    const bool sw = h.n1 < h.n0;
+    const int mr = sw ? h.n1 : h.n0, qr = sw ? h.n0 : h.n1;
+    const bool ok = live && mr >= 1 && mr <= 64 * RS && qr <= kCwMaxQ;       // (wave-uniform; otherwise the position is left to the sorting form)
+    const Q1Raw* dummy = reinterpret_cast<const Q1Raw*>(kKsBig4);
+    const Q1Raw* row_s = ok ? reinterpret_cast<const Q1Raw*>(sw ? args.sig1 : args.sig0) + (sw ? h.o1 : h.o0) : dummy;
+    const Q1Raw* row_q = ok ? reinterpret_cast<const Q1Raw*>(sw ? args.sig0 : args.sig1) + (sw ? h.o0 : h.o1) : dummy;
+    const int m_ = ok ? mr : 1, q_ = ok ? qr : 1;
+    const int full_ = q_ / 256;
+    if (with_q) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        const bool v = j < full_;
+        R.qa[j] = load_at(v ? row_q + j * 256 : dummy, v ? (unsigned)(4 * lane) * (unsigned)sizeof(Q1Raw) : 0u, Q4Raw());
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) R.rt[j] = load_at(row_q, (unsigned)min(full_ * 256 + j * 64 + lane, q_ - 1) * (unsigned)sizeof(Q1Raw), Q1Raw());
+      if constexpr (RDT == 0) R.q0 = load_at(row_q, 0u, Q1Raw());
+    }
+    if (with_s) {
+#pragma unroll
+      for (int r = 0; r < RS; ++r) R.s[r] = load_at(row_s, (unsigned)min(r * 64 + lane, m_ - 1) * (unsigned)sizeof(Q1Raw), Q1Raw());
+    }
+  };
   Hdr nxt = load_hdr(start);
+  Rows rows;
+#pragma unroll
+  for (int r = 0; r < RS; ++r) rows.s[r] = Q1Raw(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rows.rt[j] = Q1Raw(0);
+  rows.q0 = Q1Raw(0);
+  request(nxt, start < count, rows, true, PS);
   for (int64_t it = start; it < count; it += wave_stride) {
     const Hdr cur = nxt;
     nxt = load_hdr(it + wave_stride);
-    const int64_t pos = cur.pos, o0 = cur.o0, o1 = cur.o1;
+    const int64_t pos = cur.pos;
     const int n0 = cur.n0, n1 = cur.n1;
     const bool swap = n1 < n0;                             // S = the smaller group (ties: group 1)
     const int m = swap ? n1 : n0, q = swap ? n0 : n1;
-    const void* sig_s = swap ? args.sig1 : args.sig0; const void* sig_q = swap ? args.sig0 : args.sig1;
-    const int64_t off_s = swap ? o1 : o0, off_q = swap ? o0 : o1;
+    const Q1Raw* rowq = reinterpret_cast<const Q1Raw*>(swap ? args.sig0 : args.sig1) + (swap ? cur.o0 : cur.o1);
     bool fit = m >= 1 && m <= 64 * RS && q <= kCwMaxQ;     // (wave-uniform)
     const int mm = fit ? m : 0, qq = fit ? q : 0;
-    // Q's rows are requested before anything else is done: up to PF chunks of 256 samples (four per lane) and the <= 255 that
-    // remain one per lane; with one chunk in flight the loop waited a memory latency per 50 instructions
-    constexpr int PF = (RDT == 0 && RS == 16) ? 2 : 4;
+    const double rcp_m = kCwRcp.v[mm], rcp_q = kCwRcp.v[qq];   // (requested here, used at the end: scalar loads)
     const int full = qq / 256;
     const int tail = (qq - full * 256 + 63) / 64;
-    const Q1Raw* rowq = reinterpret_cast<const Q1Raw*>(sig_q) + off_q;
-    Q4Raw qa[PF];
-    Q1Raw rt[4];
-#pragma unroll
-    for (int j = 0; j < PF; ++j) qa[j] = ks_global_load<Q4Raw>(j < full ? rowq + j * 256 + 4 * lane : reinterpret_cast<const Q1Raw*>(kKsBig4));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rt[j] = ks_global_load<Q1Raw>(full * 256 + j * 64 + lane < qq ? rowq + full * 256 + j * 64 + lane : reinterpret_cast<const Q1Raw*>(kKsBig4));
     float xq0 = 0.0f;
-    if constexpr (RDT == 0) xq0 = (float)ks_global_load<Q1Raw>(qq > 0 ? rowq : reinterpret_cast<const Q1Raw*>(kKsBig4));
+    if constexpr (RDT == 0) xq0 = (float)rows.q0;
+    if constexpr (!PS) request(cur, true, rows, false, true);
 
     // ---- S: sample r * 64 + lane in register r.  Keys, float32 moments, range.
     int ks[RS];
@@ -230,12 +270,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
     double ms1 = 0.0, ms2 = 0.0;                           // float32 rows: shifted moment sums
     float xs0 = 0.0f;
     {
-      Q1Raw raw[RS];
-#pragma unroll
-      for (int r = 0; r < RS; ++r) {
-        const int idx = r * 64 + lane;
-        raw[r] = ks_global_load<Q1Raw>(idx < mm ? reinterpret_cast<const Q1Raw*>(sig_s) + off_s + idx : reinterpret_cast<const Q1Raw*>(kKsBig4));
-      }
+      Q1Raw (&raw)[RS] = rows.s;
       if constexpr (RDT == 0) {
         xs0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)raw[0])));
         const double K = (double)xs0;
@@ -279,32 +314,41 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
     double mq1 = 0.0, mq2 = 0.0;
     unsigned mws = 0u; int vmax = 0, vmin = 0; unsigned best = 0u;
     double dmax = 0.0;
-    unsigned addr[RS];
+    constexpr bool KEEPA = RS <= 8;                        // the samples' table addresses stay in registers (RS = 16: recomputed from the keys)
+    unsigned addr[KEEPA ? RS : 1];
     const CntS2 qm = {(short)q, (short)-m};
+    const int nch = 1 << (lgE - 2);                      // 16-byte chunks of a lane block: 2, 4, 8
+    uint4* blk = reinterpret_cast<uint4*>(__builtin_assume_aligned(reinterpret_cast<char*>(tbl) + lane * ((4 << lgE) + 16) + 16, 16));
+    auto entry = [&](unsigned u) -> unsigned { return tbE + (u << 2) + ((u >> lgE) << 4); };
+    auto below_of = [&](int r, bool have) -> unsigned {      // LDS address of the word just below sample r's own (no sample: two zero words of block 0's pad)
+      if constexpr (KEEPA) return have ? addr[r] - 4u : tb + 8u;
+      else return have ? entry((unsigned)(ks[r] - base)) - 4u : tb + 8u;
+    };
     if (fit) {
-      const int nch = 1 << (lgE - 2);                      // 16-byte chunks of a lane block: 2, 4, 8
-      uint4* blk = reinterpret_cast<uint4*>(__builtin_assume_aligned(reinterpret_cast<char*>(tbl) + lane * ((4 << lgE) + 16) + 16, 16));
-      auto entry = [&](unsigned u) -> unsigned { return tbE + (u << 2) + ((u >> lgE) << 4); };
       {                                                    // ---- clear
         unsigned z = 0u;
         asm volatile("" : "+v"(z));
 #pragma unroll
         for (int i = 0; i < 9; ++i) if (i <= nch) blk[i - 1] = make_uint4(z, z, z, z);
+        *(CntLdsU32)(uintptr_t)entry((unsigned)W) = z;     // the dump entry
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
-      auto arrive = [&](unsigned a, unsigned inc, bool have) {     // count one sample; its arrival number among the copies of its value
-        const unsigned old = __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)a, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        unsigned p = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, old), one2, 0u, false);
-        p = have ? p : 0u;
+      // count one sample; the word that comes back holds the copies of its value counted before it (both groups): its arrival
+      // number p.  A sample that does not exist adds nothing to the dump entry, which stays 0 in a position that fits.
+      // (Using the word four arrivals later, when it has long returned, changed nothing: measured, profiles/r5_count_wide_ab.txt.)
+      auto arrive = [&](unsigned a, unsigned inc, bool have) {
+        const unsigned old = __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)a, have ? inc : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const unsigned p = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, old), one2, 0u, false);
         sp2 = __umul24(p, p) + sp2; sp += p;
       };
       // ---- S
 #pragma unroll
       for (int r = 0; r < RS; ++r) {
         const bool have = r * 64 + lane < m;
-        addr[r] = entry(have ? (unsigned)(ks[r] - base) : (unsigned)W);      // (no sample: the dump entry, one past the window)
-        arrive(addr[r], 1u, have);
+        const unsigned a_ = entry(have ? (unsigned)(ks[r] - base) : (unsigned)W);      // (no sample: the dump entry, one past the window)
+        if constexpr (KEEPA) addr[r] = a_;
+        arrive(a_, 1u, have);
         if constexpr (RDT == 1) { const int d = have ? ks[r] - c : 0; is1 += d; is2 += (unsigned)__mul24(d, d); }
       }
       // ---- Q, streamed once
@@ -319,7 +363,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         u = have ? u : (unsigned)W;
         arrive(entry(u), 0x10000u, have);
       };
-      auto q_pair16 = [&](unsigned kk) {                   // two int16 samples of a full chunk
+      auto q_pair16 = [&](unsigned kk) {        // two int16 samples of a full chunk
         const CntS2 d2 = __builtin_bit_cast(CntS2, kk) - __builtin_bit_cast(CntS2, cc);
         iq1 = __builtin_amdgcn_sdot2(d2, sone2, iq1, false);
         iq2 = (unsigned)__builtin_amdgcn_sdot2(d2, d2, (int)iq2, false);
@@ -334,10 +378,10 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
       for (int ch0 = 0; ch0 < full; ch0 += PF) {
         Q4Raw qb[PF];
 #pragma unroll
-        for (int j = 0; j < PF; ++j) qb[j] = qa[j];
+        for (int j = 0; j < PF; ++j) qb[j] = rows.qa[j];
         if (ch0 + PF < full) {                             // (wave-uniform)
 #pragma unroll
-          for (int j = 0; j < PF; ++j) qa[j] = ks_global_load<Q4Raw>(ch0 + PF + j < full ? rowq + (ch0 + PF + j) * 256 + 4 * lane : reinterpret_cast<const Q1Raw*>(kKsBig4));
+          for (int j = 0; j < PF; ++j) if (ch0 + PF + j < full) rows.qa[j] = load_at(rowq, (unsigned)((ch0 + PF + j) * 256 + 4 * lane) * (unsigned)sizeof(Q1Raw), Q4Raw());
         }
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
@@ -355,7 +399,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
       for (int j = 0; j < 4; ++j) {
         if (j < tail) {                                    // (wave-uniform)
           const bool have = full * 256 + j * 64 + lane < q;
-          const Q1Raw cur1 = rt[j];
+          const Q1Raw cur1 = rows.rt[j];
           if constexpr (RDT == 0) {
             q_f32(have ? (float)cur1 : xq0, have);
           } else {
@@ -375,7 +419,9 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-
+    }
+    request(nxt, it + wave_stride < count, rows, true, PS);       // the next position's rows: in flight while this one's table is scanned
+    if (fit) {
       // ---- prefix sums in place (both halves at once: the S half stays below 2^16); the pad's last word = the sum below the block
       unsigned tot = 0u;
 #pragma unroll
@@ -406,7 +452,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
           const bool have = r * 64 + lane < m;
-          const CntLdsU32 pw = (CntLdsU32)(uintptr_t)(have ? addr[r] - 4u : tb + 8u);      // (no sample: two zero words of block 0's pad)
+          const CntLdsU32 pw = (CntLdsU32)(uintptr_t)below_of(r, have);
           const unsigned w0 = pw[0], w1 = pw[1];
           mws = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, w0), hi1, mws, false);      // #{q < s} + #{q <= s}
           mws = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, w1), hi1, mws, false);
@@ -419,13 +465,13 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         // D in the float form at the candidates that reach the maximum (few: their table words are read again)
         if (best != 0u) {
           const double dm_ = (double)m, dq_ = (double)q;
-          const double rm_ = kCwRcp.v[m], rq_ = kCwRcp.v[q];
+          const double rm_ = rcp_m, rq_ = rcp_q;
 #pragma unroll
           for (int r = 0; r < RS; ++r) {
             int xr[2];
             if constexpr (KEEP) { xr[0] = xs[2 * r]; xr[1] = xs[2 * r + 1]; }
             else {
-              const CntLdsU32 pw = (CntLdsU32)(uintptr_t)((r * 64 + lane < m) ? addr[r] - 4u : tb + 8u);
+              const CntLdsU32 pw = (CntLdsU32)(uintptr_t)below_of(r, r * 64 + lane < m);
               xr[0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, pw[0]), qm, 0, false);
               xr[1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, pw[1]), qm, 0, false);
             }
@@ -434,7 +480,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
               const bool hit = xr[e] == (int)best || xr[e] == -(int)best;
               if (__ballot(hit) != 0ull) {
                 const bool have = r * 64 + lane < m;
-                const unsigned w = ((CntLdsU32)(uintptr_t)(have ? addr[r] - 4u : tb + 8u))[e];
+                const unsigned w = ((CntLdsU32)(uintptr_t)below_of(r, have))[e];
                 const double d = fabs(hist_exact_quot((int)(w & 0xffffu), dm_, rm_) - hist_exact_quot((int)(w >> 16), dq_, rq_));
                 dmax = hit ? fmax(dmax, d) : dmax;
               }
@@ -446,7 +492,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
 
     if (fit) {                                             // (wave-uniform)
       const double dm = (double)m, dq = (double)q;
-      const double rm = kCwRcp.v[m], rq = kCwRcp.v[q];
+      const double rm = rcp_m, rq = rcp_q;
       dmax = wave_max_f64(dmax);
       const unsigned MWS = cw_wave_sum_u32(mws);           // <= 2 m q
       const unsigned long long TIE = 3ull * wave_sum_u64((unsigned long long)(sp2 + sp));      // sum_v t^3 - n = 3 sum (p^2 + p)

@@ -47,6 +47,9 @@ struct RankStatsArgs {
   // cnt_done: one byte per entry of the work list (four per item, read as a dword), 1 where it produced the position's results
   // (0: left to the rank_hist_kernel<.., AFTER> launch that follows).  Both null: the counting form is not tried.
   int32_t* cnt_gate; uint8_t* cnt_done;
+  // counting form for any coverage (rank_count_wide.hpp): where alt_gates[class_id] != 0 the class's positions were tried by it and
+  // the sorting form walks what is left: alt_list / alt_meta (the layout of pos_list / class_meta).  Null: not in play.
+  const int32_t* alt_gates; const int32_t* alt_list; const int32_t* alt_meta;
   int32_t cnt_mode;                            // rank_hist_kernel launches around the counting form: 1 = run only when the gate is clear (the plain
                                                // instance takes the whole list), 2 = only when it is set (the AFTER instance takes what is left); 0 = always
 };

@@ -223,7 +223,7 @@ hipError_t NMOD_CW_PREP_NAME(const int* classes, int nclasses, hipStream_t strea
   if (nclasses <= 0) return hipSuccess;
   CntWideProbeArgs pa;
   pa.sig0 = a.sig0; pa.sig1 = a.sig1; pa.off0 = a.off0; pa.off1 = a.off1; pa.stride0 = a.stride0; pa.stride1 = a.stride1; pa.npos = a.npos;
-  pa.pos_list = a.pos_list; pa.class_meta = a.class_meta; pa.nclasses = nclasses; pa.gate = w.gates; pa.segs = w.gates + kClassStride;
+  pa.pos_list = a.pos_list; pa.class_meta = a.class_meta; pa.nclasses = nclasses; pa.gate = w.gates; pa.segs = w.gates + kClassStride; pa.work_meta = w.work_meta;
   for (int i = 0; i < nclasses && i < kClassStride; ++i) { pa.cls[i] = classes[i]; pa.max_s[i] = 64 << count_wide_rs_index(classes[i]); }
   hipError_t e = hipMemsetAsync(w.gates, 0, kClassStride * 4, stream);
   if (e != hipSuccess) return e;
@@ -233,9 +233,6 @@ hipError_t NMOD_CW_PREP_NAME(const int* classes, int nclasses, hipStream_t strea
 #else
   hipLaunchKernelGGL(cnt_wide_probe_kernel<1>, dim3((unsigned)nclasses), dim3(1024), 0, stream, pa);
 #endif
-  const unsigned cb = (unsigned)std::min<int64_t>((a.npos + 255) / 256, 2048);
-  hipLaunchKernelGGL(cnt_worklist_init_kernel<DT>, dim3(cb ? cb : 1), dim3(256), 0, stream, a.npos, a.pos_list, a.class_meta, w.work_list, w.work_meta,
-                     (const int32_t*)w.gates, classes[0]);
   return hipGetLastError();
 }
 

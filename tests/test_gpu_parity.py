@@ -950,11 +950,12 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
     # what runs: the dispatch description names the kernel for the sizes of the extremes
     L = nm._lib
     import ctypes as C
-    buf = C.create_string_buffer(96)
-    for (a, b), want in (((50, 1000), b'rank_hist_kernel<1,64,f32,wide>'), ((256, 4096), b'rank_hist_kernel<4,64,f32,wide>'),
-                         ((4096, 130), b'rank_hist_kernel<4,64,f32,wide>'), ((300, 4096), b'big_hist_kernel<f32>')):
+    buf = C.create_string_buffer(128)
+    cw = b'rank_count_wide_kernel<f32> (event-like rows) | '
+    for (a, b), want in (((50, 1000), cw + b'rank_hist_kernel<1,64,f32,wide>'), ((256, 4096), cw + b'rank_hist_kernel<4,64,f32,wide>'),
+                         ((4096, 130), cw + b'rank_hist_kernel<4,64,f32,wide>'), ((300, 4096), b'big_hist_kernel<f32>')):
         prm = L.make_params(method=L.METHOD_FISHER, nb=1)
-        assert L.load().nmod_describe_dispatch(C.byref(prm), a, b, buf, 96) == 0
+        assert L.load().nmod_describe_dispatch(C.byref(prm), a, b, buf, 128) == 0
         assert buf.value == want, (a, b, buf.value)
 
 

@@ -40,10 +40,14 @@ if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minut
                 ('ragged_all_f32_realties', ['--config', 'ragged', '--all-tests', '--ties', 'real', '--steps', '3', '--warmup', '1']),
                 ('ragged_all_i16', ['--config', 'ragged', '--all-tests', '--dtype', 'i16', '--steps', '3', '--warmup', '1']),
                 ('ragged_ks_f32', ['--config', 'ragged', '--steps', '3', '--warmup', '1']),
-                ('chr20_ks_f32', ['--config', 'chr20', '--steps', '3', '--warmup', '1'])]
+                ('chr20_ks_f32', ['--config', 'chr20', '--steps', '3', '--warmup', '1']),
+                ('ragged_all_i16_spread200', ['--config', 'ragged', '--all-tests', '--dtype', 'i16', '--spread', '200', '--steps', '3', '--warmup', '1']),
+                ('ragged_all_f32_spread200', ['--config', 'ragged', '--all-tests', '--spread', '200', '--steps', '3', '--warmup', '1']),
+                ('chr20_all_i16_spread200', ['--config', 'chr20', '--all-tests', '--dtype', 'i16', '--spread', '200', '--steps', '3', '--warmup', '1']),
+                ('chr20_all_f32_spread200', ['--config', 'chr20', '--all-tests', '--spread', '200', '--steps', '3', '--warmup', '1'])]
 if len(sys.argv) > 2:                      # python3 tools/profile_round.py r3 ks_f32,all_f32
     CONFIGS = [c for c in CONFIGS if c[0] in sys.argv[2].split(',')]
-K1_NAMES = ('ks_rank_kernel', 'rank_hist_kernel', 'rank_pair_kernel', 'big_rank_kernel', 'big_hist_kernel', 'rank_count_kernel')
+K1_NAMES = ('ks_rank_kernel', 'rank_hist_kernel', 'rank_pair_kernel', 'big_rank_kernel', 'big_hist_kernel', 'rank_count_kernel', 'rank_count_wide_kernel')
 PMC_GROUPS = [
     ['FETCH_SIZE'], ['WRITE_SIZE'],
     ['SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_VALU', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY'],

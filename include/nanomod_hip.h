@@ -12,7 +12,11 @@
  * large-position pass is allocated stream-ordered (freed slabs stay cached in
  * that pool until nmod_trim_scratch(); the device's default pool is not touched),
  * and the four tunables of nmod_host_pipeline_config (atomics; they change how a
- * host-resident batch is chunked and copied, never a result).
+ * host-resident batch is chunked and copied, never a result).  Two environment
+ * switches, read once per process, choose between kernel forms that produce
+ * the same numbers (A/B measurements): NMOD_NO_COUNTING=1 keeps event-like rows
+ * on the sorting forms, NMOD_NO_COUNT_WIDE=1 only those outside the
+ * 256-capacity class.
  *
  * Data layout: the tested positions, in the
  * reference's iteration order (sorted (chrom,strand), then ascending

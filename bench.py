@@ -1170,10 +1170,13 @@ def main():
         # the same shapes on event-like rows (sigma = 0.2), all three tests — what getKStest computes on stored events at real, ragged
         # coverage: the counting form for any coverage (rank_count_wide_kernel) where the device-side probe accepts a class
         if 'real_spread' in legs:
-            ev = {'note': 'nmod_synth_fill_events, sigma = 0.2, all three tests + Fisher; the ragged preset (~1 131 v ~57) and the chr20 shape (500 v 500)'}
+            ev = {'note': 'nmod_synth_fill_events, sigma = 0.2; the ragged preset (~1 131 v ~57) and the chr20 shape (500 v 500); all three tests + Fisher, and (_ks_) KS + Stouffer'}
             for nm_, kw in (('ragged_i16', dict(name='ragged', i16=True)), ('ragged_f32', dict(name='ragged', i16=False)),
-                            ('chr20_i16', dict(name='chr20', i16=True)), ('chr20_f32', dict(name='chr20', i16=False))):
-                ev[nm_] = preset_leg(kw['name'], True, 3, spread=200, i16=kw['i16'])
+                            ('chr20_i16', dict(name='chr20', i16=True)), ('chr20_f32', dict(name='chr20', i16=False)),
+                            # ... and the presets' own mask, KS + Stouffer (the form without the tie term and the moments)
+                            ('ragged_ks_i16', dict(name='ragged', i16=True, ks=True)), ('chr20_ks_i16', dict(name='chr20', i16=True, ks=True)),
+                            ('chr20_ks_f32', dict(name='chr20', i16=False, ks=True))):
+                ev[nm_] = preset_leg(kw['name'], not kw.get('ks', False), 3, spread=200, i16=kw['i16'])
                 torch.cuda.empty_cache()
             side['real_spread_presets'] = ev
 

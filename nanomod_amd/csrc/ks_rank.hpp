@@ -388,7 +388,10 @@ void ks_rank_kernel(RankStatsArgs args) {
 
   int64_t count = args.npos;
   const int32_t* list = nullptr;
-  if (args.pos_list) {
+  if (args.alt_gates != nullptr && args.alt_gates[args.class_id] != 0) {     // what rank_count_wide_kernel left of the class
+    count = args.alt_meta[args.class_id];
+    list = args.alt_list + args.alt_meta[kClassStride + args.class_id];
+  } else if (args.pos_list) {
     count = args.class_meta[args.class_id];
     list = args.pos_list + args.class_meta[kClassStride + args.class_id];
   }

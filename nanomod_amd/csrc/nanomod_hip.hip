@@ -513,21 +513,26 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   // when its probe finds the class event-like; the sorting form of the class then runs over the work list that is left
   // (NMOD_NO_COUNT_WIDE=1 turns it off)
   static const bool cw_off = []() { const char* e = getenv("NMOD_NO_COUNT_WIDE"); return e && *e && *e != '0'; }();
-  const bool cw_on = all && !counting_off && !cw_off;
+  // (KS-only batches too — the form without the tie term and the moments — when a group of the batch can reach the size it takes)
+  const bool cw_on = !counting_off && !cw_off && (all || std::max(max0, max1) >= kCwKsMinQ);
   CountWideWs cww;
   cww.gates = ws.work_meta + 2 * kClassStride; cww.done = ws.cw_done; cww.work_list = ws.work_list; cww.work_meta = ws.work_meta;
   auto cw_prepare = [&](const std::vector<int>& classes) -> hipError_t {
     if (classes.empty()) return hipSuccess;
-    return prm->dtype == NMOD_DTYPE_F32 ? launch_count_wide_prepare_d0_a1(classes.data(), (int)classes.size(), stream, ra, cww)
-                                        : launch_count_wide_prepare_d1_a1(classes.data(), (int)classes.size(), stream, ra, cww);
+    if (prm->dtype == NMOD_DTYPE_F32)
+      return all ? launch_count_wide_prepare_d0_a1(classes.data(), (int)classes.size(), stream, ra, cww)
+                 : launch_count_wide_prepare_d0_a0(classes.data(), (int)classes.size(), stream, ra, cww);
+    return all ? launch_count_wide_prepare_d1_a1(classes.data(), (int)classes.size(), stream, ra, cww)
+               : launch_count_wide_prepare_d1_a0(classes.data(), (int)classes.size(), stream, ra, cww);
   };
   // ... then the counting form over every class the probe accepted and the compaction of what it left, in one launch each
   auto cw_run = [&](const std::vector<int>& classes) -> hipError_t {
     if (classes.empty()) return hipSuccess;
     hipError_t e = cw_prepare(classes);
     if (e != hipSuccess) return e;
-    return prm->dtype == NMOD_DTYPE_F32 ? launch_count_wide_run_d0_a1(num_cus, npos, stream, ra, cww)
-                                        : launch_count_wide_run_d1_a1(num_cus, npos, stream, ra, cww);
+    if (prm->dtype == NMOD_DTYPE_F32)
+      return all ? launch_count_wide_run_d0_a1(num_cus, npos, stream, ra, cww) : launch_count_wide_run_d0_a0(num_cus, npos, stream, ra, cww);
+    return all ? launch_count_wide_run_d1_a1(num_cus, npos, stream, ra, cww) : launch_count_wide_run_d1_a0(num_cus, npos, stream, ra, cww);
   };
   // a class's sorting form; where the counting form was in play (its gate is set, on the device) it walks the work list
   auto launch_class = [&](int cls, int64_t work, bool counted) -> hipError_t {
@@ -565,7 +570,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     std::vector<int> counted_classes;
     if (cw_on) {
       for (int cls = 0; cls < kNumClasses; ++cls) if (wanted[cls] && count_wide_rs_index(cls) >= 0) counted_classes.push_back(cls);
-      if (big_possible) for (int cs = 0; cs < kNumWideBig; ++cs) counted_classes.push_back(kWideBigBase + cs);
+      if (big_possible && all) for (int cs = 0; cs < kNumWideBig; ++cs) counted_classes.push_back(kWideBigBase + cs);
       NMOD_HIP(cw_run(counted_classes));
     }
     for (int cls = 0; cls < kNumClasses; ++cls) {
@@ -1041,7 +1046,10 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
   if (!all) {
     const int cs = std::min(c0, c1);
     const int LG = ksonly_lanes_per_group(cs), R = (64 << cs) / LG;
-    snprintf(buf, buflen, "ks_rank_kernel<%d,%d,%s>", R, LG, dt);
+    // (the larger group of at least kCwKsMinQ samples, the smaller one of at most 1 024: the counting form when the probe finds the class event-like)
+    if (cs <= 4 && std::max(n0, n1) >= kCwKsMinQ && std::max(n0, n1) <= 4095)
+      snprintf(buf, buflen, "rank_count_wide_kernel<%s,ks> (event-like rows) | ks_rank_kernel<%d,%d,%s>", prm->dtype == NMOD_DTYPE_F64 ? "f32 keys" : dt, R, LG, dt);
+    else snprintf(buf, buflen, "ks_rank_kernel<%d,%d,%s>", R, LG, dt);
     return NMOD_OK;
   }
   const int cls = launch_class_of(c0, c1);

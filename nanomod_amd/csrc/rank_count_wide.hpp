@@ -47,12 +47,13 @@ struct CntWideProbeArgs {
   int32_t* gate;                                                 // [kClassStride]: gate[class]
   int32_t* segs;                                                 // [0] nclasses, [1 + b] cls[b]: the list the later kernels walk
   int32_t* work_meta;                                            // [class] = 0, [kClassStride + class] = the class list's offset: the work lists start empty
+  int32_t min_q;                                                 // KS-only mode: the form takes positions whose larger group holds at least this many (0: all)
 };
-template <int DTYPE>
+template <int DTYPE, bool KS>                                  // (KS: only to give each translation unit's instance its own name)
 __global__ __launch_bounds__(1024) void cnt_wide_probe_kernel(CntWideProbeArgs a) {
-  __shared__ int fits, seen;
+  __shared__ int fits, seen, looked;
   const int cid = a.cls[blockIdx.x];
-  if (threadIdx.x == 0) { fits = 0; seen = 0; }
+  if (threadIdx.x == 0) { fits = 0; seen = 0; looked = 0; }
   __syncthreads();
   int64_t count = a.npos;
   const int32_t* list = nullptr;
@@ -85,11 +86,12 @@ __global__ __launch_bounds__(1024) void cnt_wide_probe_kernel(CntWideProbeArgs a
     const int vmax = (int)(wave_max_u32((unsigned)hi ^ 0x80000000u) ^ 0x80000000u);
     const int vmin = (int)(~wave_max_u32(~((unsigned)lo ^ 0x80000000u)) ^ 0x80000000u);
     const bool fit = __ballot(!ok) == 0ull && (unsigned)(vmax - vmin) < 2048u;
-    if (lane == 0) { atomicAdd(&seen, 1); if (fit) atomicAdd(&fits, 1); }
+    if (lane == 0) { atomicAdd(&looked, 1); if (q >= a.min_q) { atomicAdd(&seen, 1); if (fit) atomicAdd(&fits, 1); } }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    a.gate[cid] = (seen > 0 && fits * 8 >= seen * 7) ? 1 : 0;
+    // (KS-only: at least half of the class must be of the form's sizes — it walks the whole class list)
+    a.gate[cid] = (seen > 0 && fits * 8 >= seen * 7 && seen * 2 >= looked) ? 1 : 0;
     a.segs[1 + blockIdx.x] = cid;
     a.work_meta[cid] = 0; a.work_meta[kClassStride + cid] = a.pos_list ? a.class_meta[kClassStride + cid] : 0;
     if (blockIdx.x == 0) a.segs[0] = a.nclasses;
@@ -102,7 +104,7 @@ struct CntCompactArgs {
   int64_t npos; const int32_t* pos_list; const int32_t* class_meta;
   const int32_t* gates; const int32_t* segs; const uint8_t* done; int32_t* work_list; int32_t* work_meta;       // work_meta[c] = count, [kClassStride + c] = offset
 };
-template <int DT>
+template <int DT, bool KS>
 __global__ __launch_bounds__(256) void cnt_compact_kernel(CntCompactArgs a) {
   const int lane = threadIdx.x & 63;
   __shared__ int base_s;
@@ -158,7 +160,7 @@ struct CwRcpTable {
 static __device__ const CwRcpTable kCwRcp = CwRcpTable();
 
 // one class of the batch (a segment of the class lists): positions start, start + stride, ... of its list
-template <int DTYPE, int RS>
+template <int DTYPE, int RS, bool KS>
 __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* done, unsigned* tbl, int64_t count, int64_t loff, const int32_t* list,
                                            int64_t start, int64_t wave_stride, int lane) {
   constexpr int RDT = (DTYPE == 1) ? 1 : 0;
@@ -218,7 +220,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
   auto request = [&](const Hdr& h, bool live, Rows& R, bool with_q, bool with_s) {
     const bool sw = h.n1 < h.n0;
     const int mr = sw ? h.n1 : h.n0, qr = sw ? h.n0 : h.n1;
-    const bool ok = live && mr >= 1 && mr <= 64 * RS && qr <= kCwMaxQ;       // (wave-uniform; otherwise the position is left to the sorting form)
+    const bool ok = live && mr >= 1 && mr <= 64 * RS && qr <= kCwMaxQ && (!KS || qr >= kCwKsMinQ);   // (wave-uniform; otherwise the position is left to the sorting form)
     const Q1Raw* dummy = reinterpret_cast<const Q1Raw*>(kKsBig4);
     const Q1Raw* row_s = ok ? reinterpret_cast<const Q1Raw*>(sw ? args.sig1 : args.sig0) + (sw ? h.o1 : h.o0) : dummy;
     const Q1Raw* row_q = ok ? reinterpret_cast<const Q1Raw*>(sw ? args.sig0 : args.sig1) + (sw ? h.o0 : h.o1) : dummy;
@@ -255,7 +257,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
     const bool swap = n1 < n0;                             // S = the smaller group (ties: group 1)
     const int m = swap ? n1 : n0, q = swap ? n0 : n1;
     const Q1Raw* rowq = reinterpret_cast<const Q1Raw*>(swap ? args.sig0 : args.sig1) + (swap ? cur.o0 : cur.o1);
-    bool fit = m >= 1 && m <= 64 * RS && q <= kCwMaxQ;     // (wave-uniform)
+    bool fit = m >= 1 && m <= 64 * RS && q <= kCwMaxQ && (!KS || q >= kCwKsMinQ);     // (wave-uniform)
     const int mm = fit ? m : 0, qq = fit ? q : 0;
     const double rcp_m = kCwRcp.v[mm], rcp_q = kCwRcp.v[qq];   // (requested here, used at the end: scalar loads)
     const int full = qq / 256;
@@ -282,7 +284,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
           const bool ok = key_of(x, k);
           bad = bad || !ok;
           ks[r] = k;
-          if constexpr (DTYPE == 0) { const double d = (double)x - K; ms1 += d; ms2 = __fma_rn(d, d, ms2); }
+          if constexpr (DTYPE == 0 && !KS) { const double d = (double)x - K; ms1 += d; ms2 = __fma_rn(d, d, ms2); }
         }
       } else {
         const int ks0 = __builtin_amdgcn_readfirstlane((int)raw[0]);
@@ -338,9 +340,15 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
       // number p.  A sample that does not exist adds nothing to the dump entry, which stays 0 in a position that fits.
       // (Using the word four arrivals later, when it has long returned, changed nothing: measured, profiles/r5_count_wide_ab.txt.)
       auto arrive = [&](unsigned a, unsigned inc, bool have) {
-        const unsigned old = __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)a, have ? inc : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        const unsigned p = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, old), one2, 0u, false);
-        sp2 = __umul24(p, p) + sp2; sp += p;
+        if constexpr (KS && DTYPE != 2) {                  // (KS only: no tie term — the add returns nothing)
+          __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)a, have ? inc : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else if constexpr (KS) {                         // (keys of float64 samples: whether any value occurs twice is reported, RankStatsArgs::tied)
+          sp |= __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)a, have ? inc : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+          const unsigned old = __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)a, have ? inc : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          const unsigned p = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, old), one2, 0u, false);
+          sp2 = __umul24(p, p) + sp2; sp += p;
+        }
       };
       // ---- S
 #pragma unroll
@@ -349,7 +357,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         const unsigned a_ = entry(have ? (unsigned)(ks[r] - base) : (unsigned)W);      // (no sample: the dump entry, one past the window)
         if constexpr (KEEPA) addr[r] = a_;
         arrive(a_, 1u, have);
-        if constexpr (RDT == 1) { const int d = have ? ks[r] - c : 0; is1 += d; is2 += (unsigned)__mul24(d, d); }
+        if constexpr (RDT == 1 && !KS) { const int d = have ? ks[r] - c : 0; is1 += d; is2 += (unsigned)__mul24(d, d); }
       }
       // ---- Q, streamed once
       const double KQ = (double)xq0;
@@ -358,15 +366,17 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         int k;
         const bool ok = key_of(x, k);
         bad = bad || !ok;
-        if constexpr (DTYPE == 0) { const double d = (double)x - KQ; mq1 += d; mq2 = __fma_rn(d, d, mq2); }
+        if constexpr (DTYPE == 0 && !KS) { const double d = (double)x - KQ; mq1 += d; mq2 = __fma_rn(d, d, mq2); }
         unsigned u = min((unsigned)(k - base), (unsigned)W);
         u = have ? u : (unsigned)W;
         arrive(entry(u), 0x10000u, have);
       };
       auto q_pair16 = [&](unsigned kk) {        // two int16 samples of a full chunk
         const CntS2 d2 = __builtin_bit_cast(CntS2, kk) - __builtin_bit_cast(CntS2, cc);
-        iq1 = __builtin_amdgcn_sdot2(d2, sone2, iq1, false);
-        iq2 = (unsigned)__builtin_amdgcn_sdot2(d2, d2, (int)iq2, false);
+        if constexpr (!KS) {
+          iq1 = __builtin_amdgcn_sdot2(d2, sone2, iq1, false);
+          iq2 = (unsigned)__builtin_amdgcn_sdot2(d2, d2, (int)iq2, false);
+        }
         const unsigned uu = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(CntU2, d2) + __builtin_bit_cast(CntU2, hw2), __builtin_bit_cast(CntU2, w2)));
         const unsigned x0 = ((uu & 0xffffu) >> lgE << 4) + tbE, x1 = ((uu >> 16) >> lgE << 4) + tbE;
         unsigned a0, a1;
@@ -406,8 +416,10 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
             // (the sample and, as its pair, the centre: d = 0 there and only the low half is counted)
             const unsigned kk = have ? (((unsigned)(int)cur1 & 0xffffu) | (cc & 0xffff0000u)) : cc;
             const CntS2 d2 = __builtin_bit_cast(CntS2, kk) - __builtin_bit_cast(CntS2, cc);
-            iq1 = __builtin_amdgcn_sdot2(d2, sone2, iq1, false);
-            iq2 = (unsigned)__builtin_amdgcn_sdot2(d2, d2, (int)iq2, false);
+            if constexpr (!KS) {
+              iq1 = __builtin_amdgcn_sdot2(d2, sone2, iq1, false);
+              iq2 = (unsigned)__builtin_amdgcn_sdot2(d2, d2, (int)iq2, false);
+            }
             unsigned uu = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(CntU2, d2) + __builtin_bit_cast(CntU2, hw2), __builtin_bit_cast(CntU2, w2)));
             uu = have ? uu : (unsigned)W;
             const unsigned x0 = ((uu & 0xffffu) >> lgE << 4) + tbE;
@@ -454,8 +466,10 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
           const bool have = r * 64 + lane < m;
           const CntLdsU32 pw = (CntLdsU32)(uintptr_t)below_of(r, have);
           const unsigned w0 = pw[0], w1 = pw[1];
-          mws = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, w0), hi1, mws, false);      // #{q < s} + #{q <= s}
-          mws = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, w1), hi1, mws, false);
+          if constexpr (!KS) {
+            mws = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, w0), hi1, mws, false);    // #{q < s} + #{q <= s}
+            mws = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, w1), hi1, mws, false);
+          }
           const int x0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, w0), qm, 0, false);   // A nQ - B nS just below the value
           const int x1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, w1), qm, 0, false);   // ... at it
           if constexpr (KEEP) { xs[2 * r] = x0; xs[2 * r + 1] = x1; }
@@ -463,7 +477,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         }
         best = wave_max_u32((unsigned)max(vmax, -vmin));
         // D in the float form at the candidates that reach the maximum (few: their table words are read again)
-        if (best != 0u) {
+        if (best != 0u && !(KS && args.ks_rational_d)) {
           const double dm_ = (double)m, dq_ = (double)q;
           const double rm_ = rcp_m, rq_ = rcp_q;
 #pragma unroll
@@ -491,33 +505,42 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
     }
 
     if (fit) {                                             // (wave-uniform)
-      const double dm = (double)m, dq = (double)q;
-      const double rm = rcp_m, rq = rcp_q;
       dmax = wave_max_f64(dmax);
-      const unsigned MWS = cw_wave_sum_u32(mws);           // <= 2 m q
-      const unsigned long long TIE = 3ull * wave_sum_u64((unsigned long long)(sp2 + sp));      // sum_v t^3 - n = 3 sum (p^2 + p)
-      double mean_s = 0.0, m2_s = 0.0, mean_q = 0.0, m2_q = 0.0;
-      if constexpr (DTYPE == 0) {
-        const double s1 = wave_sum_f64(ms1), s2 = wave_sum_f64(ms2), t1 = wave_sum_f64(mq1), t2 = wave_sum_f64(mq2);
-        mean_s = (double)xs0 + s1 * rm; m2_s = s2 - s1 * s1 * rm;
-        mean_q = (double)xq0 + t1 * rq; m2_q = t2 - t1 * t1 * rq;
-      } else if constexpr (DTYPE == 1) {
-        // exact integer sums about the centre: |sum d| <= 4 095 * 1 024, sum d^2 <= 4 095 * 2^20 < 2^32
-        const double s1 = (double)(int)cw_wave_sum_u32((unsigned)is1), s2 = (double)cw_wave_sum_u32(is2);
-        const double t1 = (double)(int)cw_wave_sum_u32((unsigned)iq1), t2 = (double)cw_wave_sum_u32(iq2);
-        mean_s = ((double)c + s1 * rm) * 1e-3; m2_s = __fma_rn(dm, s2, -s1 * s1) * rm * 1e-6;
-        mean_q = ((double)c + t1 * rq) * 1e-3; m2_q = __fma_rn(dq, t2, -t1 * t1) * rq * 1e-6;
-      }
-      if (lane == 0) {
-        args.ks_num[pos] = best;
-        args.ks_d_ref[pos] = dmax;
-        args.mwu_s[pos] = swap ? 2ull * (unsigned long long)n0 * (unsigned long long)n1 - (unsigned long long)MWS : (unsigned long long)MWS;
-        args.tie[pos] = TIE;
-        if constexpr (DTYPE != 2) {
-          double* mo = args.moments + pos * 4;
-          mo[swap ? 2 : 0] = mean_s; mo[swap ? 3 : 1] = m2_s; mo[swap ? 0 : 2] = mean_q; mo[swap ? 1 : 3] = m2_q;
+      if constexpr (KS) {
+        const bool any_tie = DTYPE == 2 && __ballot(sp != 0u) != 0ull;
+        if (lane == 0) {
+          args.ks_num[pos] = best;
+          args.ks_d_ref[pos] = dmax;
+          if (args.tied) args.tied[pos] = any_tie ? 1 : 0;
         }
-        if (args.tied) args.tied[pos] = TIE != 0ull ? 1 : 0;
+      } else {
+        const double dm = (double)m, dq = (double)q;
+        const double rm = rcp_m, rq = rcp_q;
+        const unsigned MWS = cw_wave_sum_u32(mws);           // <= 2 m q
+        const unsigned long long TIE = 3ull * wave_sum_u64((unsigned long long)(sp2 + sp));      // sum_v t^3 - n = 3 sum (p^2 + p)
+        double mean_s = 0.0, m2_s = 0.0, mean_q = 0.0, m2_q = 0.0;
+        if constexpr (DTYPE == 0) {
+          const double s1 = wave_sum_f64(ms1), s2 = wave_sum_f64(ms2), t1 = wave_sum_f64(mq1), t2 = wave_sum_f64(mq2);
+          mean_s = (double)xs0 + s1 * rm; m2_s = s2 - s1 * s1 * rm;
+          mean_q = (double)xq0 + t1 * rq; m2_q = t2 - t1 * t1 * rq;
+        } else if constexpr (DTYPE == 1) {
+          // exact integer sums about the centre: |sum d| <= 4 095 * 1 024, sum d^2 <= 4 095 * 2^20 < 2^32
+          const double s1 = (double)(int)cw_wave_sum_u32((unsigned)is1), s2 = (double)cw_wave_sum_u32(is2);
+          const double t1 = (double)(int)cw_wave_sum_u32((unsigned)iq1), t2 = (double)cw_wave_sum_u32(iq2);
+          mean_s = ((double)c + s1 * rm) * 1e-3; m2_s = __fma_rn(dm, s2, -s1 * s1) * rm * 1e-6;
+          mean_q = ((double)c + t1 * rq) * 1e-3; m2_q = __fma_rn(dq, t2, -t1 * t1) * rq * 1e-6;
+        }
+        if (lane == 0) {
+          args.ks_num[pos] = best;
+          args.ks_d_ref[pos] = dmax;
+          args.mwu_s[pos] = swap ? 2ull * (unsigned long long)n0 * (unsigned long long)n1 - (unsigned long long)MWS : (unsigned long long)MWS;
+          args.tie[pos] = TIE;
+          if constexpr (DTYPE != 2) {
+            double* mo = args.moments + pos * 4;
+            mo[swap ? 2 : 0] = mean_s; mo[swap ? 3 : 1] = m2_s; mo[swap ? 0 : 2] = mean_q; mo[swap ? 1 : 3] = m2_q;
+          }
+          if (args.tied) args.tied[pos] = TIE != 0ull ? 1 : 0;
+        }
       }
     }
     if (lane == 0) done[loff + it] = fit ? 1 : 0;
@@ -526,7 +549,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
 
 // every class the probe accepted, in one launch: a wave takes positions w, w + (waves), ... of the classes' lists laid end to end
 // (no tail per class: 15 classes of a ragged batch in 15 launches left the chip half idle)
-template <int DTYPE>
+template <int DTYPE, bool KS>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 4)
 void rank_count_wide_kernel(CntWideArgs cw) {
   extern __shared__ __attribute__((aligned(16))) unsigned lds_cw[];
@@ -548,11 +571,11 @@ void rank_count_wide_kernel(CntWideArgs cw) {
     if (start < 0) start += nw;
     rot = (rot + count) % nw;
     switch (count_wide_rs_index(cls)) {
-      case 0: cw_segment<DTYPE, 1>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
-      case 1: cw_segment<DTYPE, 2>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
-      case 2: cw_segment<DTYPE, 4>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
-      case 3: cw_segment<DTYPE, 8>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
-      case 4: cw_segment<DTYPE, 16>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
+      case 0: cw_segment<DTYPE, 1, KS>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
+      case 1: cw_segment<DTYPE, 2, KS>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
+      case 2: cw_segment<DTYPE, 4, KS>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
+      case 3: cw_segment<DTYPE, 8, KS>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
+      case 4: cw_segment<DTYPE, 16, KS>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
       default: break;
     }
   }

@@ -214,24 +214,23 @@ hipError_t NMOD_LAUNCH_NAME(int cls, int num_cus, int64_t work_items, hipStream_
 
 }  // namespace nmod
 
-#if NMOD_INST_ALL
-#define NMOD_CW_PREP_NAME NMOD_CAT(NMOD_CAT(launch_count_wide_prepare_d, NMOD_INST_DTYPE), _a1)
-#define NMOD_CW_RUN_NAME NMOD_CAT(NMOD_CAT(launch_count_wide_run_d, NMOD_INST_DTYPE), _a1)
+#define NMOD_CW_PREP_NAME NMOD_CAT(NMOD_CAT(launch_count_wide_prepare_d, NMOD_INST_DTYPE), NMOD_CAT(_a, NMOD_INST_ALL))
+#define NMOD_CW_RUN_NAME NMOD_CAT(NMOD_CAT(launch_count_wide_run_d, NMOD_INST_DTYPE), NMOD_CAT(_a, NMOD_INST_ALL))
 namespace nmod {
 
 hipError_t NMOD_CW_PREP_NAME(const int* classes, int nclasses, hipStream_t stream, const RankStatsArgs& a, const CountWideWs& w) {
   if (nclasses <= 0) return hipSuccess;
   CntWideProbeArgs pa;
   pa.sig0 = a.sig0; pa.sig1 = a.sig1; pa.off0 = a.off0; pa.off1 = a.off1; pa.stride0 = a.stride0; pa.stride1 = a.stride1; pa.npos = a.npos;
-  pa.pos_list = a.pos_list; pa.class_meta = a.class_meta; pa.nclasses = nclasses; pa.gate = w.gates; pa.segs = w.gates + kClassStride; pa.work_meta = w.work_meta;
+  pa.pos_list = a.pos_list; pa.class_meta = a.class_meta; pa.nclasses = nclasses; pa.gate = w.gates; pa.segs = w.gates + kClassStride; pa.work_meta = w.work_meta; pa.min_q = NMOD_INST_ALL ? 0 : kCwKsMinQ;
   for (int i = 0; i < nclasses && i < kClassStride; ++i) { pa.cls[i] = classes[i]; pa.max_s[i] = 64 << count_wide_rs_index(classes[i]); }
   hipError_t e = hipMemsetAsync(w.gates, 0, kClassStride * 4, stream);
   if (e != hipSuccess) return e;
 #if NMOD_INST_DTYPE == 0
-  if (a.tied != nullptr) hipLaunchKernelGGL(cnt_wide_probe_kernel<2>, dim3((unsigned)nclasses), dim3(1024), 0, stream, pa);
-  else hipLaunchKernelGGL(cnt_wide_probe_kernel<0>, dim3((unsigned)nclasses), dim3(1024), 0, stream, pa);
+  if (a.tied != nullptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(cnt_wide_probe_kernel<2, NMOD_INST_ALL == 0>), dim3((unsigned)nclasses), dim3(1024), 0, stream, pa);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(cnt_wide_probe_kernel<0, NMOD_INST_ALL == 0>), dim3((unsigned)nclasses), dim3(1024), 0, stream, pa);
 #else
-  hipLaunchKernelGGL(cnt_wide_probe_kernel<1>, dim3((unsigned)nclasses), dim3(1024), 0, stream, pa);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(cnt_wide_probe_kernel<1, NMOD_INST_ALL == 0>), dim3((unsigned)nclasses), dim3(1024), 0, stream, pa);
 #endif
   return hipGetLastError();
 }
@@ -240,10 +239,10 @@ hipError_t NMOD_CW_RUN_NAME(int num_cus, int64_t work_items, hipStream_t stream,
   typedef void (*CwFn)(CntWideArgs);
 #if NMOD_INST_DTYPE == 0
   const bool int_keys = a.tied != nullptr;
-  CwFn fn = int_keys ? (CwFn)rank_count_wide_kernel<2> : (CwFn)rank_count_wide_kernel<0>;
+  CwFn fn = int_keys ? (CwFn)rank_count_wide_kernel<2, NMOD_INST_ALL == 0> : (CwFn)rank_count_wide_kernel<0, NMOD_INST_ALL == 0>;
   const int slot = int_keys ? 1 : 0;
 #else
-  CwFn fn = (CwFn)rank_count_wide_kernel<1>;
+  CwFn fn = (CwFn)rank_count_wide_kernel<1, NMOD_INST_ALL == 0>;
   const int slot = 0;
 #endif
   static std::atomic<int> per_cu[64][2];
@@ -268,9 +267,9 @@ hipError_t NMOD_CW_RUN_NAME(int num_cus, int64_t work_items, hipStream_t stream,
   cp.npos = a.npos; cp.pos_list = a.pos_list; cp.class_meta = a.class_meta; cp.gates = w.gates; cp.segs = w.gates + kClassStride; cp.done = w.done;
   cp.work_list = w.work_list; cp.work_meta = w.work_meta;
   const unsigned cb = (unsigned)std::min<int64_t>((work_items + 255) / 256, 1024);
-  hipLaunchKernelGGL(cnt_compact_kernel<DT>, dim3(cb ? cb : 1), dim3(256), 0, stream, cp);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(cnt_compact_kernel<DT, NMOD_INST_ALL == 0>), dim3(cb ? cb : 1), dim3(256), 0, stream, cp);
   return hipGetLastError();
 }
 
 }  // namespace nmod
-#endif
+

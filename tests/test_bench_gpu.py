@@ -54,10 +54,10 @@ def test_event_like_main_configuration():
 
 def test_event_like_ragged_and_chr20_shapes():
     """`--spread 200` on the ragged preset and the chr20 shape, all tests: the counting form for any coverage, verified against the oracle"""
-    for cfg, dt in (('ragged', 'i16'), ('ragged', 'f32'), ('chr20', 'i16')):
-        d = _bench(['--config', cfg, '--all-tests', '--spread', '200', '--dtype', dt, '--positions', '60000', '--no-side', '--no-host-path'])
-        assert d['verify']['ok'] and d['config']['spread_milli'] == 200 and 'rank_count_wide_kernel' in d['roofline']['kernel'], (cfg, dt)
-        assert d['verify']['max_abs_err_ks_d'] == 0.0 and d['verify']['max_abs_err_mwu_u'] == 0.0
+    for cfg, dt, mode in (('ragged', 'i16', ['--all-tests']), ('ragged', 'f32', ['--all-tests']), ('chr20', 'i16', ['--all-tests']), ('chr20', 'i16', []), ('ragged', 'f32', [])):
+        d = _bench(['--config', cfg, '--spread', '200', '--dtype', dt, '--positions', '60000', '--no-side', '--no-host-path'] + mode)
+        assert d['verify']['ok'] and d['config']['spread_milli'] == 200 and 'rank_count_wide_kernel' in d['roofline']['kernel'], (cfg, dt, mode)
+        assert d['verify']['max_abs_err_ks_d'] == 0.0 and (not mode or d['verify']['max_abs_err_mwu_u'] == 0.0)
 
 
 def test_ragged_all_tests_grid_input_and_forced_collective():

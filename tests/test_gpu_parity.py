@@ -603,6 +603,13 @@ def test_count_wide_edges(nm, dtype):
     for k in ('mwu_p', 'ks_d', 'ks_p'):
         assert np.array_equal(sub[k][1:], got[k][lo + 1:], equal_nan=True), k
     H.assert_close_p(sub['t_p'][1:], got['t_p'][lo + 1:], 1e-9, 't_p')
+    # KS only (the form without the tie term; positions whose larger group is below its size stay with ks_rank_kernel), D bit for bit
+    # and as the exact rational (NMOD_FLAG_KS_RATIONAL_D: within 2 ulp)
+    ks = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    assert np.array_equal(ks['ks_d'], exp['ks_d'])
+    H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
+    kr = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=L.FLAG_KS_RATIONAL_D)
+    assert np.all(np.abs(kr['ks_d'] - exp['ks_d']) <= 4.5e-16)
 
 
 # general (64 lanes per group) and packed (two positions per wave) kernels, every capacity class

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 CFG=${1:-ragged}; DT=${2:-i16}; S=${3:-200}
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/cwprof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cwprof -- python3 $R/bench.py --config $CFG --all-tests --positions 2000000 --dtype $DT --spread $S --steps 5 --warmup 2 --no-cpu --no-side --no-host-path > /tmp/cwprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cwprof -- python3 $R/bench.py --config $CFG ${MODE---all-tests} --positions 2000000 --dtype $DT --spread $S --steps 5 --warmup 2 --no-cpu --no-side --no-host-path > /tmp/cwprof.log 2>&1
 F=$(find /tmp/cwprof -name "*kernel_stats.csv" | head -1); [ -z "$F" ] && { tail -20 /tmp/cwprof.log; find /tmp/cwprof | head; exit 1; }
 python3 - "$F" <<'PY'
 import csv, sys

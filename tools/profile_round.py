@@ -44,7 +44,10 @@ if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minut
                 ('ragged_all_i16_spread200', ['--config', 'ragged', '--all-tests', '--dtype', 'i16', '--spread', '200', '--steps', '3', '--warmup', '1']),
                 ('ragged_all_f32_spread200', ['--config', 'ragged', '--all-tests', '--spread', '200', '--steps', '3', '--warmup', '1']),
                 ('chr20_all_i16_spread200', ['--config', 'chr20', '--all-tests', '--dtype', 'i16', '--spread', '200', '--steps', '3', '--warmup', '1']),
-                ('chr20_all_f32_spread200', ['--config', 'chr20', '--all-tests', '--spread', '200', '--steps', '3', '--warmup', '1'])]
+                ('chr20_all_f32_spread200', ['--config', 'chr20', '--all-tests', '--spread', '200', '--steps', '3', '--warmup', '1']),
+                ('ragged_ks_i16_spread200', ['--config', 'ragged', '--dtype', 'i16', '--spread', '200', '--steps', '3', '--warmup', '1']),
+                ('chr20_ks_i16_spread200', ['--config', 'chr20', '--dtype', 'i16', '--spread', '200', '--steps', '3', '--warmup', '1']),
+                ('chr20_ks_f32_spread200', ['--config', 'chr20', '--spread', '200', '--steps', '3', '--warmup', '1'])]
 if len(sys.argv) > 2:                      # python3 tools/profile_round.py r3 ks_f32,all_f32
     CONFIGS = [c for c in CONFIGS if c[0] in sys.argv[2].split(',')]
 K1_NAMES = ('ks_rank_kernel', 'rank_hist_kernel', 'rank_pair_kernel', 'big_rank_kernel', 'big_hist_kernel', 'rank_count_kernel', 'rank_count_wide_kernel')

@@ -1,21 +1,25 @@
-// K1, counting form for any coverage (round 5) — all-tests mode for EVENT-LIKE positions of every shape the reference sees:
+// K1, counting form for any coverage (round 5) — EVENT-LIKE positions of every shape the reference sees, all tests or KS only:
 // one position per wave, the smaller group S of up to 64 RS samples (RS = 1 ... 16 registers per lane: 64 ... 1 024 samples), the
-// larger group Q of up to 4 095.  rank_count.hpp is the same idea for four 200 v 200-like positions per wave with byte tables;
-// here the prefix tables hold 16-bit entries over a window of 1 024 ... 4 096 milli-units centred on S, and Q — which is most of
-// the samples at skewed coverage (configs[4]: ~1 131 v ~57) — is never looked up:
-//   table S   count S's keys (ds_add), prefix sums in place, every sample of S reads A[u-1], A[u]        (its own group's ranks)
-//   table Q   STREAM Q once: one returning ds_add per sample counts its key and returns the earlier copies p (for sum_v b^3), its
-//             moment sums ride along; prefix sums in place; every sample of S reads B[u-1], B[u]
-// and with a(v) = A[v] - A[v-1], b(v) = B[v] - B[v-1] at the values v of S (rank_count.hpp has the derivations):
-//   KS        max over S's samples of |A[v] nQ - B[v] nS| and |A[v-1] nQ - B[v-1] nS|, the float form at the samples that reach it
+// larger group Q of up to 4 095.  rank_count.hpp is the same idea for four 200 v 200-like positions per wave with byte tables; here
+// ONE table serves both groups: a 32-bit word per value of a 512 / 1 024 / 2 048-value window centred on S,
+//   count     ds_add_rtn_u32 of 1 (a sample of S) or 0x10000 (a sample of Q) at the word of its value; the word that comes back
+//             holds the copies of the value counted before it, in both groups: the sample's arrival number p
+//   scan      prefix sums in place, both halves at once (S's half stays below 2^16): word v = A[v] | B[v] << 16
+//   look up   every sample of S reads the words just below and at its value (Q — most of the samples at skewed coverage,
+//             configs[4]: ~1 131 v ~57 — is streamed once and never looked up)
+// and from those (rank_count.hpp has the derivations):
+//   KS        max over S's samples of |A[v] nQ - B[v] nS| and |A[v-1] nQ - B[v-1] nS| (one v_dot2_i32_i16 against (nQ, -nS)); the float
+//             form of D at the candidates that reach the maximum
 //   MWU       sum over S of (B[v-1] + B[v]) = sum (#{q < s} + #{q <= s}); mwu_s is that sum when S is group 1, else 2 n0 n1 - it
-//   ties      sum_v (a + b)^3 = sum over S of (a^2 + 3 a b + 3 b^2) + sum_v b^3,  sum_v b^3 = sum over Q of (3 p^2 + 3 p + 1)
-// Per streamed sample: key, window test, address, one LDS atomic, three integer multiply-adds — against a binary search (27
-// instructions), a histogram add, a tie counter and the moments in the sorting form's WIDE instance (rank_hist.hpp).
-// A position is left to the sorting forms (flag byte per list entry, compacted into a work list by cnt_compact_kernel) when a
-// group is out of range, a float32 sample is off the milli-unit grid, a sample of Q falls outside the window, or a value occurs
-// 255 times or more.  Whether a class of a batch is event-like at all is decided by cnt_wide_probe_kernel on a sample of its
-// positions (gate): continuous signals pay the probe, an empty launch and the copy of the class list.
+//   ties      sum_v t^3 - n = 3 sum over all arrivals of (p^2 + p)   (sum_{p < t} (3 p^2 + 3 p + 1) = t^3): no limit on the copies
+// Per streamed int16 sample 12.5 instructions (pairs: v_pk_sub_i16, v_pk_min_u16 against the window size, v_dot2 moment sums about the
+// window's centre, v_mad_u32_u16 with op_sel for the address) against 27 for the sorting form's binary search alone; float32 adds
+// the sample's key (grid_key, 9) and its fp64 moment sums (4).  KS only: the adds return nothing, no moments, no MWU sums.
+// A position is left to the sorting forms (flag byte per list entry, compacted into a work list by cnt_compact_kernel; the sorting
+// kernel of the class walks that list where the class's gate is set: RankStatsArgs::alt_*) when a group is out of range, a float32
+// sample is off the milli-unit grid, S spans 2 047 values or more, or a sample of Q falls outside the window (it lands in a dump
+// entry and the table's total comes up short).  Whether a class of a batch is event-like at all is decided by
+// cnt_wide_probe_kernel on a sample of its positions (gate): continuous signals pay the probe and two empty launches.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,7 +28,7 @@
 
 namespace nmod {
 
-constexpr int kCwMaxQ = 4095;                                  // 16-bit prefix sums, 12-bit arrival numbers
+constexpr int kCwMaxQ = 4095;                                  // Q's half of a word, and |A nQ - B nS| through 16-bit dot products
 constexpr int kCwWindow = 2048;                                // values the table can cover: 64 lane blocks of 8, 16 or 32 entries
 constexpr int kCwWaveWords = 64 * 36 + 8;                      // a lane's block: 4 pad words + up to 32 entries; + the dump entry: 9 248 B per wave
 __host__ __device__ constexpr size_t rank_count_wide_lds_bytes() { return (size_t)kWavesPerBlock * kCwWaveWords * 4; }

@@ -1,7 +1,7 @@
 // K1, counting form for any coverage (round 5) — EVENT-LIKE positions of every shape the reference sees, all tests or KS only:
 // one position per wave, the smaller group S of up to 64 RS samples (RS = 1 ... 16 registers per lane: 64 ... 1 024 samples), the
 // larger group Q of up to 4 095.  rank_count.hpp is the same idea for four 200 v 200-like positions per wave with byte tables; here
-// ONE table serves both groups: a 32-bit word per value of a 512 / 1 024 / 2 048-value window centred on S,
+// ONE table serves both groups: a 32-bit word per value of a 2 048-value window centred on S,
 //   count     ds_add_rtn_u32 of 1 (a sample of S) or 0x10000 (a sample of Q) at the word of its value; the word that comes back
 //             holds the copies of the value counted before it, in both groups: the sample's arrival number p
 //   scan      prefix sums in place, both halves at once (S's half stays below 2^16): word v = A[v] | B[v] << 16
@@ -29,7 +29,7 @@
 namespace nmod {
 
 constexpr int kCwMaxQ = 4095;                                  // Q's half of a word, and |A nQ - B nS| through 16-bit dot products
-constexpr int kCwWindow = 2048;                                // values the table can cover: 64 lane blocks of 8, 16 or 32 entries
+constexpr int kCwWindow = 2048;                                // values the table covers: 64 lane blocks of 32 entries
 constexpr int kCwWaveWords = 64 * 36 + 8;                      // a lane's block: 4 pad words + up to 32 entries; + the dump entry: 9 248 B per wave
 __host__ __device__ constexpr size_t rank_count_wide_lds_bytes() { return (size_t)kWavesPerBlock * kCwWaveWords * 4; }
 
@@ -139,13 +139,25 @@ __global__ __launch_bounds__(256) void cnt_compact_kernel(CntCompactArgs a) {
   }
 }
 
-// ---- wave-wide helpers of this form
+// ---- wave-wide helpers of this form: four DPP steps inside each 16-lane row, two row broadcasts into lane 63, one v_readlane
+// (wave_ops.hpp's reductions read four row results and combine them with scalar instructions: eleven operations instead of seven)
 __device__ __forceinline__ unsigned cw_wave_sum_u32(unsigned v) {
   v += (unsigned)dpp_i<NMOD_QP(1, 0, 3, 2)>(0, (int)v);
   v += (unsigned)dpp_i<NMOD_QP(2, 3, 0, 1)>(0, (int)v);
   v += (unsigned)dpp_i<kDppRowHalfMirror>(0, (int)v);
   v += (unsigned)dpp_i<kDppRowMirror>(0, (int)v);
-  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+  v += (unsigned)dpp_i<kDppRowBcast15, 0xA>(0, (int)v);     // rows 1, 3 += rows 0, 2
+  v += (unsigned)dpp_i<kDppRowBcast31, 0xC>(0, (int)v);     // rows 2, 3 += row 1
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned cw_wave_max_u32(unsigned v) {
+  v = max(v, (unsigned)dpp_i<NMOD_QP(1, 0, 3, 2)>((int)v, (int)v));
+  v = max(v, (unsigned)dpp_i<NMOD_QP(2, 3, 0, 1)>((int)v, (int)v));
+  v = max(v, (unsigned)dpp_i<kDppRowHalfMirror>((int)v, (int)v));
+  v = max(v, (unsigned)dpp_i<kDppRowMirror>((int)v, (int)v));
+  v = max(v, (unsigned)dpp_i<kDppRowBcast15, 0xA>((int)v, (int)v));
+  v = max(v, (unsigned)dpp_i<kDppRowBcast31, 0xC>((int)v, (int)v));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ unsigned cw_wave_max_pk_u16(unsigned v) {          // both 16-bit halves at once
   auto mx = [](unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(CntU2, a), __builtin_bit_cast(CntU2, b))); };
@@ -153,7 +165,9 @@ __device__ __forceinline__ unsigned cw_wave_max_pk_u16(unsigned v) {          //
   v = mx(v, (unsigned)dpp_i<NMOD_QP(2, 3, 0, 1)>((int)v, (int)v));
   v = mx(v, (unsigned)dpp_i<kDppRowHalfMirror>((int)v, (int)v));
   v = mx(v, (unsigned)dpp_i<kDppRowMirror>((int)v, (int)v));
-  return mx(mx(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), mx(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+  v = mx(v, (unsigned)dpp_i<kDppRowBcast15, 0xA>((int)v, (int)v));
+  v = mx(v, (unsigned)dpp_i<kDppRowBcast31, 0xC>((int)v, (int)v));
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // 1 / n, correctly rounded, n <= 4 095 (hist_exact_quot's r): one scalar load instead of a float64 division per position
@@ -181,32 +195,42 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
   const CntS2 sone2 = {1, 1};
   const CntU2 hi1 = {0, 1};
 
-  // Headers (list entry, row offsets, sizes): 64 positions at a time, one per lane, by vector loads; a position's header is read
-  // out of its lane.  (As scalar loads per position they were two dependent memory latencies, and their counter is the LDS's:
-  // the first wait for a returning ds_add waited for them too.)
-  struct Hdr { int64_t pos, o0, o1; int n0, n1; };
-  int hb_pos = 0, hb_n0 = 0, hb_n1 = 0; int64_t hb_o0 = 0, hb_o1 = 0;
+  // Headers: 64 positions at a time, one per lane, by vector loads — list entry, row offsets, sizes — and everything that follows
+  // from them computed there, 64 positions per instruction: which group is S, whether the sizes are this form's, the rows' addresses.
+  // A position's header is read out of its lane (six v_readlane).  (As scalar loads per position the entries were two dependent
+  // memory latencies on the LDS's counter; as scalar arithmetic per position the rest was 50 of its 275 scalar instructions.)
+  struct Hdr { int pos; int m, q; bool swap, fit; const Q1Raw* row_s; const Q1Raw* row_q; };
+  int hb_pos = 0; unsigned hb_mq = 0u; uint64_t hb_rs = 0ull, hb_rq = 0ull;
   auto load_batch = [&](int64_t it0) {                     // lane j: position it0 + j * wave_stride of the list
     const int64_t itj = it0 + (int64_t)lane * wave_stride;
-    hb_pos = 0; hb_n0 = hb_n1 = 0; hb_o0 = hb_o1 = 0;
+    int64_t p = 0, o0 = 0, o1 = 0; int n0 = 0, n1 = 0;
     if (itj < count) {
-      const int64_t p = list ? (int64_t)list[itj] : itj;
-      hb_pos = (int)p;
-      if (args.stride0 > 0) { hb_o0 = p * args.stride0; hb_n0 = (int)args.stride0; } else { hb_o0 = args.off0[p]; hb_n0 = (int)(args.off0[p + 1] - hb_o0); }
-      if (args.stride1 > 0) { hb_o1 = p * args.stride1; hb_n1 = (int)args.stride1; } else { hb_o1 = args.off1[p]; hb_n1 = (int)(args.off1[p + 1] - hb_o1); }
+      p = list ? (int64_t)list[itj] : itj;
+      if (args.stride0 > 0) { o0 = p * args.stride0; n0 = (int)args.stride0; } else { o0 = args.off0[p]; n0 = (int)(args.off0[p + 1] - o0); }
+      if (args.stride1 > 0) { o1 = p * args.stride1; n1 = (int)args.stride1; } else { o1 = args.off1[p]; n1 = (int)(args.off1[p + 1] - o1); }
     }
+    const bool sw = n1 < n0;                               // S = the smaller group (ties: group 1)
+    const int mr = sw ? n1 : n0, qr = sw ? n0 : n1;
+    const bool ok = mr >= 1 && mr <= 64 * RS && qr >= 4 && qr <= kCwMaxQ && (!KS || qr >= kCwKsMinQ);   // (otherwise: left to the sorting form)
+    const Q1Raw* dummy = reinterpret_cast<const Q1Raw*>(kKsBig4);                                       // (read as a row of one / four samples)
+    hb_pos = (int)p;
+    hb_mq = (unsigned)(ok ? mr : 1) | ((unsigned)(ok ? qr : 4) << 12) | (sw ? 1u << 24 : 0u) | (ok ? 1u << 25 : 0u);
+    hb_rs = (uint64_t)(uintptr_t)(ok ? reinterpret_cast<const Q1Raw*>(sw ? args.sig1 : args.sig0) + (sw ? o1 : o0) : dummy);
+    hb_rq = (uint64_t)(uintptr_t)(ok ? reinterpret_cast<const Q1Raw*>(sw ? args.sig0 : args.sig1) + (sw ? o0 : o1) : dummy);
   };
-  auto rl64 = [&](int64_t v, int j) -> int64_t {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, j);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), j);
-    return (int64_t)(((unsigned long long)hi << 32) | lo);
+  auto rl64 = [&](uint64_t v, int j) -> uint64_t {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, j);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), j);
+    return ((uint64_t)hi << 32) | lo;
   };
   int hb_j = 0;                                            // lane of the header read next
   auto load_hdr = [&](int64_t it) -> Hdr {                 // called with it = start, start + wave_stride, ... in order
     if (hb_j == 0) load_batch(it);
     Hdr h;
-    h.pos = (int64_t)__builtin_amdgcn_readlane(hb_pos, hb_j); h.n0 = __builtin_amdgcn_readlane(hb_n0, hb_j); h.n1 = __builtin_amdgcn_readlane(hb_n1, hb_j);
-    h.o0 = rl64(hb_o0, hb_j); h.o1 = rl64(hb_o1, hb_j);
+    h.pos = __builtin_amdgcn_readlane(hb_pos, hb_j);
+    const unsigned mq = (unsigned)__builtin_amdgcn_readlane((int)hb_mq, hb_j);
+    h.m = (int)(mq & 0xfffu); h.q = (int)((mq >> 12) & 0xfffu); h.swap = ((mq >> 24) & 1u) != 0u; h.fit = ((mq >> 25) & 1u) != 0u;
+    h.row_s = reinterpret_cast<const Q1Raw*>((uintptr_t)rl64(hb_rs, hb_j)); h.row_q = reinterpret_cast<const Q1Raw*>((uintptr_t)rl64(hb_rq, hb_j));
     hb_j = (hb_j + 1) & 63;
     return h;
   };
@@ -214,28 +238,21 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
   // reduced: up to PF chunks of 256 samples of Q (four per lane), the <= 255 that remain one per lane, S one per lane and register.
   // (With one chunk in flight and the requests at the top the waves waited a memory latency per 50 instructions.)  A sample that
   // does not exist is read as the row's last one and masked.
-  constexpr int PF = (RS == 16) ? 2 : 4;
+  constexpr int PF = (RS == 16) ? (RDT == 0 ? 1 : 2) : 4;
   constexpr bool PS = RS <= 8;                             // S a position ahead as well (RS = 16: sixteen more live registers spill)
   struct Rows { Q1Raw s[RS]; Q4Raw qa[PF]; Q1Raw rt[4]; Q1Raw q0; };
   auto load_at = [&](const void* row, unsigned byte_off, auto tag) { return ks_global_load<decltype(tag)>(reinterpret_cast<const char*>(row) + byte_off); };
   // (every load is issued whatever the position looks like — a chunk or a position that does not exist reads the 16-byte dummy:
   // a conditional load makes the loaded registers phi nodes, and the copies the compiler places for them wait for the data
   // right where the request was meant to run ahead)
-  auto request = [&](const Hdr& h, bool live, Rows& R, bool with_q, bool with_s) {
-    const bool sw = h.n1 < h.n0;
-    const int mr = sw ? h.n1 : h.n0, qr = sw ? h.n0 : h.n1;
-    const bool ok = live && mr >= 1 && mr <= 64 * RS && qr <= kCwMaxQ && (!KS || qr >= kCwKsMinQ);   // (wave-uniform; otherwise the position is left to the sorting form)
-    const Q1Raw* dummy = reinterpret_cast<const Q1Raw*>(kKsBig4);
-    const Q1Raw* row_s = ok ? reinterpret_cast<const Q1Raw*>(sw ? args.sig1 : args.sig0) + (sw ? h.o1 : h.o0) : dummy;
-    const Q1Raw* row_q = ok ? reinterpret_cast<const Q1Raw*>(sw ? args.sig0 : args.sig1) + (sw ? h.o0 : h.o1) : dummy;
-    const int m_ = ok ? mr : 1, q_ = ok ? qr : 1;
+  auto request = [&](const Hdr& h, Rows& R, bool with_q, bool with_s) {      // (a position past the list's end: the dummy rows, load_batch)
+    const Q1Raw* row_s = h.row_s; const Q1Raw* row_q = h.row_q;
+    const int m_ = h.m, q_ = h.q;
     const int full_ = q_ / 256;
     if (with_q) {
+      // (a chunk the row does not have reads the row's last four samples: no pointer selects)
 #pragma unroll
-      for (int j = 0; j < PF; ++j) {
-        const bool v = j < full_;
-        R.qa[j] = load_at(v ? row_q + j * 256 : dummy, v ? (unsigned)(4 * lane) * (unsigned)sizeof(Q1Raw) : 0u, Q4Raw());
-      }
+      for (int j = 0; j < PF; ++j) R.qa[j] = load_at(row_q, (unsigned)min(j * 256 + 4 * lane, q_ - 4) * (unsigned)sizeof(Q1Raw), Q4Raw());
 #pragma unroll
       for (int j = 0; j < 4; ++j) R.rt[j] = load_at(row_q, (unsigned)min(full_ * 256 + j * 64 + lane, q_ - 1) * (unsigned)sizeof(Q1Raw), Q1Raw());
       if constexpr (RDT == 0) R.q0 = load_at(row_q, 0u, Q1Raw());
@@ -252,23 +269,22 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
 #pragma unroll
   for (int j = 0; j < 4; ++j) rows.rt[j] = Q1Raw(0);
   rows.q0 = Q1Raw(0);
-  request(nxt, start < count, rows, true, PS);
+  request(nxt, rows, true, PS);
   for (int64_t it = start; it < count; it += wave_stride) {
     const Hdr cur = nxt;
     nxt = load_hdr(it + wave_stride);
     const int64_t pos = cur.pos;
-    const int n0 = cur.n0, n1 = cur.n1;
-    const bool swap = n1 < n0;                             // S = the smaller group (ties: group 1)
-    const int m = swap ? n1 : n0, q = swap ? n0 : n1;
-    const Q1Raw* rowq = reinterpret_cast<const Q1Raw*>(swap ? args.sig0 : args.sig1) + (swap ? cur.o0 : cur.o1);
-    bool fit = m >= 1 && m <= 64 * RS && q <= kCwMaxQ && (!KS || q >= kCwKsMinQ);     // (wave-uniform)
+    const bool swap = cur.swap;
+    const int m = cur.m, q = cur.q;                        // (a position that is not this form's: 1 and 4, fit = false)
+    const Q1Raw* rowq = cur.row_q;
+    bool fit = cur.fit;                                    // (wave-uniform)
     const int mm = fit ? m : 0, qq = fit ? q : 0;
     const double rcp_m = kCwRcp.v[mm], rcp_q = kCwRcp.v[qq];   // (requested here, used at the end: scalar loads)
     const int full = qq / 256;
     const int tail = (qq - full * 256 + 63) / 64;
     float xq0 = 0.0f;
     if constexpr (RDT == 0) xq0 = (float)rows.q0;
-    if constexpr (!PS) request(cur, true, rows, false, true);
+    if constexpr (!PS) request(cur, rows, false, true);
 
     // ---- S: sample r * 64 + lane in register r.  Keys, float32 moments, range.
     int ks[RS];
@@ -305,12 +321,12 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
       smax = (int)(P & 0xffffu) - 32768; smin = 32767 - (int)(P >> 16);
     }
     fit = fit && __ballot(bad) == 0ull && (smax - smin) < kCwWindow - 1;
-    // the window: 512, 1 024 or 2 048 values centred on S, at least 1.5 times S's own range + 640 wide when that fits (Q is 10-20
-    // times S at skewed coverage and spreads a little further; a sample of Q outside the window lands in the dump entry, the
-    // table's total comes up short and the position goes to the sorting form); E = 1 << lgE entries per lane block
-    const int need = fit ? (3 * (smax - smin)) / 2 + 640 : 0;
-    const int lgE = need <= 512 ? 3 : (need <= 1024 ? 4 : 5);
-    const int W = 64 << lgE;
+    // the window: 2 048 values centred on S (Q is 10-20 times S at skewed coverage and spreads a little further; a sample of Q outside
+    // the window lands in the dump entry, the table's total comes up short and the position goes to the sorting form); E = 1 << lgE
+    // entries per lane block.  (A window of 512 / 1 024 values where S's range allowed it — a shorter clear and scan — was measured:
+    // event-like rows at sigma >= 0.1 never took it, and its wave-uniform branches cost every position 4-8 %.)
+    constexpr int lgE = 5;
+    constexpr int W = 64 << lgE;
     int base = ((smin + smax) >> 1) - (W >> 1);
     base = max(-32768, min(base, 32768 - W));             // (inside the int16 domain: k - base mod 2^16 cannot alias into the window)
     const int c = base + (W >> 1);                         // moments are taken about the centre: |k - c| <= 1 024
@@ -323,7 +339,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
     constexpr bool KEEPA = RS <= 8;                        // the samples' table addresses stay in registers (RS = 16: recomputed from the keys)
     unsigned addr[KEEPA ? RS : 1];
     const CntS2 qm = {(short)q, (short)-m};
-    const int nch = 1 << (lgE - 2);                      // 16-byte chunks of a lane block: 2, 4, 8
+    constexpr int nch = 1 << (lgE - 2);                    // 16-byte chunks of a lane block
     uint4* blk = reinterpret_cast<uint4*>(__builtin_assume_aligned(reinterpret_cast<char*>(tbl) + lane * ((4 << lgE) + 16) + 16, 16));
     auto entry = [&](unsigned u) -> unsigned { return tbE + (u << 2) + ((u >> lgE) << 4); };
     auto below_of = [&](int r, bool have) -> unsigned {      // LDS address of the word just below sample r's own (no sample: two zero words of block 0's pad)
@@ -436,7 +452,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    request(nxt, it + wave_stride < count, rows, true, PS);       // the next position's rows: in flight while this one's table is scanned
+    request(nxt, rows, true, PS);       // the next position's rows: in flight while this one's table is scanned
     if (fit) {
       // ---- prefix sums in place (both halves at once: the S half stays below 2^16); the pad's last word = the sum below the block
       unsigned tot = 0u;
@@ -479,7 +495,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
           if constexpr (KEEP) { xs[2 * r] = x0; xs[2 * r + 1] = x1; }
           vmax = max(vmax, max(x0, x1)); vmin = min(vmin, min(x0, x1));
         }
-        best = wave_max_u32((unsigned)max(vmax, -vmin));
+        best = cw_wave_max_u32((unsigned)max(vmax, -vmin));
         // D in the float form at the candidates that reach the maximum (few: their table words are read again)
         if (best != 0u && !(KS && args.ks_rational_d)) {
           const double dm_ = (double)m, dq_ = (double)q;
@@ -537,7 +553,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         if (lane == 0) {
           args.ks_num[pos] = best;
           args.ks_d_ref[pos] = dmax;
-          args.mwu_s[pos] = swap ? 2ull * (unsigned long long)n0 * (unsigned long long)n1 - (unsigned long long)MWS : (unsigned long long)MWS;
+          args.mwu_s[pos] = swap ? 2ull * (unsigned long long)m * (unsigned long long)q - (unsigned long long)MWS : (unsigned long long)MWS;
           args.tie[pos] = TIE;
           if constexpr (DTYPE != 2) {
             double* mo = args.moments + pos * 4;

@@ -49,7 +49,7 @@ PLANT_PERIOD = 10000
 PLANT_SHIFT = 0.8
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GUIDE_GBS = 6290.0    # same guide: measured float4 copy
-# instruction budget of the design per position (VALU wave-instructions), by (mode, n0, n1)
+# profiles/HISTORY.md B.3: instruction budget of the design per position (VALU wave-instructions), by (mode, n0, n1)
 FLOOR_INSTR = {('ks', 200, 200): 342 + 39, ('all', 200, 200): 640}
 KS_D_RATIONAL_ABS = 4.5e-16    # gate on D under NMOD_FLAG_KS_RATIONAL_D (2 ulp); without the flag D is bit for bit
 
@@ -1244,7 +1244,7 @@ def main():
                          'note': 'achieved / peak / frac are against HBM, the mandated yard-stick (sort / search / scan, no MFMA); what '
                                  'bounds the kernel is VALU instruction issue (see `valu`): traffic ~ 1.0 x algorithmic, ~0.9 of the issue '
                                  'slots taken, clock held near 2.2 GHz by the power limit.  `floor_instr_per_position` is the budget of this '
-                                 'design (DESIGN.md Appendix B.3: sort of the smaller group + one binary search per sample + prefix-sum evaluation)',
+                                 'design (profiles/HISTORY.md B.3: sort of the smaller group + one binary search per sample + prefix-sum evaluation)',
                          'floor_instr_per_position': FLOOR_INSTR.get(('all' if all_tests else 'ks', n0, n1)),
                          'definition': 'SURVEY.md 8(d) bytes/position x positions per launch / HIP-event time of K1 + K2 + K3 of that launch',
                          'algorithmic_bytes_per_position': algo, 'positions_per_launch': pos_per_launch, 'profile_key': key,

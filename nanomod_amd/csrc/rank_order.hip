@@ -2,16 +2,16 @@
 //
 // nmod_rank_order — the 3-key ranking of the result table (myDetect.py:447-462) on the device.
 // The reference sorts the records by the tuple (combined, KS, MWU) p-value (or statistic) with Python's stable
-// sorted(); here: three stable LSD passes of rocPRIM's radix sort over order-preserving 64-bit images of the fp64
-// keys (least significant key first), carrying the record index.  Outside the timed hot path;
-// the sort itself is the ROCm library's, like a plain GEMM would be hipBLASLt's.
+// sorted(); here: three stable LSD radix sorts (radix_sort.hpp: hand-written, eight one-byte passes each) over
+// order-preserving 64-bit images of the fp64 keys (least significant key first), carrying the record index.
+// Outside the timed hot path.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <stdint.h>
 #include <vector>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "../../include/nanomod_hip.h"
+#include "radix_sort.hpp"
 
 namespace nmod {
 
@@ -67,18 +67,13 @@ extern "C" int nmod_rank_order(const nmod_params* prm, int64_t npos, const doubl
     NMOD_RO_HIP(dout.alloc(n * 4));
   }
   NMOD_RO_HIP(ka.alloc(n * 8)); NMOD_RO_HIP(kb.alloc(n * 8)); NMOD_RO_HIP(ia.alloc(n * 4)); NMOD_RO_HIP(ib.alloc(n * 4));
-  size_t tmp_bytes = 0;
-  NMOD_RO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint64_t*)ka.p, (uint64_t*)kb.p, (const uint32_t*)ia.p,
-                                        (uint32_t*)ib.p, n, 0, 64, stream));
-  NMOD_RO_HIP(tmp.alloc(tmp_bytes));
+  NMOD_RO_HIP(tmp.alloc(rs_scratch_bytes((int64_t)n)));
   const unsigned blocks = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
   hipLaunchKernelGGL(rank_iota_kernel, dim3(blocks), dim3(256), 0, stream, (uint32_t*)ia.p, (int64_t)n);
-  uint32_t* cur = (uint32_t*)ia.p; uint32_t* nxt = (uint32_t*)ib.p;
+  uint32_t* cur = (uint32_t*)ia.p;
   for (int k = 0; k < 3; ++k) {
     hipLaunchKernelGGL(rank_keys_kernel, dim3(blocks), dim3(256), 0, stream, keys[k], cur, (int64_t)n, (uint64_t*)ka.p);
-    NMOD_RO_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const uint64_t*)ka.p, (uint64_t*)kb.p, (const uint32_t*)cur, nxt,
-                                          n, 0, 64, stream));
-    uint32_t* t = cur; cur = nxt; nxt = t;
+    NMOD_RO_HIP(rs_sort_pairs((uint64_t*)ka.p, cur, (uint64_t*)kb.p, (uint32_t*)ib.p, (int64_t)n, tmp.p, stream));   // (in place: eight passes)
   }
   int32_t* dst = host ? (int32_t*)dout.p : order_out;
   hipLaunchKernelGGL(rank_emit_kernel, dim3(blocks), dim3(256), 0, stream, cur, (int64_t)n, (int)(descending != 0), dst);
@@ -94,7 +89,7 @@ extern "C" int nmod_rank_order(const nmod_params* prm, int64_t npos, const doubl
 // pk-w .. pk+w tested and below the strand's last position, and is keyed by the `percentile`-th smallest value
 // of its (base-filtered) members, ties broken by |w - index of the window minimum|.  One thread per position
 // computes the key of the window centred there (selection by counting: windows are a few dozen values); the
-// windows are ranked with the same device radix sort as nmod_rank_order; the overlap suppression of WindOvlp == 1
+// windows are ranked with the same device radix sort as nmod_rank_order (radix_sort.hpp); the overlap suppression of WindOvlp == 1
 // (a window is dropped when a better one on the same strand lies closer than w) is a sequential greedy pass on
 // the host over the ranked list, O(w) per window with a per-position flag instead of the reference's scan of
 // everything kept so far.

@@ -1318,6 +1318,24 @@ def test_rank_order_entry_point(nm):
     assert nm.engine.rank_order_host(k1[:0], k2[:0], k3[:0]).tolist() == []
 
 
+@pytest.mark.parametrize('n', [1, 255, 2047, 2048, 2049, 4096 * 3 + 17, 1_300_000])
+def test_rank_order_radix_sort_sizes_and_key_ranges(nm, n):
+    """the hand-written radix sort behind nmod_rank_order (radix_sort.hpp) at its tile boundaries and over many tiles: keys over the
+    whole float64 range (signs, infinities, denormals, NaN last), every byte of the image exercised, long runs of equal keys (stable)"""
+    rng = np.random.default_rng(n)
+    raw = rng.integers(0, 1 << 63, n, dtype=np.int64).view(np.float64)              # random bit patterns: every exponent, NaNs among them
+    raw = np.where(rng.random(n) < 0.5, -raw, raw)
+    k1 = np.where(rng.random(n) < 0.3, np.round(rng.normal(0, 1, n), 0), raw)       # a third: a handful of values, long equal runs
+    k1[rng.random(n) < 0.01] = np.inf; k1[rng.random(n) < 0.01] = -np.inf
+    k2 = rng.integers(0, 3, n).astype(np.float64) * 1e-310                          # denormals
+    k3 = rng.normal(0, 1, n)
+    img = np.where(np.isnan(k1), np.inf, k1)                                         # NaN sorts last, among themselves by the later keys
+    nan = np.isnan(k1).astype(np.int8)
+    exp = np.lexsort((k3, k2, img, nan))                                             # (lexsort: last key is primary; stable)
+    got = nm.engine.rank_order_host(k1, k2, k3)
+    assert np.array_equal(got, exp)
+
+
 @pytest.mark.parametrize('name', ['g50_stouffer', 'ragged_stouffer'])
 def test_rank_order_matches_reference_ranking(nm, name):
     """the device ranking reproduces the reference's sorted_sign_test order on the golden numbers"""

@@ -297,7 +297,7 @@ int nmod_format_probe(const double* v, int64_t n, int32_t sci, char* out, int64_
 /* Replaces the ranking of the result records (myDetect.py:447-462): order_out[i] = index of the i-th record of
  * sorted(records, key = (key_primary, key_second, key_third)) — Python's stable tuple sort, ascending, -0.0 tied
  * with 0.0, NaN last — reversed as a whole when `descending` (rankUse == 'st': the reference reverses the sorted
- * list).  The reference's keys are (combined p, KS p, MWU p) or the three statistics.  Device radix sort (rocPRIM),
+ * list).  The reference's keys are (combined p, KS p, MWU p) or the three statistics.  Device radix sort (radix_sort.hpp),
  * three stable passes; synchronises before returning. */
 int nmod_rank_order(const nmod_params* prm, int64_t npos, const double* key_primary, const double* key_second,
                     const double* key_third, int32_t descending, int32_t* order_out);

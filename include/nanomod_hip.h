@@ -302,6 +302,12 @@ int nmod_format_probe(const double* v, int64_t n, int32_t sci, char* out, int64_
 int nmod_rank_order(const nmod_params* prm, int64_t npos, const double* key_primary, const double* key_second,
                     const double* key_third, int32_t descending, int32_t* order_out);
 
+/* The stable ascending order of n signed 64-bit keys: order_out[i] = index of the i-th smallest key, equal keys in index
+ * order (what numpy.argsort(kind='stable') returns).  keys / order_out: host or device memory by prm->memspace.  Behind the
+ * grouping of events by (chrom, strand, position) that replaces getGenomeEvents' dict inserts for the simulation loops
+ * (mySimulat2.py:127-171; nanomod_amd/simulate.py).  Synchronises before returning. */
+int nmod_argsort_keys(const nmod_params* prm, int64_t n, const int64_t* keys, int32_t* order_out);
+
 /* Replaces the window ranking of --RegionRankbyST 1 (myDetect.py:463-515) on array-shaped records in the
  * reference's record order (sorted (chrom, strand), ascending position).  strand_lo[i] / strand_hi[i]: index of the
  * first / last record of record i's (chrom, strand); value[i]: the p-value or statistic the ranking uses

@@ -81,6 +81,7 @@ _SIGNATURES = {
     'nmod_build_info': (C.c_char_p, []),
     'nmod_downsample_ks': (C.c_int, [C.POINTER(NmodParams), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p]),
+    'nmod_argsort_keys': (C.c_int, [C.POINTER(NmodParams), C.c_int64, C.c_void_p, C.c_void_p]),
     'nmod_describe_dispatch': (C.c_int, [C.POINTER(NmodParams), C.c_int64, C.c_int64, C.c_char_p, C.c_int32]),
     'nmod_write_sign_test': (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_void_p,
                                        C.c_char_p] + [C.c_void_p] * 10 + [C.c_int32]),

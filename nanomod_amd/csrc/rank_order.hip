@@ -83,6 +83,45 @@ extern "C" int nmod_rank_order(const nmod_params* prm, int64_t npos, const doubl
   return NMOD_OK;
 }
 
+// nmod_argsort_keys — the stable ascending order of signed 64-bit keys (one radix sort of their order-preserving images): the
+// grouping of a read pool's events by (chrom, strand, position) key in nanomod_amd/simulate.py (getGenomeEvents,
+// mySimulat2.py:127-171), which used torch.argsort until round 5.
+namespace nmod {
+__global__ __launch_bounds__(256) void argsort_keys_kernel(const int64_t* key, int64_t n, uint64_t* out, uint32_t* idx) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    out[i] = (uint64_t)key[i] ^ 0x8000000000000000ull;
+    idx[i] = (uint32_t)i;
+  }
+}
+}  // namespace nmod
+
+extern "C" int nmod_argsort_keys(const nmod_params* prm, int64_t n, const int64_t* keys, int32_t* order_out) {
+  if (!prm || prm->struct_size != (int32_t)sizeof(nmod_params) || n < 0 || n > INT32_MAX) return NMOD_ERR_INVALID_ARG;
+  if (n == 0) return NMOD_OK;
+  if (!keys || !order_out) return NMOD_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || prm->device < 0 || prm->device >= ndev) return NMOD_ERR_NO_DEVICE;
+  NMOD_RO_HIP(hipSetDevice(prm->device));
+  hipStream_t stream = (hipStream_t)prm->stream;
+  const bool host = prm->memspace == NMOD_MEM_HOST;
+  const size_t cnt = (size_t)n;
+  Buf dk, ka, kb, ia, ib, tmp;
+  const int64_t* src = keys;
+  if (host) {
+    NMOD_RO_HIP(dk.alloc(cnt * 8));
+    NMOD_RO_HIP(hipMemcpyAsync(dk.p, keys, cnt * 8, hipMemcpyHostToDevice, stream));
+    src = (const int64_t*)dk.p;
+  }
+  NMOD_RO_HIP(ka.alloc(cnt * 8)); NMOD_RO_HIP(kb.alloc(cnt * 8)); NMOD_RO_HIP(ia.alloc(cnt * 4)); NMOD_RO_HIP(ib.alloc(cnt * 4));
+  NMOD_RO_HIP(tmp.alloc(rs_scratch_bytes(n)));
+  const unsigned blocks = (unsigned)((cnt + 255) / 256 < 8192 ? (cnt + 255) / 256 : 8192);
+  hipLaunchKernelGGL(argsort_keys_kernel, dim3(blocks), dim3(256), 0, stream, src, n, (uint64_t*)ka.p, (uint32_t*)ia.p);
+  NMOD_RO_HIP(rs_sort_pairs((uint64_t*)ka.p, (uint32_t*)ia.p, (uint64_t*)kb.p, (uint32_t*)ib.p, n, tmp.p, stream));
+  NMOD_RO_HIP(hipMemcpyAsync(order_out, ia.p, cnt * 4, host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, stream));
+  NMOD_RO_HIP(hipStreamSynchronize(stream));          // the temporaries are freed on return
+  return NMOD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // nmod_region_rank — window ranking of --RegionRankbyST 1 (myDetect.py:463-515).
 // A window is centred on a tested position pk = pmin + t * movesize of one (chrom, strand), needs all of

@@ -156,6 +156,17 @@ def rank_order_host(key_primary, key_second, key_third, descending=False, device
     return order
 
 
+def argsort_device(key):
+    """stable ascending order of an int64 CUDA tensor (nmod_argsort_keys: the library's radix sort), as an int64 CUDA tensor"""
+    import torch
+    assert key.is_cuda and key.dtype == torch.int64 and key.is_contiguous()
+    n = key.numel()
+    order = torch.empty(n, dtype=torch.int32, device=key.device)
+    prm = L.make_params(device=key.device.index or 0, memspace=L.MEM_DEVICE, stream=torch.cuda.current_stream(key.device).cuda_stream)
+    L.check(L.load().nmod_argsort_keys(C.byref(prm), n, key.data_ptr(), order.data_ptr()), 'nmod_argsort_keys')
+    return order.to(torch.int64)
+
+
 def region_rank_host(strand_lo, strand_hi, pos, base, value, w, movesize, na, percentile, wind_ovlp, device=0):
     """myDetect.py:463-515 on array-shaped records (see nmod_region_rank): indices of the ranked window centres."""
     lib = L.load()

@@ -74,7 +74,8 @@ def group_events(parts, cs_names):
         k, v, b = _expand(pool, sel, cs_map)
         keys.append(k); vals.append(v); bases.append(b)
     key = torch.cat(keys); val = torch.cat(vals); base = torch.cat(bases)
-    order = torch.argsort(key, stable=True)
+    # (on the device: the library's own radix sort, nmod_argsort_keys; a CPU pool — the tests' — sorts with torch)
+    order = engine.argsort_device(key.contiguous()) if key.is_cuda else torch.argsort(key, stable=True)
     key = key[order]
     ukey, counts = torch.unique_consecutive(key, return_counts=True)
     off = torch.zeros(len(ukey) + 1, dtype=torch.int64, device=dev)

@@ -1336,6 +1336,24 @@ def test_rank_order_radix_sort_sizes_and_key_ranges(nm, n):
     assert np.array_equal(got, exp)
 
 
+def test_argsort_keys_entry_point(nm):
+    """nmod_argsort_keys (the grouping sort of nanomod_amd/simulate.py) against numpy's stable argsort: negative keys, long equal runs,
+    host and device memory"""
+    import torch
+    rng = np.random.default_rng(8)
+    for n in (1, 2049, 700_001):
+        key = rng.integers(-5, 6, n).astype(np.int64) * (1 << 40) + rng.integers(0, 50, n)
+        exp = np.argsort(key, kind='stable')
+        got = nm.engine.argsort_device(torch.from_numpy(key).cuda())
+        assert np.array_equal(got.cpu().numpy(), exp)
+        out = np.empty(n, np.int32)
+        L = nm._lib
+        import ctypes as C
+        prm = L.make_params(memspace=L.MEM_HOST)
+        assert L.load().nmod_argsort_keys(C.byref(prm), n, key.ctypes.data, out.ctypes.data) == 0
+        assert np.array_equal(out, exp)
+
+
 @pytest.mark.parametrize('name', ['g50_stouffer', 'ragged_stouffer'])
 def test_rank_order_matches_reference_ranking(nm, name):
     """the device ranking reproduces the reference's sorted_sign_test order on the golden numbers"""

@@ -845,6 +845,48 @@ def test_device_path_unknown_max_side_stream_and_too_large_hint(nm):
         H.assert_close_p(res4['ks_p'].cpu().numpy()[~over], exp['ks_p'][~over], 1e-9, 'ks_p under the hint')
 
 
+def test_count_wide_device_path_unknown_max_hint_and_workspace_reuse(nm):
+    """the counting form for any coverage through the DEVICE entry: maxima unknown (the library reduces the offsets), a side stream,
+    a max_n hint below some positions (TOO_LARGE there, the rest exact), and one detector (one workspace) running a skewed batch,
+    a 500 v 500-like batch and the skewed one again — stale work lists / gates of the previous batch must not leak; both masks"""
+    import torch
+    import oracle_c
+    L = nm._lib
+    rng = np.random.default_rng(21)
+    P = 500
+    a0 = rng.integers(400, 1500, P); b0 = rng.integers(20, 120, P)
+    a1 = rng.integers(330, 513, P); b1 = rng.integers(330, 513, P)
+    batches = []
+    for a, b in ((a0, b0), (a1, b1)):
+        k0, off0, k1, off1 = _event_rows(rng, a, b, 200)
+        rid = np.zeros(P, np.int32)
+        exp = oracle_c.detect_batch(k0, off0, k1, off1, rid, 2, 2.0, 'stouffer', tests=7)
+        batches.append((k0, off0, k1, off1, rid, exp))
+    t = lambda x: torch.from_numpy(x).to('cuda:0')
+    for tests in (L.TEST_ALL, L.TEST_KS):
+        det = nm.DeviceDetector(0, nb=2, weights_dif=2.0, method='stouffer', tests=tests)
+        for which in (0, 1, 0):
+            k0, off0, k1, off1, rid, exp = batches[which]
+            res = det.run(t(k0), t(k1), t(rid), off0=t(off0), off1=t(off1))                 # maxima unknown
+            torch.cuda.synchronize()
+            assert np.array_equal(res['ks_d'].cpu().numpy(), exp['ks_d'])
+            H.assert_close_p(res['comb_p'].cpu().numpy(), exp['comb_p'], 1e-9, 'comb_p')
+            if tests == L.TEST_ALL:
+                assert np.array_equal(res['mwu_u'].cpu().numpy(), exp['mwu_u'])
+                H.assert_close_p(res['t_p'].cpu().numpy(), exp['t_p'], 1e-9, 't_p')
+        k0, off0, k1, off1, rid, exp = batches[0]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            res = det.run(t(k0), t(k1), t(rid), off0=t(off0), off1=t(off1), max_n0=1000, max_n1=200)      # some groups exceed the hint
+        side.synchronize()
+        n0 = np.diff(off0)
+        big = n0 > 1000
+        st = res['status'].cpu().numpy()
+        assert big.any() and np.all((st[big] & L.STATUS_TOO_LARGE) != 0) and np.all(st[~big] & L.STATUS_TOO_LARGE == 0)
+        assert np.array_equal(res['ks_d'].cpu().numpy()[~big], exp['ks_d'][~big]) and np.all(np.isnan(res['ks_d'].cpu().numpy()[big]))
+
+
 def test_ks_only_large_ranked_group(nm):
     """KS-only mode: only the smaller group of a position is capacity-bound (2048); the other one is ranked,
     not sorted, and may be much larger (cfg5's 4000-read positions)"""

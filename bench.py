@@ -141,7 +141,7 @@ def synth_rows(seed, pos_begin, npos, group, n_per_pos, plant_period, plant_shif
     return v
 
 
-def synth_event_rows(seed, pos_begin, npos, group, n_per_pos, plant_period, plant_shift_milli, spread_milli, i16):
+def synth_event_rows(seed, pos_begin, npos, group, n_per_pos, plant_period, plant_shift_milli, spread_milli, i16, outlier_permille=0):
     """numpy restatement of nmod_synth_fill_events (include/nanomod_hip.h; bit-equal, tests/test_gpu_parity.py) as an
     [npos, n_per_pos] array: a level per position shared by both groups, reads spread around it, on the milli-unit grid."""
     import numpy as np
@@ -164,6 +164,10 @@ def synth_event_rows(seed, pos_begin, npos, group, n_per_pos, plant_period, plan
     if group == 1 and plant_period > 0:
         mm = pos % plant_period
         k = k + np.where((mm == 0) | (mm == 1) | (mm == plant_period - 1), int(plant_shift_milli), 0)
+    if outlier_permille > 0:
+        o = mix(np.uint64(seed) ^ np.uint64(0x0DDBA11C0FFEE123), pos, group, read)
+        hit = ((o >> np.uint64(20)) % np.uint64(1000)).astype(np.int64) < int(outlier_permille)
+        k = np.where(hit, ((o >> np.uint64(32)) % np.uint64(10001)).astype(np.int64) - 5000, k)
     k = np.clip(k, -32767, 32767)
     return k.astype(np.int16) if i16 else (k.astype(np.float64) / 1000.0).astype(np.float32)
 
@@ -190,8 +194,8 @@ def refpy_worker(idx, go, results, cfg):
         else:
             s0 = np.full(block, n0); s1 = np.full(block, n1)
         if cfg.get('spread', 0) > 0:
-            a = synth_event_rows(seed, pos, block, 0, int(s0.max()), PLANT_PERIOD, int(round(PLANT_SHIFT * 1000)), cfg['spread'], i16)
-            b = synth_event_rows(seed, pos, block, 1, int(s1.max()), PLANT_PERIOD, int(round(PLANT_SHIFT * 1000)), cfg['spread'], i16)
+            a = synth_event_rows(seed, pos, block, 0, int(s0.max()), PLANT_PERIOD, int(round(PLANT_SHIFT * 1000)), cfg['spread'], i16, cfg.get('outliers', 0))
+            b = synth_event_rows(seed, pos, block, 1, int(s1.max()), PLANT_PERIOD, int(round(PLANT_SHIFT * 1000)), cfg['spread'], i16, cfg.get('outliers', 0))
         else:
             a = synth_rows(seed, pos, block, 0, int(s0.max()), PLANT_PERIOD, PLANT_SHIFT, i16)
             b = synth_rows(seed, pos, block, 1, int(s1.max()), PLANT_PERIOD, PLANT_SHIFT, i16)
@@ -296,6 +300,7 @@ def cpu_baseline(rows, what, method, tests, threads, target_seconds=12.0, refpy=
         ref_shaped = {'value': npy / dpy, 'unit': 'positions/s', 'cores': 1, 'positions': npy, 'wall_seconds': dpy,
                       'sample': 'oracle/nanomod_oracle.py getKStest + combine per position on the first %d positions, one core' % npy}
     return {'value': sample * reps / dt, 'unit': 'positions/s', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model(),
+            'sample_short': 'first %d positions of the same workload x %d passes, oracle/nanomod_oracle.c (OpenMP, %d threads), %.1f s' % (sample, reps, threads, dt),
             'sample': 'first %d positions of the same workload (%s) x %d passes, oracle/nanomod_oracle.c '
                       'with OpenMP on %d threads (cgroup CPU quota), %.1f s' % (sample, what, reps, threads, dt),
             'one_core': {'value': one / dt1, 'unit': 'positions/s', 'cores': 1,
@@ -574,6 +579,125 @@ def rank_plan(args, world, rank):
             'sample_bytes': samples * sb, 'device_bytes': dev_bytes, 'fits_288GB': bool(dev_bytes < 288e9 * 0.9)}
 
 
+SIDE_FILE_DEFAULT = os.path.join(ROOT, 'bench_side.json')
+LAST_LINE_CAP = 8000            # the driver keeps an 8 KB tail of stdout: the record must fit it whole (target < 4 KB)
+DEFAULT_SIDE_LEGS = ('all_tests', 'int16', 'real_spread', 'outliers', 'presets')
+ALL_SIDE_LEGS = ('all_tests', 'int16', 'rational_d', 'real_ties', 'real_spread', 'real_spread_sweep', 'outliers', 'presets', 'presets_event',
+                 'host_path', 'drop_in')
+
+
+def _sig(x, digits=6):
+    """floats of the compact record carry 6 significant digits (the side file keeps every digit)"""
+    if isinstance(x, float):
+        return float('%.*g' % (digits, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _leg_values(side):
+    """{leg: positions/s} of every measured side leg, nested groups flattened with a dot"""
+    out, ok = {}, True
+    for k, v in side.items():
+        if not isinstance(v, dict):
+            continue
+        if 'value' in v:
+            out[k] = v['value']
+            ok = ok and bool(v.get('verify', {}).get('ok', True))
+        else:
+            for k2, v2 in v.items():
+                if isinstance(v2, dict) and 'value' in v2:
+                    out[k + '.' + k2] = v2['value']
+                    ok = ok and bool(v2.get('verify', {}).get('ok', True))
+    return out, ok
+
+
+def compact_record(full, side, host_path, drop_in, side_file):
+    """The LAST stdout line: the contract's keys + roofline + cpu_baseline + verify, short enough for the driver's 8 KB tail
+    (tests/test_bench_launcher.py pins < 8 000 bytes on a canned full record).  Everything verbose — notes, definitions, every
+    side leg with its own verification — is in `side_legs_file` and on earlier stdout lines of its own."""
+    r = full['roofline']
+    v = full['verify'] or {}
+    errs_p = [v[k] for k in v if k.startswith('max_rel_err_') and k.endswith('_p')]
+    errs_abs_p = [v[k] for k in v if k.startswith('max_abs_err_') and k.endswith('_p')]
+    cb = full.get('cpu_baseline')
+    rec = {k: full[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                'vs_baseline', 'dtype')}
+    rec['data'] = full['data_short']
+    c = full['config']
+    rec['config'] = {k: c[k] for k in ('workload', 'preset', 'positions_total', 'positions_per_gpu', 'n0', 'n1', 'layout', 'ties',
+                                       'spread_milli', 'outlier_permille', 'rccl_ranks') if k in c}
+    rec['config']['ks_d'] = 'rational (NMOD_FLAG_KS_RATIONAL_D)' if 'RATIONAL' in c['ks_d'] else 'float form, bit for bit'
+    rec['config']['parallelism'] = c['parallelism_short']
+    rec['compute_only'] = full['compute_only']['value']
+    if full.get('allgather_exposed_ms'):
+        rec['allgather_exposed_ms_max'] = full['allgather_exposed_ms']['max']
+    rec['roofline'] = {'bound': 'hbm', 'achieved': r['achieved'], 'peak': r['peak'], 'unit': r['unit'], 'frac': r['frac'],
+                       'traffic': r['traffic'], 'traffic_attached_from': r['traffic_source'], 'limited_by': 'valu-issue',
+                       'kernel': r['kernel'], 'kernel_avg_ms': r['kernel_avg_ms'], 'path_avg_ms': r['path_avg_ms'],
+                       'launches_timed': r['launches_timed'], 'algorithmic_bytes_per_position': r['algorithmic_bytes_per_position'],
+                       'positions_per_launch': r['positions_per_launch'], 'measured_copy_GBps': r['measured_copy_GBps']}
+    rec['valu'] = {'instr_per_position': full['valu']['instr_per_position'], 'issue_util': full['valu']['issue_util'],
+                   'attached_from': full['valu']['source']}
+    if full.get('form_share') is not None:
+        rec['form_share'] = full['form_share']
+    rec['verify'] = {'ok': bool(v.get('ok')), 'positions': v.get('positions'), 'against': 'oracle/nanomod_oracle.c, same input',
+                     'max_rel_err_p': max(errs_p) if errs_p else None, 'max_abs_err_p': max(errs_abs_p) if errs_abs_p else None,
+                     'max_abs_err_ks_d': v.get('max_abs_err_ks_d'), 'max_abs_err_mwu_u': v.get('max_abs_err_mwu_u')}
+    for k in ('gathered_track_equals_local', 'block_boundaries_checked', 'block_boundary_positions_differing'):
+        if k in v:
+            rec['verify'][k] = v[k]
+    if cb is not None:
+        rec['cpu_baseline'] = {'value': cb['value'], 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'],
+                               'cpu_model': cb.get('cpu_model'), 'sample': cb['sample_short'],
+                               'one_core': cb['one_core']['value'],
+                               'reference_shaped_python': {'value': cb['reference_shaped_python']['value'],
+                                                           'cores': cb['reference_shaped_python']['cores']}}
+    vals, side_ok = _leg_values(side)
+    if vals:
+        rec['side'] = vals
+        rec['side_verify_ok'] = side_ok
+    if host_path is not None:
+        rec['host_path'] = {k: v_['positions_per_s'] for k, v_ in host_path.items() if isinstance(v_, dict) and 'positions_per_s' in v_}
+        rec['host_path']['pinned_h2d_GBps'] = host_path.get('pinned_h2d_GBps')
+    if drop_in is not None:
+        rec['drop_in_mtest2'] = {k: v_['positions_per_s'] for k, v_ in drop_in.items() if isinstance(v_, dict) and 'positions_per_s' in v_}
+        big = drop_in.get('at_200v200', {}).get('arrays')
+        if big:
+            rec['drop_in_mtest2']['at_200v200'] = big['positions_per_s']
+    rec['side_legs_file'] = side_file
+    rec['leg_seconds'] = full.get('leg_seconds')
+    rec['build_info'] = full['build_info_short']
+    rec['lib_sha16'] = full.get('lib_sha16')
+    rec = _sig(rec)
+    text = json.dumps(rec, separators=(',', ':'))
+    if len(text) >= LAST_LINE_CAP:                                   # never hand the driver a line it cannot keep
+        for k in ('leg_seconds', 'drop_in_mtest2', 'host_path', 'side'):
+            rec.pop(k, None)
+            text = json.dumps(rec, separators=(',', ':'))
+            if len(text) < LAST_LINE_CAP:
+                break
+    return rec, text
+
+
+def short_build_info(info):
+    """'arch=gfx950 abi=3 hip=7.2' + the experiment switches that differ from the shipped setting in any translation unit"""
+    parts = info.split(' | ')
+    head = parts[0]
+    shipped = {'NMOD_SKIP': '0', 'NMOD_EXP': '0', 'NMOD_SWZ_MASK': '0', 'NMOD_PK_SELECT': '0', 'NMOD_CE_BUILTIN': '0', 'NMOD_XOR4_BANKS': '0',
+               'NMOD_NO_GRID': '0', 'NMOD_CNT_SKIP': '0'}
+    odd = set()
+    for tu in parts[1:]:
+        name, _, kv = tu.partition(': ')
+        for item in kv.split():
+            k, _, val = item.partition('=')
+            if k in shipped and val != shipped[k]:
+                odd.add('%s:%s' % (name, item))
+    return head + (' | experiment switches on: ' + ' '.join(sorted(odd)) if odd else ' | experiment switches: none')
+
+
 def emit_line(text):
     """One record = ONE write(2): torch.distributed.run starts its workers with `python -u`, where print() sends the body
     and the newline separately and the lines of different ranks interleave on the shared pipe."""
@@ -641,6 +765,10 @@ def main():
                     help='real: signals on the 3-decimal grid of NanoMod events (myRefBaseSignalAnnotation.py:1108)')
     ap.add_argument('--spread', type=int, default=0, help='event-like rows (nmod_synth_fill_events): a level per position in +-3 units, reads spread '
                     'SPREAD milli-units around it, on the 3-decimal grid (most samples of a position tie); 0 = the unit-variance generator')
+    ap.add_argument('--outliers', type=int, default=0, help='with --spread: this many reads per 1 000 are mis-segmented events, a uniform draw over +-5 units '
+                    '(the clip range of the raw normalisation, myRefBaseSignalAnnotation.py:251-259)')
+    ap.add_argument('--no-counting', action='store_true', help='NMOD_FLAG_NO_COUNTING: every position on the sorting forms (A/B; also env NMOD_NO_COUNTING=1, read here, not by the library)')
+    ap.add_argument('--no-count-wide', action='store_true', help='NMOD_FLAG_NO_COUNT_WIDE (also env NMOD_NO_COUNT_WIDE=1)')
     ap.add_argument('--strong', action='store_true', help='fixed total size: --positions in total, split over the ranks')
     ap.add_argument('--chunks', type=int, default=0, help='rounds of the block-cyclic pipeline (default 4 for N>1, 1 for N=1)')
     ap.add_argument('--force-collective', action='store_true', help='N=1: initialise RCCL with one rank and issue the all-gather anyway')
@@ -650,7 +778,10 @@ def main():
     ap.add_argument('--refpy-seconds', type=float, default=6.0, help='reference-shaped Python CPU leg: at least this many seconds per process')
     ap.add_argument('--no-side', '--no-real-ties', dest='no_side', action='store_true',
                     help='skip the side measurements of the default run (all tests, int16, rational D, tie-heavy input)')
-    ap.add_argument('--side-legs', default='all', help='comma list of side measurements to run (all_tests,int16,rational_d,real_ties,real_spread,presets,drop_in); default all')
+    ap.add_argument('--side-legs', default='default', help='comma list of side measurements to run, `default` (%s) or `all` (%s)'
+                    % (','.join(DEFAULT_SIDE_LEGS), ','.join(ALL_SIDE_LEGS)))
+    ap.add_argument('--side-file', default=SIDE_FILE_DEFAULT, help='where the side legs (each also a stdout line of its own) and the verbose form '
+                    'of the record are written; the last stdout line names it')
     ap.add_argument('--no-host-path', action='store_true', help='skip the host-resident (NMOD_MEM_HOST, PCIe-bound) measurement')
     ap.add_argument('--rational-d', action='store_true', help='KS-only configurations: time NMOD_FLAG_KS_RATIONAL_D (D as the exact rational, <= 2 ulp '
                     'from ks_2samp\'s float form) instead of the library default (D bit for bit); the default run reports this rate as a side figure')
@@ -677,7 +808,7 @@ def main():
         pz = PRESETS[args.config]
         at = bool(args.all_tests or pz['all_tests'])
         refpy = start_refpy_workers({'seed': SEED, 'n0': args.n0 or pz['n0'], 'n1': args.n1 or pz['n1'], 'csr': pz['layout'] == 'csr',
-                                     'i16': args.dtype == 'i16', 'method': 'fisher' if at else 'stouffer', 'pos_begin': 0, 'spread': args.spread,
+                                     'i16': args.dtype == 'i16', 'method': 'fisher' if at else 'stouffer', 'pos_begin': 0, 'spread': args.spread, 'outliers': args.outliers,
                                      'stride': 1_000_000, 'min_positions': args.refpy_positions, 'max_positions': 50 * args.refpy_positions,
                                      'budget_s': args.refpy_seconds, 'workload_positions': args.positions or pz['positions']}, usable_cpus())
 
@@ -687,6 +818,8 @@ def main():
     from nanomod_amd import sharding
     L = nm._lib
 
+    form_flags = (L.FLAG_NO_COUNTING if (args.no_counting or os.environ.get('NMOD_NO_COUNTING', '0') not in ('', '0')) else 0) | \
+                 (L.FLAG_NO_COUNT_WIDE if (args.no_count_wide or os.environ.get('NMOD_NO_COUNT_WIDE', '0') not in ('', '0')) else 0)
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
     dist = None
@@ -715,19 +848,21 @@ def main():
     # opt-out (include/nanomod_hip.h: NMOD_FLAG_KS_RATIONAL_D, KS-only mode), which the default run reports as a side figure
     rational_d = (not all_tests) and args.rational_d
     det = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests,
-                            flags=L.FLAG_KS_RATIONAL_D if rational_d else 0)
+                            flags=(L.FLAG_KS_RATIONAL_D if rational_d else 0) | form_flags)
     d_gate = [KS_D_RATIONAL_ABS if rational_d else 0.0]
 
-    def fill(b, ties, spread=None, keys=('sig0', 'sig1')):
+    def fill(b, ties, spread=None, keys=('sig0', 'sig1'), outliers=None):
         """(re)generate a block's samples on the device from global position counters.  ties == 'real': the int16
         milli-unit grid (float32 input: k / 1000 as float32 — equal k <=> equal value).  spread > 0: event-like rows
         (nmod_synth_fill_events: a level per position, reads spread around it, on the grid)."""
         spread = args.spread if spread is None else spread
+        outliers = args.outliers if outliers is None else outliers
         for g, key in ((0, keys[0]), (1, keys[1])):
             dst = b[key]
             if spread > 0:
                 det.synth_fill_events(dst, SEED, b['lo_h'], b['n'], g, n_per_pos=0 if csr else (n0, n1)[g], off=b['off%d' % g] if csr else None,
-                                      plant_period=PLANT_PERIOD, plant_shift_milli=int(round(PLANT_SHIFT * 1000)), spread_milli=spread)
+                                      plant_period=PLANT_PERIOD, plant_shift_milli=int(round(PLANT_SHIFT * 1000)), spread_milli=spread,
+                                      outlier_permille=outliers)
                 continue
             grid = ties == 'real' and dst.dtype == torch.float32
             tgt = torch.empty(dst.numel(), dtype=torch.int16, device=dev) if grid else dst
@@ -875,10 +1010,18 @@ def main():
         v['ok'] = bool(ok)
         return v
 
+    def form_share(st):
+        """which K1 form took the positions of a pass (nmod_last_dispatch_stats), as shares of the batch"""
+        n = max(st['positions'], 1)
+        out = {k: round(st[k] / n, 6) for k in ('ks_rank', 'rank_hist', 'rank_hist_wide', 'rank_pair', 'rank_count', 'rank_count_wide', 'big', 'skipped') if st[k]}
+        out['counting_rejected'] = round(st['count_rejected'] / n, 6)
+        return out
+
     # ---- one untimed pass, checked on rank 0 against the CPU oracle on a bounded sample of the same input
     step(gather)
     state.wait()
     torch.cuda.synchronize()
+    headline_share = form_share(det.dispatch_stats())          # (of the pass's last block)
     verify = None
     cpu_rows = None
     mean_n = samples_local / max(n_local, 1)
@@ -969,18 +1112,19 @@ def main():
         copy_gbs = 2 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
-    # ---- side measurements of the default run (N = 1): the same step, 10 timed steps each, every one checked against the
-    # oracle on 20 000 positions before it is timed
+    # ---- side measurements of the default run (N = 1): the same step, up to 10 timed steps each, every one checked against the
+    # oracle on 20 000 positions before it is timed; `form_share`: which K1 form took the positions (nmod_last_dispatch_stats)
     def side_leg(det_x, sig_keys, outs, leg_all, leg_method, gate, note):
         def run_once():
             for b in blocks:
                 det_x.run(b[sig_keys[0]], b[sig_keys[1]], b['rid'], stride0=n0, stride1=n1, npos=b['n'], out=outs)
         run_once(); torch.cuda.synchronize()
+        share = form_share(det_x.dispatch_stats())
         cap = min(20_000, blocks[0]['n'])
         o0 = np.arange(0, (cap + 1) * n0, n0, dtype=np.int64); o1 = np.arange(0, (cap + 1) * n1, n1, dtype=np.int64)
         rows = (blocks[0][sig_keys[0]][:cap * n0].cpu().numpy(), o0, blocks[0][sig_keys[1]][:cap * n1].cpu().numpy(), o1)
         v = verify_against_oracle(rows, cap, outs, leg_all, leg_method, gate)
-        for _ in range(3):
+        for _ in range(2):
             run_once()
         tm = nm.EventTimer(64)
         det_x.timer = tm
@@ -1001,19 +1145,42 @@ def main():
             print('bench.py: verification of a side measurement FAILED (%s): %r' % (note, v), file=sys.stderr)
         return {'value': total * ks / el, 'unit': 'positions/s', 'steps': ks, 'ms_per_step': el / ks * 1e3,
                 'kernel_avg_ms': k1 / max(kn, 1), 'algorithmic_bytes_per_position': algo_leg,
-                'roofline_frac': gbs / HBM_PEAK_GBS, 'achieved_GBps': gbs, 'note': note, 'verify': v}
+                'roofline_frac': gbs / HBM_PEAK_GBS, 'achieved_GBps': gbs, 'form_share': share, 'note': note, 'verify': v}
 
-    side = {}
-    legs = set(args.side_legs.split(',')) if args.side_legs != 'all' else {'all_tests', 'int16', 'rational_d', 'real_ties', 'real_spread', 'presets', 'drop_in'}
+    leg_seconds = {}
+
+    class SideLegs(dict):
+        """a finished side leg is a stdout line of its own at once (a crash later in the run does not lose it) and an entry of the side file"""
+        def __setitem__(self, k, v):
+            dict.__setitem__(self, k, v)
+            if rank == 0:
+                emit_line(json.dumps({'side_leg': k, 'record': v}))
+
+    side = SideLegs()
+    legs = set(ALL_SIDE_LEGS) if args.side_legs == 'all' else set(DEFAULT_SIDE_LEGS) if args.side_legs == 'default' else set(args.side_legs.split(','))
+    if 'real_spread_sweep' in legs:
+        legs.add('real_spread')
+    if 'presets_event' in legs:
+        legs.add('presets')
+    t_leg = [time.perf_counter()]
+
+    def leg_done(name):
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        leg_seconds[name] = round(now - t_leg[0], 2)
+        t_leg[0] = now
+
+    leg_done('headline')
     simple = world == 1 and not csr and not args.force_collective and not args.no_side and chunks == 1
     headline_default = simple and args.config == 'ecoli' and args.dtype == 'f32' and args.ties == 'few' and not all_tests and args.spread == 0
     if headline_default and 'all_tests' in legs:
         # (a) all three tests + Fisher on the same buffers: what every real getKStest call computes (myDetect.py:331-343), BASELINE configs[2]
-        det_all = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method='fisher', tests=L.TEST_ALL)
+        det_all = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method='fisher', tests=L.TEST_ALL, flags=form_flags)
         outs_all = det_all.alloc_outputs(blocks[0]['n'])
         side['all_tests'] = side_leg(det_all, ('sig0', 'sig1'), outs_all, True, 'fisher', 0.0,
                                      'BASELINE configs[2] on the same buffers: KS + MWU + Welch-t per position + Fisher window=5 (rank_hist_kernel)')
         del outs_all
+        leg_done('all_tests')
     if headline_default and 'int16' in legs:
         # (b) the same rows as int16 milli-units, the format of real events (myRefBaseSignalAnnotation.py:1108): 844 B / position
         for b in blocks:
@@ -1025,12 +1192,14 @@ def main():
                                  'the same generator as int16 milli-units (844 algorithmic bytes per position): ks_rank_kernel<16,16,i16>, packed v_pk_min/max_i16 sort')
         for b in blocks:
             del b['q0'], b['q1']
+        leg_done('int16')
     if headline_default and 'rational_d' in legs and not rational_d:
         # (c) NMOD_FLAG_KS_RATIONAL_D: D as the correctly rounded rational (<= 2 ulp from ks_2samp's float form) — an opt-out no
         # reference-shaped entry point uses; rounds 1-3 quoted this rate as the headline
-        det_r = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests, flags=L.FLAG_KS_RATIONAL_D)
+        det_r = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests, flags=L.FLAG_KS_RATIONAL_D | form_flags)
         side['rational_d'] = side_leg(det_r, ('sig0', 'sig1'), blocks[0]['out'], False, method, KS_D_RATIONAL_ABS,
                                       'flags = NMOD_FLAG_KS_RATIONAL_D (skips the float-form pass of D; gate 4.5e-16); the headline of BENCH_r01..r03')
+        leg_done('rational_d')
     if simple and args.ties == 'few' and args.spread == 0 and args.dtype == 'f32' and args.config in ('ecoli', 'alltests') and 'real_ties' in legs:
         # (d) tie-heavy input (real NanoMod events are 3-decimal values): the buffers are refilled in place — last, nothing
         # after this leg sees the headline's rows
@@ -1040,61 +1209,91 @@ def main():
                                      'the same generator on the 3-decimal grid (round(1000 x) / 1000 as float32): ties between and inside the groups as in real events')
         for b in blocks:
             fill(b, args.ties)
-    if headline_default and 'real_spread' in legs:
+        leg_done('real_ties')
+    if headline_default and ('real_spread' in legs or 'outliers' in legs):
         # (e) event-like rows: a signal level per position (+-3 units, both groups), reads spread sigma around it, 3-decimal grid —
-        # most samples of a position tie with another one.  All three tests (what getKStest runs on every position) at
-        # sigma = 0.1 / 0.2 / 0.4 as float32 and as int16 milli-units, KS + Stouffer at 0.2; each pass checked against the oracle
-        det_all = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method='fisher', tests=L.TEST_ALL)
+        # most samples of a position tie with another one.  All three tests (what getKStest runs on every position) and KS + Stouffer
+        # at sigma = 0.2 as float32 and as int16 milli-units (`real_spread_sweep`: sigma = 0.1 and 0.4 as well); `outliers`: the same
+        # rows with 1 and 10 reads per 1 000 replaced by a uniform draw over +-5 units (mis-segmented events).  Each pass is checked
+        # against the oracle and says which K1 form took its positions
+        det_all = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method='fisher', tests=L.TEST_ALL, flags=form_flags)
         outs_all = det_all.alloc_outputs(blocks[0]['n'])
         det_q = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=method, tests=tests, flags=det.flags)
         for b in blocks:
             b['q0'] = torch.empty(b['n'] * n0, dtype=torch.int16, device=dev); b['q1'] = torch.empty(b['n'] * n1, dtype=torch.int16, device=dev)
         rs = {'note': 'nmod_synth_fill_events: level(position) in +-3 units shared by both groups, reads spread sigma around it, values on the '
                       '3-decimal grid of stored events (myRefBaseSignalAnnotation.py:1108); the same 4.6 M x 200 v 200 positions'}
-        for sg in (200, 100, 400):
+        ol = {'note': 'the event-like rows at sigma = 0.2 with N reads per 1 000 replaced by a uniform draw over +-5 units (the clip range of the raw '
+                      'normalisation, myRefBaseSignalAnnotation.py:251-259): what a counting form does with samples outside its window'}
+        plan = []
+        if 'real_spread' in legs:
+            plan += [(sg, 0) for sg in ((200, 100, 400) if 'real_spread_sweep' in legs else (200,))]
+        if 'outliers' in legs:
+            plan += [(200, 1), (200, 10)]
+        for sg, outl in plan:
             for b in blocks:
-                fill(b, 'few', sg); fill(b, 'few', sg, ('q0', 'q1'))
-            tag = 'sigma_0.%d' % (sg // 100)
-            rs['all_tests_f32_' + tag] = side_leg(det_all, ('sig0', 'sig1'), outs_all, True, 'fisher', 0.0, 'all three tests + Fisher, float32 rows, sigma = %.1f' % (sg / 1000))
-            rs['all_tests_i16_' + tag] = side_leg(det_all, ('q0', 'q1'), outs_all, True, 'fisher', 0.0, 'all three tests + Fisher, int16 milli-unit rows, sigma = %.1f' % (sg / 1000))
-            if sg == 200:
-                rs['ks_f32_' + tag] = side_leg(det, ('sig0', 'sig1'), blocks[0]['out'], False, method, d_gate[0], 'KS + Stouffer, float32 rows, sigma = 0.2')
-                rs['ks_i16_' + tag] = side_leg(det_q, ('q0', 'q1'), blocks[0]['out'], False, method, d_gate[0], 'KS + Stouffer, int16 milli-unit rows, sigma = 0.2')
-        side['real_spread'] = rs
+                fill(b, 'few', sg, outliers=outl); fill(b, 'few', sg, ('q0', 'q1'), outliers=outl)
+            tag = 'sigma_0.%d' % (sg // 100) if not outl else '%d_permille' % outl
+            dst = ol if outl else rs
+            what = 'sigma = %.1f' % (sg / 1000) + (', %d per mille outliers' % outl if outl else '')
+            dst['all_tests_f32_' + tag] = side_leg(det_all, ('sig0', 'sig1'), outs_all, True, 'fisher', 0.0, 'all three tests + Fisher, float32 rows, ' + what)
+            dst['all_tests_i16_' + tag] = side_leg(det_all, ('q0', 'q1'), outs_all, True, 'fisher', 0.0, 'all three tests + Fisher, int16 milli-unit rows, ' + what)
+            if sg == 200 and not outl:
+                dst['ks_f32_' + tag] = side_leg(det, ('sig0', 'sig1'), blocks[0]['out'], False, method, d_gate[0], 'KS + Stouffer, float32 rows, sigma = 0.2')
+                dst['ks_i16_' + tag] = side_leg(det_q, ('q0', 'q1'), blocks[0]['out'], False, method, d_gate[0], 'KS + Stouffer, int16 milli-unit rows, sigma = 0.2')
+        if 'real_spread' in legs:
+            side['real_spread'] = rs
+        if 'outliers' in legs:
+            side['outliers'] = ol
         del outs_all
         for b in blocks:
             del b['q0'], b['q1']
             fill(b, args.ties)
-    if side:
+        leg_done('real_spread+outliers')
+    if len(side):
         step(False); state.wait(); torch.cuda.synchronize()     # the headline's outputs are back for what follows
 
     # ---- the other BASELINE configurations at their per-GPU size, a few timed steps each (configs[3]: one GPU's share of chr20;
     # configs[4]: the ragged stress, KS + Stouffer and all three tests): every BASELINE config gets a number in the default run
-    def preset_leg(name, leg_all, steps, spread=0, i16=False, positions=None):
+    ragged_cache = {}
+
+    def preset_rows(name, P):
+        """sizes / offsets of a preset's rows (host + device), made once per run: 10 M ragged sizes are a second of numpy each"""
+        if (name, P) not in ragged_cache:
+            hoff, doff = [None, None], [None, None]
+            for g in (0, 1):
+                sz = ragged_sizes(SEED, 0, P, g)
+                hoff[g] = np.zeros(P + 1, np.int64)
+                np.cumsum(sz, out=hoff[g][1:])
+                doff[g] = torch.from_numpy(hoff[g]).to(dev)
+            ragged_cache[(name, P)] = (hoff, doff)
+        return ragged_cache[(name, P)]
+
+    def preset_leg(name, leg_all, steps, spread=0, i16=False, positions=None, outliers=0):
         pz = PRESETS[name]
         csr_ = pz['layout'] == 'csr'
         P, m0, m1 = positions or pz['positions'], pz['n0'], pz['n1']
         leg_method = 'fisher' if leg_all else 'stouffer'
         tdt = torch.int16 if i16 else torch.float32
         shift_m = int(round(PLANT_SHIFT * 1000))
-        det_x = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=leg_method, tests=L.TEST_ALL if leg_all else L.TEST_KS)
+        det_x = nm.DeviceDetector(local_rank, nb=NB, weights_dif=WDIF, method=leg_method, tests=L.TEST_ALL if leg_all else L.TEST_KS, flags=form_flags)
         rid_x = torch.zeros(P, dtype=torch.int32, device=dev)
         sig, hoff, doff = [None, None], [None, None], [None, None]
+        if csr_:
+            hoff, doff = preset_rows(name, P)
         for g in (0, 1):
             if csr_:
-                sz = ragged_sizes(SEED, 0, P, g)
-                hoff[g] = np.zeros(P + 1, np.int64)
-                np.cumsum(sz, out=hoff[g][1:])
-                doff[g] = torch.from_numpy(hoff[g]).to(dev)
                 sig[g] = torch.empty(int(hoff[g][-1]), dtype=tdt, device=dev)
                 if spread:
-                    det_x.synth_fill_events(sig[g], SEED, 0, P, g, n_per_pos=0, off=doff[g], plant_period=PLANT_PERIOD, plant_shift_milli=shift_m, spread_milli=spread)
+                    det_x.synth_fill_events(sig[g], SEED, 0, P, g, n_per_pos=0, off=doff[g], plant_period=PLANT_PERIOD, plant_shift_milli=shift_m, spread_milli=spread,
+                                            outlier_permille=outliers)
                 else:
                     det_x.synth_fill_csr(sig[g], SEED, 0, doff[g], g, PLANT_PERIOD, PLANT_SHIFT)
             else:
                 sig[g] = torch.empty(P * (m0, m1)[g], dtype=tdt, device=dev)
                 if spread:
-                    det_x.synth_fill_events(sig[g], SEED, 0, P, g, n_per_pos=(m0, m1)[g], plant_period=PLANT_PERIOD, plant_shift_milli=shift_m, spread_milli=spread)
+                    det_x.synth_fill_events(sig[g], SEED, 0, P, g, n_per_pos=(m0, m1)[g], plant_period=PLANT_PERIOD, plant_shift_milli=shift_m, spread_milli=spread,
+                                            outlier_permille=outliers)
                 else:
                     det_x.synth_fill(sig[g], SEED, 0, P, g, (m0, m1)[g], PLANT_PERIOD, PLANT_SHIFT)
         outs = det_x.alloc_outputs(P)
@@ -1105,6 +1304,7 @@ def main():
             else:
                 det_x.run(sig[0], sig[1], rid_x, stride0=m0, stride1=m1, npos=P, out=outs)
         run_once(); torch.cuda.synchronize()
+        share = form_share(det_x.dispatch_stats())
         vn = 5_000 if csr_ else 20_000
         if csr_:
             o0, o1 = hoff[0][:vn + 1], hoff[1][:vn + 1]
@@ -1130,20 +1330,24 @@ def main():
             verify['ok'] = False
             print('bench.py: verification of the %s leg FAILED: %r' % (name, v), file=sys.stderr)
         return {'value': P * steps / el, 'unit': 'positions/s', 'steps': steps, 'ms_per_step': el / steps * 1e3, 'positions': P,
-                'workload': '%s, %s, %s%s' % (pz['name'], 'KS + MWU + Welch-t + Fisher' if leg_all else 'KS + weighted Stouffer', 'int16 milli-units' if i16 else 'float32',
-                                              (', event-like rows (sigma = %.1f)' % (spread / 1000)) if spread else ''),
+                'workload': '%s, %s, %s%s%s' % (pz['name'], 'KS + MWU + Welch-t + Fisher' if leg_all else 'KS + weighted Stouffer', 'int16 milli-units' if i16 else 'float32',
+                                                (', event-like rows (sigma = %.1f)' % (spread / 1000)) if spread else '',
+                                                (', %d per mille outliers' % outliers) if outliers else ''),
                 'mean_reads': [mean0_, mean1_], 'k1_ms_per_step': k1 / steps, 'algorithmic_bytes_per_position': algo_leg,
-                'achieved_GBps': gbs, 'roofline_frac': gbs / HBM_PEAK_GBS, 'verify': v}
+                'achieved_GBps': gbs, 'roofline_frac': gbs / HBM_PEAK_GBS, 'form_share': share, 'verify': v}
 
     # ---- the host-resident entry on the same rows (NMOD_MEM_HOST): PCIe-bound, its own roofline
     host_path = None
-    if world == 1 and not csr and not args.no_host_path and chunks == 1 and not args.force_collective:
+    if world == 1 and not csr and not args.no_host_path and chunks == 1 and not args.force_collective and ('host_path' in legs or not headline_default):
         host_path = host_path_leg(nm, torch, local_rank, blocks, n0, n1, NB, WDIF, method, tests,
                                   want_i16=(args.dtype == 'f32'), ref_out=blocks[0]['out'], flags=det.flags)
         bad = [k for k, v in host_path.items() if isinstance(v, dict) and (v.get('equals_device_resident_pass') is False or v.get('equals_int16_pass') is False)]
         if bad:
             verify['ok'] = False
             print('bench.py: the host-resident entry differs from the device-resident pass: %r' % bad, file=sys.stderr)
+        if rank == 0:
+            emit_line(json.dumps({'side_leg': 'host_path', 'record': host_path}))
+        leg_done('host_path')
 
     # ---- the function-level drop-in on the reference's dict shape (host glue + PCIe + kernels + table), a tenth of E. coli
     drop_in = None
@@ -1157,6 +1361,9 @@ def main():
         if not all(v['verify_ok'] for v in flat):
             verify['ok'] = False
             print('bench.py: the drop-in mtest2 leg differs from the oracle: %r' % drop_in, file=sys.stderr)
+        if rank == 0:
+            emit_line(json.dumps({'side_leg': 'drop_in_mtest2', 'record': drop_in}))
+        leg_done('drop_in')
 
     # (after the host-resident leg: freeing the presets' 79 GB of device memory slows the PCIe copies that follow for a while —
     # 0.77 instead of 0.95 of the pinned rate when the order is reversed)
@@ -1165,20 +1372,32 @@ def main():
         torch.cuda.empty_cache()
         side['ragged'] = preset_leg('ragged', False, 3)
         torch.cuda.empty_cache()
-        side['ragged_all_tests'] = preset_leg('ragged', True, 3)
-        torch.cuda.empty_cache()
-        # the same shapes on event-like rows (sigma = 0.2), all three tests — what getKStest computes on stored events at real, ragged
-        # coverage: the counting form for any coverage (rank_count_wide_kernel) where the device-side probe accepts a class
-        if 'real_spread' in legs:
-            ev = {'note': 'nmod_synth_fill_events, sigma = 0.2; the ragged preset (~1 131 v ~57) and the chr20 shape (500 v 500); all three tests + Fisher, and (_ks_) KS + Stouffer'}
-            for nm_, kw in (('ragged_i16', dict(name='ragged', i16=True)), ('ragged_f32', dict(name='ragged', i16=False)),
+        leg_done('presets')
+        # configs[4] on event-like int16 rows (sigma = 0.2), all three tests — what getKStest computes on stored events at real, ragged
+        # coverage: the counting form for any coverage where the device-side probe accepts a class — clean and with 1 / 10 per mille outliers
+        if 'outliers' in legs or 'presets_event' in legs:
+            ev = {'note': 'nmod_synth_fill_events, sigma = 0.2, on the ragged preset (~1 131 v ~57), all three tests + Fisher; N per mille of the reads replaced by outliers over +-5 units'}
+            for outl in (0, 1, 10):
+                ev['ragged_i16_%d_permille' % outl] = preset_leg('ragged', True, 3, spread=200, i16=True, outliers=outl)
+                torch.cuda.empty_cache()
+            side['ragged_event_outliers'] = ev
+            leg_done('ragged_event_outliers')
+        if 'presets_event' in legs:
+            side['ragged_all_tests'] = preset_leg('ragged', True, 3)
+            torch.cuda.empty_cache()
+            ev = {'note': 'nmod_synth_fill_events, sigma = 0.2; the ragged preset (~1 131 v ~57) and the chr20 shape (500 v 500); all three tests + Fisher, and (_ks_) KS + Stouffer; '
+                          '_1pm / _10pm: with 1 / 10 per mille outliers'}
+            for nm_, kw in (('ragged_f32', dict(name='ragged', i16=False)), ('ragged_f32_1pm', dict(name='ragged', i16=False, outliers=1)),
+                            ('ragged_f32_10pm', dict(name='ragged', i16=False, outliers=10)),
                             ('chr20_i16', dict(name='chr20', i16=True)), ('chr20_f32', dict(name='chr20', i16=False)),
                             # ... and the presets' own mask, KS + Stouffer (the form without the tie term and the moments)
                             ('ragged_ks_i16', dict(name='ragged', i16=True, ks=True)), ('chr20_ks_i16', dict(name='chr20', i16=True, ks=True)),
                             ('chr20_ks_f32', dict(name='chr20', i16=False, ks=True))):
-                ev[nm_] = preset_leg(kw['name'], not kw.get('ks', False), 3, spread=200, i16=kw['i16'])
+                ev[nm_] = preset_leg(kw['name'], not kw.get('ks', False), 3, spread=200, i16=kw['i16'], outliers=kw.get('outliers', 0))
                 torch.cuda.empty_cache()
             side['real_spread_presets'] = ev
+            leg_done('presets_event')
+    ragged_cache.clear()
 
     line = None
     if rank == 0:
@@ -1201,7 +1420,7 @@ def main():
         kbuf = ctypes.create_string_buffer(128)
         L.check(L.load().nmod_describe_dispatch(ctypes.byref(prm), n0, n1, kbuf, 128), 'nmod_describe_dispatch')
         shape = 'ragged' if csr else '%dv%d' % (n0, n1)
-        key = '%s_%s_%s_%d%s' % ('all' if all_tests else 'ks', args.dtype, shape, int(pos_per_launch), ('_realties' if args.ties == 'real' else '') + ('_spread%d' % args.spread if args.spread else '') + ('_rationald' if rational_d else ''))
+        key = '%s_%s_%s_%d%s' % ('all' if all_tests else 'ks', args.dtype, shape, int(pos_per_launch), ('_realties' if args.ties == 'real' else '') + ('_spread%d' % args.spread if args.spread else '') + ('_outl%d' % args.outliers if args.outliers else '') + ('_rationald' if rational_d else ''))
         rec = profile_record(L.LIB_PATH, key) or {}
         tests_txt = 'KS + MWU + Welch-t + Fisher window=%d' % (2 * NB + 1) if all_tests else 'KS + weighted Stouffer window=%d' % (2 * NB + 1)
         reads_txt = ('n0 ~ LogNormal(ln 1000, 0.5) in [5, 4000], n1 ~ LogNormal(ln 50, 0.5) in [5, 400] (means %.0f v %.0f), CSR'
@@ -1222,6 +1441,8 @@ def main():
                                    % (preset['name'], ' x %d' % world if (world > 1 and not args.strong) else '', total, total // world, reads_txt, tests_txt),
                        'preset': args.config, 'positions_total': total, 'positions_per_gpu': total // world, 'n0': n0, 'n1': n1,
                        'layout': 'csr' if csr else 'fixed stride', 'neighborPvalues': NB, 'WeightsDif': WDIF, 'ties': args.ties, 'spread_milli': args.spread,
+                       'outlier_permille': args.outliers, 'flags': det.flags,
+                       'parallelism_short': ('block-cyclic position shards x%d, %d rounds, +-%d halo, async RCCL all-gather per round' % (world, chunks, NB)) if gather else 'one GPU, no collective',
                        'ks_d': ('exact rational max|c0 n1 - c1 n0| / (n0 n1), correctly rounded (NMOD_FLAG_KS_RATIONAL_D; <= 2 ulp from '
                                 'ks_2samp\'s float form, gate 4.5e-16)') if rational_d else
                                'ks_2samp\'s float form bit for bit (library default, flags = 0)',
@@ -1261,16 +1482,21 @@ def main():
                      'source': rec.get('source') if rec.get('valu_instr_per_position') is not None else None,
                      'note': 'rocprofv3 SQ_INSTS_VALU / positions and SQ_ACTIVE_INST_VALU x 4 / SIMD cycles of the K1 kernel, taken '
                              'with this library binary (null: this binary has not been profiled)'},
+            'form_share': headline_share,
             'verify': verify,
             'build_info': L.load().nmod_build_info().decode(),
         }
-        line.update(side)
-        if host_path is not None:
-            line['host_path'] = host_path
-        if drop_in is not None:
-            line['drop_in_mtest2'] = drop_in
+        line['data_short'] = ('synthetic event-like rows, sigma %.1f, %d per mille outliers, 3-decimal grid' % (args.spread / 1000, args.outliers)) if args.spread else \
+                             ('synthetic Irwin-Hall(4) stand-in for N(0,1)%s, +0.8 shift planted every 10 000 positions' % (' on the 3-decimal grid' if args.ties == 'real' else ''))
+        line['build_info_short'] = short_build_info(line['build_info'])
+        try:
+            line['lib_sha16'] = hashlib.sha256(open(L.LIB_PATH, 'rb').read()).hexdigest()[:16]
+        except OSError:
+            line['lib_sha16'] = None
         if not args.no_cpu and world == 1:           # the CPU baseline is an N=1 figure
             line['cpu_baseline'] = cpu_baseline(cpu_rows, '%s, %s' % (reads_txt, tests_txt), method, 7 if all_tests else 1, usable_cpus(), refpy=refpy)
+            leg_done('cpu_baseline')
+        line['leg_seconds'] = leg_seconds
     ok = torch.tensor([1 if (rank != 0 or verify['ok']) else 0], device=dev)
     if dist is not None:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -1284,7 +1510,24 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        emit_line(json.dumps(line))
+        # the verbose record and every side leg go to the side file (each leg was a stdout line of its own when it finished); the LAST
+        # stdout line is the compact record the driver parses
+        full = dict(line)
+        full['side_legs'] = dict(side)
+        if host_path is not None:
+            full['host_path'] = host_path
+        if drop_in is not None:
+            full['drop_in_mtest2'] = drop_in
+        side_file = args.side_file
+        try:
+            with open(side_file, 'w') as f:
+                json.dump(full, f, indent=1)
+        except OSError as e:
+            print('bench.py: could not write %s: %s' % (side_file, e), file=sys.stderr)
+            side_file = None
+        rel = os.path.relpath(side_file, ROOT) if side_file else None
+        rec_, text = compact_record(line, side, host_path, drop_in, rel)
+        emit_line(text)
     if int(ok.item()) == 0:
         sys.exit(3)                                  # a numerically wrong build must not look like a benchmark record
 

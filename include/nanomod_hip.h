@@ -12,11 +12,10 @@
  * large-position pass is allocated stream-ordered (freed slabs stay cached in
  * that pool until nmod_trim_scratch(); the device's default pool is not touched),
  * and the four tunables of nmod_host_pipeline_config (atomics; they change how a
- * host-resident batch is chunked and copied, never a result).  Two environment
- * switches, read once per process, choose between kernel forms that produce
- * the same numbers (A/B measurements): NMOD_NO_COUNTING=1 keeps event-like rows
- * on the sorting forms, NMOD_NO_COUNT_WIDE=1 only those outside the
- * 256-capacity class.
+ * host-resident batch is chunked and copied, never a result).  The library
+ * reads no environment variable that changes which kernel runs: the choice
+ * between kernel forms that produce the same numbers is per call
+ * (NMOD_FLAG_NO_COUNTING / NMOD_FLAG_NO_COUNT_WIDE below).
  *
  * Data layout: the tested positions, in the
  * reference's iteration order (sorted (chrom,strand), then ascending
@@ -43,7 +42,7 @@
 extern "C" {
 #endif
 
-#define NMOD_ABI_VERSION 3
+#define NMOD_ABI_VERSION 4
 
 /* sample dtype of sig0 / sig1 */
 enum {
@@ -133,6 +132,13 @@ typedef struct nmod_params {
  * holding a NaN or an infinite sample, in every mode.  Without it the bit comes from the Welch moments alone (free, whenever they
  * are computed): that catches every NaN and -inf, and +inf except in the group a kernel form sorts with +inf pads. */
 #define NMOD_FLAG_CHECK_FINITE 2
+/* Kernel-form switches for A/B measurements and parity tests; the numbers are the same with and without them.  Event-like
+ * rows (every sample on the milli-unit grid, a position's samples within a window of 2 048 milli-units apart from a few
+ * outliers) are taken by counting forms of K1 instead of sorting forms when a device-side probe finds a size class of the
+ * batch event-like.  NMOD_FLAG_NO_COUNTING keeps every position on the sorting forms;
+ * NMOD_FLAG_NO_COUNT_WIDE only those outside the 256-capacity class. */
+#define NMOD_FLAG_NO_COUNTING 4
+#define NMOD_FLAG_NO_COUNT_WIDE 8
 
 /* Caller-allocated SoA outputs, npos elements each; a NULL member is skipped.
  * One (stat, p) pair per test = the tuples getKStest returns
@@ -201,6 +207,29 @@ typedef struct nmod_host_stats {
 } nmod_host_stats;
 int nmod_last_host_stats(nmod_host_stats* st);
 
+/* Which K1 form computed the positions of the calling thread's last nmod_detect_batch.  The forms produce the same numbers
+ * (tests/test_gpu_parity.py runs batches through both and compares); which one runs is decided on the device — size classes,
+ * and for the counting forms a probe per class plus a per-position check — so the split is a property of the data the caller
+ * can only learn here.  NMOD_MEM_DEVICE: the counters are reduced on request from facts the call left in `workspace` (one
+ * small kernel on the call's stream, one synchronisation): ask before the workspace is reused or freed.  NMOD_MEM_HOST: they
+ * were read back with the results.  NMOD_ERR_INVALID_ARG when the thread has made no such call. */
+typedef struct nmod_dispatch_stats {
+  int64_t positions;        /* positions of the batch */
+  int64_t ks_rank;          /* ks_rank_kernel: KS only, the smaller group sorted */
+  int64_t rank_hist;        /* rank_hist_kernel: all tests, both groups sorted (groups of similar size) */
+  int64_t rank_hist_wide;   /* rank_hist_kernel, WIDE form: the smaller group sorted, the larger one streamed */
+  int64_t rank_pair;        /* rank_pair_kernel: all tests, both groups beyond 256 samples and of different capacity */
+  int64_t rank_count;       /* rank_count_kernel: the counting form of the 256-capacity class (event-like rows) */
+  int64_t rank_count_wide;  /* rank_count_wide_kernel: the counting form for any coverage (event-like rows) */
+  int64_t big;              /* big_rank_kernel / big_hist_kernel: a group beyond NMOD_MAX_GROUP */
+  int64_t skipped;          /* no K1 form (NMOD_STATUS_EMPTY / NMOD_STATUS_TOO_LARGE) */
+  int64_t count_tried;      /* positions of the classes whose probe let a counting form run */
+  int64_t count_rejected;   /* ... that the counting form handed on to the class's sorting form (counted there above) */
+  int64_t f64_redo;         /* NMOD_DTYPE_F64: positions done again on 64-bit keys (their first form counts them as well) */
+  int64_t reserved[4];
+} nmod_dispatch_stats;
+int nmod_last_dispatch_stats(nmod_dispatch_stats* st);
+
 /* "arch=gfx950 abi=3 ... | <translation unit>: NMOD_SKIP=0 NMOD_EXP=0 ..." — the value of every experiment macro
  * (phase-skip and variant switches of the kernel headers) in each translation unit of THIS binary.  A product build
  * reports NMOD_SKIP=0 NMOD_EXP=0 everywhere (tests/test_abi_and_host.py). */
@@ -261,13 +290,16 @@ int nmod_synth_fill_csr(const nmod_params* prm, uint64_t seed, int64_t pos_begin
  * per 200 v 200 position.  Integer-only up to the last quotient, so tests restate it bit for bit:
  *   level(pos) = (mix64(seed ^ 0xA5A5A5A5DEADBEEF, pos, 0, 0) >> 40) % 6001 - 3000                          [milli-units]
  *   z = (sum of the four 16-bit fields of mix64(seed, group, pos, read)) - 131070     (as nmod_synth_fill; sd 37837.2)
- *   k = level + floor((2 z spread_milli + 37837) / 75674)  [+ plant_shift_milli at planted positions of group 1], |k| <= 32767
+ *   k = level + floor((2 z spread_milli + 37837) / 75674)  [+ plant_shift_milli at planted positions of group 1]
+ *   o = mix64(seed ^ 0x0DDBA11C0FFEE123, group, pos, read);  if ((o >> 20) % 1000 < outlier_permille) k = (o >> 32) % 10001 - 5000
+ *       (a mis-segmented event: uniform over the +-5 unit clip range of the raw normalisation, myRefBaseSignalAnnotation.py:251-259)
+ *   |k| <= 32767
  * int16 output: k.  float32 output: (float)((double)k / 1000.0), the float32 image of the stored 3-decimal value.
  * Rows: n_per_pos > 0 fixed stride (off ignored), else `off` = DEVICE array of npos + 1 element offsets into sig_out.
- * 0 <= spread_milli <= 8000. */
+ * 0 <= spread_milli <= 8000, 0 <= outlier_permille <= 1000. */
 int nmod_synth_fill_events(const nmod_params* prm, uint64_t seed, int64_t pos_begin, int64_t npos,
                            int32_t group, int32_t n_per_pos, const int64_t* off, int64_t plant_period,
-                           int32_t plant_shift_milli, int32_t spread_milli, void* sig_out);
+                           int32_t plant_shift_milli, int32_t spread_milli, int32_t outlier_permille, void* sig_out);
 
 /* HIP-event timer: records (start, stop) around every kernel the library
  * launches while prm->timer points to it; read it after synchronising. */

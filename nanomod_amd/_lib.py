@@ -12,12 +12,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (NMOD_HIP_LIB: another build of the same library, for A/B measurements of kernel variants on one box)
 LIB_PATH = os.environ.get('NMOD_HIP_LIB') or os.path.join(_HERE, 'libnanomod_hip.so')
 
-NMOD_ABI_VERSION = 3
+NMOD_ABI_VERSION = 4
 DTYPE_F32, DTYPE_I16_MILLI, DTYPE_F64 = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 METHOD_KS, METHOD_STOUFFER, METHOD_FISHER = 0, 1, 2
 TEST_KS, TEST_MWU, TEST_WELCH, TEST_ALL = 1, 2, 4, 7
-FLAG_KS_RATIONAL_D, FLAG_CHECK_FINITE = 1, 2
+FLAG_KS_RATIONAL_D, FLAG_CHECK_FINITE, FLAG_NO_COUNTING, FLAG_NO_COUNT_WIDE = 1, 2, 4, 8
 STATUS_MWU_ALL_IDENTICAL, STATUS_T_NAN, STATUS_EMPTY, STATUS_TOO_LARGE, STATUS_NONFINITE = 1, 2, 4, 8, 16
 KERNEL_RANK_STATS, KERNEL_FINALIZE, KERNEL_COMBINE, KERNEL_SYNTH = 0, 1, 2, 3
 MAX_GROUP = 2048          # largest group of the wave-resident kernels; larger ones (<= MAX_RANKED) take big_rank_kernel
@@ -47,6 +47,18 @@ class NmodHostStats(C.Structure):
                                          'device_bytes', 'pinned_bytes', 'h2d_bytes', 'd2h_bytes')]
 
 
+class NmodDispatchStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ('positions', 'ks_rank', 'rank_hist', 'rank_hist_wide', 'rank_pair', 'rank_count', 'rank_count_wide',
+                                         'big', 'skipped', 'count_tried', 'count_rejected', 'f64_redo')] + [('reserved', C.c_int64 * 4)]
+
+
+def last_dispatch_stats():
+    """nmod_last_dispatch_stats as a dict: which K1 form computed the positions of this thread's last nmod_detect_batch"""
+    st = NmodDispatchStats()
+    check(load().nmod_last_dispatch_stats(C.byref(st)), 'nmod_last_dispatch_stats')
+    return {n: int(getattr(st, n)) for n, _ in NmodDispatchStats._fields_ if n != 'reserved'}
+
+
 class NanomodLibraryError(RuntimeError):
     pass
 
@@ -68,7 +80,7 @@ _SIGNATURES = {
     'nmod_synth_fill_csr': (C.c_int, [C.POINTER(NmodParams), C.c_uint64, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     'nmod_synth_fill_events': (C.c_int, [C.POINTER(NmodParams), C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
-                                         C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+                                         C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     'nmod_evtimer_create': (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
     'nmod_evtimer_reset': (C.c_int, [C.c_void_p]),
     'nmod_evtimer_read': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
@@ -78,6 +90,7 @@ _SIGNATURES = {
     'nmod_trim_scratch': (C.c_int, [C.c_int32]),
     'nmod_host_pipeline_config': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     'nmod_last_host_stats': (C.c_int, [C.POINTER(NmodHostStats)]),
+    'nmod_last_dispatch_stats': (C.c_int, [C.POINTER(NmodDispatchStats)]),
     'nmod_build_info': (C.c_char_p, []),
     'nmod_downsample_ks': (C.c_int, [C.POINTER(NmodParams), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p]),

@@ -275,7 +275,8 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
   if (csr1) dp.stride1 = 0;
   const int64_t wsb = align256(nmod_workspace_bytes(&dp, cap_pos));
   const int64_t dev_slot = in_slot + wsb + out_slab;
-  const int64_t full_tracks = want_comb ? align256(npos * 8) * 4 + align256(npos * 4) : 0;   // ks_d, ks_p, comb_st, comb_p, run ids
+  const int64_t stats_bytes = align256(kStatsWords * 8);                                     // dispatch_stats_kernel's accumulator of the call
+  const int64_t full_tracks = stats_bytes + (want_comb ? align256(npos * 8) * 4 + align256(npos * 4) : 0);   // + ks_d, ks_p, comb_st, comb_p, run ids
   const size_t pinned_need = (size_t)slots * (size_t)(in_bounce + out_slab);
 
   HpCall call(dev);
@@ -287,7 +288,10 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
   NMOD_HIP(dmem.alloc((size_t)(slots * dev_slot + full_tracks), res.s_k, dev));
   NMOD_HIP(hipStreamSynchronize(res.s_k));        // (the copy streams use it too: it must exist before they do)
   char* dbase = (char*)dmem.p;
-  char* dfull = dbase + (int64_t)slots * dev_slot;
+  unsigned long long* d_stats = (unsigned long long*)(dbase + (int64_t)slots * dev_slot);
+  NMOD_HIP(hipMemsetAsync(d_stats, 0, kStatsWords * 8, res.s_k));
+  g_dispatch.valid = false;
+  char* dfull = dbase + (int64_t)slots * dev_slot + stats_bytes;
   double* f_ksd = (double*)dfull; double* f_ksp = (double*)(dfull + align256(npos * 8));
   double* f_cst = (double*)(dfull + 2 * align256(npos * 8)); double* f_cp = (double*)(dfull + 3 * align256(npos * 8));
   int32_t* f_run = (int32_t*)(dfull + 4 * align256(npos * 8));
@@ -378,6 +382,11 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
                         csr1 ? (const int64_t*)(di + o_off1) : nullptr, nullptr, ws_dev(s), wsb, &dout);
     }
     if (r != NMOD_OK) return r;
+    {                                             // which K1 form took the chunk's positions (nmod_last_dispatch_stats)
+      StatsArgs sa = g_dispatch.args;
+      sa.acc = d_stats;
+      NMOD_HIP(enqueue_dispatch_stats(sa, res.s_k));
+    }
     if (want_comb) {                              // the KS track of the whole batch stays on the device for K3
       NMOD_HIP(hipMemcpyAsync(f_ksd + lo, dv[4], (size_t)n * 8, hipMemcpyDeviceToDevice, res.s_k));
       NMOD_HIP(hipMemcpyAsync(f_ksp + lo, dv[5], (size_t)n * 8, hipMemcpyDeviceToDevice, res.s_k));
@@ -409,8 +418,10 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
     NMOD_HIP(hipMemcpyAsync(out->comb_p, f_cp, (size_t)npos * 8, hipMemcpyDeviceToHost, res.s_k));
     g_host_stats.d2h_bytes += npos * 16;
   }
+  NMOD_HIP(hipMemcpyAsync(g_dispatch.host_totals, d_stats, kStatsWords * 8, hipMemcpyDeviceToHost, res.s_k));
   for (int c = std::max(0, nchunks - slots); c < nchunks; ++c) { rc = retire(c); if (rc != NMOD_OK) return rc; }
   NMOD_HIP(hipStreamSynchronize(res.s_k));
+  g_dispatch.valid = true; g_dispatch.host = true; g_dispatch.npos = npos;
   g_host_stats.chunks = nchunks; g_host_stats.slots = slots; g_host_stats.copy_threads = threads;
   g_host_stats.pinned_input = pinned_in ? 1 : 0;
   g_host_stats.chunk_positions = cap_pos;

@@ -65,8 +65,13 @@ struct Workspace {
   double* tmp_ks_d; double* tmp_ks_p; double* ks_d_ref;
   int32_t* order; int32_t* redo; uint8_t* cls; uint8_t* tied; uint8_t* cnt_done; uint8_t* nonfinite; int32_t* meta;
   int32_t* work_list; int32_t* work_meta; uint8_t* cw_done;      // counting form for any coverage (rank_count_wide.hpp)   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
+  unsigned long long* stats;                                     // nmod_last_dispatch_stats: kStatsWords counters, written only on request
   int64_t bytes;
 };
+// raw counters of dispatch_stats_kernel: [0] the 256-capacity counting form's gate, [1] positions it produced, [2] float64 redo,
+// [kStatsClass + c] positions of launch class c, [kStatsGate + c] the any-coverage counting form's gate of class c (summed over the
+// chunks of a host-resident batch), [kStatsLeft + c] positions it left to the class's sorting form
+constexpr int kStatsClass = 8, kStatsGate = 64, kStatsLeft = 128, kStatsTried = 192, kStatsWords = 256;
 constexpr int kMetaInts = 256;
 constexpr int kMetaMax = 3 * kClassStride;      // [168..169] max n0 / n1
 constexpr int kMetaBigTotal = kMetaMax + 2;     // [170..171] u64: scratch floats the large positions need
@@ -78,7 +83,7 @@ constexpr int kMetaRedo = 184;                  // float64 front end: [184] coun
 constexpr int kMetaRedoTotal = 242, kMetaRedoCursor = 244;
 static_assert(kMetaRedo + kClassStride < kMetaRedoTotal && kMetaRedoCursor + 2 <= kMetaInts && kMetaBigCursor + 2 <= kMetaWideRedo && kMetaWideRedo < kMetaCntGate && kMetaCntGate < kMetaRedo, "meta layout");
 // (kBigClass, kBigHistClass, kWideBigBase .., kNumPairs: rank_stats_launch.hpp)
-static_assert(kNumPairs <= kClassStride, "class tables");
+static_assert(kNumPairs <= kClassStride && kStatsClass + kClassStride <= kStatsGate && kStatsGate + kClassStride <= kStatsLeft && kStatsLeft + kClassStride <= kStatsTried && kStatsTried + kClassStride <= kStatsWords, "class tables");
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -104,6 +109,7 @@ static Workspace carve(void* base, int64_t npos) {
   w.work_list = (int32_t*)take(4 * npos);          // rank_count_wide.hpp: what the sorting forms still have to do, per class
   w.work_meta = (int32_t*)take(kMetaInts * 4);      // [c] counts, [kClassStride + c] offsets, [2 kClassStride + c] the probes' gates
   w.cw_done = (uint8_t*)take(npos + 16);
+  w.stats = (unsigned long long*)take(kStatsWords * 8);
   w.bytes = o;
   return w;
 }
@@ -326,6 +332,56 @@ __global__ __launch_bounds__(256) void f64_redo_list_kernel(F64Args a) {
   }
 }
 
+
+// ---------------------------------------------------------------- dispatch statistics (nmod_last_dispatch_stats)
+// Which K1 form took how many positions of a batch is decided on the device (class lists, the probes' gates, the counting forms'
+// per-position flags) and never leaves it on the hot path.  detect_device remembers where those facts sit in the caller's
+// workspace; dispatch_stats_kernel reduces them to kStatsWords counters when somebody asks (device-resident batches: on request,
+// nothing is launched otherwise; host-resident batches: once per chunk into a per-call accumulator, the path is PCIe-bound).
+struct StatsArgs {
+  int64_t npos; int32_t uniform_cls;             // >= 0: one class holds all npos positions (no class lists were built)
+  const int32_t* meta; const int32_t* work_meta; const int32_t* gates; const uint8_t* cnt_done;
+  int32_t cnt256_ran, cw_ran, f64;
+  unsigned long long* acc;
+};
+__global__ __launch_bounds__(256) void dispatch_stats_kernel(StatsArgs a) {
+  const int c256 = kNumGeneralClasses + 2;
+  auto count_of = [&](int c) -> int64_t { return a.uniform_cls >= 0 ? (c == a.uniform_cls ? a.npos : 0) : (int64_t)a.meta[c]; };
+  if (blockIdx.x == 0) {
+    const int c = threadIdx.x;
+    if (c < kNumPairs) {
+      const int64_t n = count_of(c);
+      if (n) atomicAdd(&a.acc[kStatsClass + c], (unsigned long long)n);
+      if (a.cw_ran && n && a.gates[c] != 0) {
+        atomicAdd(&a.acc[kStatsGate + c], 1ull);
+        atomicAdd(&a.acc[kStatsTried + c], (unsigned long long)n);
+        atomicAdd(&a.acc[kStatsLeft + c], (unsigned long long)a.work_meta[c]);
+      }
+    }
+    if (c == 64 && a.cnt256_ran && a.meta[kMetaCntGate] != 0 && count_of(c256) > 0) { atomicAdd(&a.acc[0], 1ull); atomicAdd(&a.acc[kStatsTried + c256], (unsigned long long)count_of(c256)); }
+    if (c == 65 && a.f64) atomicAdd(&a.acc[2], (unsigned long long)a.meta[kMetaRedo]);
+  }
+  if (a.cnt256_ran && a.meta[kMetaCntGate] != 0) {        // entries of the class list whose flag byte says "produced by rank_count_kernel"
+    const int64_t n = count_of(c256);
+    unsigned mine = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) mine += a.cnt_done[i] != 0 ? 1u : 0u;
+    mine = (unsigned)wave_sum_u64((unsigned long long)mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&a.acc[1], (unsigned long long)mine);
+  }
+}
+struct DispatchRec {
+  bool valid = false; bool host = false; int device = 0; hipStream_t stream = nullptr;
+  StatsArgs args;                                // (acc = the workspace's own block for a device-resident batch)
+  unsigned long long host_totals[kStatsWords];   // a host-resident batch: read back before the call returned
+  int64_t npos = 0; int32_t ks_only = 0;
+};
+thread_local DispatchRec g_dispatch;
+static hipError_t enqueue_dispatch_stats(const StatsArgs& a, hipStream_t stream) {
+  const unsigned blocks = a.cnt256_ran ? (unsigned)std::max<int64_t>(1, std::min<int64_t>((a.npos + 255) / 256, 512)) : 1u;
+  hipLaunchKernelGGL(dispatch_stats_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- helpers
 static int check_params(const nmod_params* prm) {
   if (!prm || prm->struct_size != (int32_t)sizeof(nmod_params)) return NMOD_ERR_INVALID_ARG;
@@ -334,7 +390,7 @@ static int check_params(const nmod_params* prm) {
   if (prm->method < NMOD_METHOD_KS || prm->method > NMOD_METHOD_FISHER) return NMOD_ERR_INVALID_ARG;
   if (prm->nb < 0 || prm->nb > NMOD_MAX_NB) return NMOD_ERR_INVALID_ARG;
   if ((prm->tests & ~NMOD_TEST_ALL) != 0) return NMOD_ERR_INVALID_ARG;
-  if ((prm->flags & ~(NMOD_FLAG_KS_RATIONAL_D | NMOD_FLAG_CHECK_FINITE)) != 0 || prm->reserved != 0) return NMOD_ERR_INVALID_ARG;
+  if ((prm->flags & ~(NMOD_FLAG_KS_RATIONAL_D | NMOD_FLAG_CHECK_FINITE | NMOD_FLAG_NO_COUNTING | NMOD_FLAG_NO_COUNT_WIDE)) != 0 || prm->reserved != 0) return NMOD_ERR_INVALID_ARG;
   return NMOD_OK;
 }
 
@@ -496,8 +552,8 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   const bool wide_f32 = all && prm->dtype == NMOD_DTYPE_F32;
   // all tests on capacity-256 positions: the counting form is tried first (rank_count.hpp; a device-side probe decides whether
   // the batch is event-like, positions it cannot take fall through to rank_hist_kernel).  The float32 images of float64 samples
-  // qualify where they are whole numbers (positions on the 0.001 grid carry k as keys).  NMOD_NO_COUNTING=1 turns it off (A/B).
-  static const bool counting_off = []() { const char* e = getenv("NMOD_NO_COUNTING"); return e && *e && *e != '0'; }();
+  // qualify where they are whole numbers (positions on the 0.001 grid carry k as keys).  NMOD_FLAG_NO_COUNTING turns it off (A/B, parity tests).
+  const bool counting_off = (prm->flags & NMOD_FLAG_NO_COUNTING) != 0;
   if (all && !counting_off) { ra.cnt_gate = ws.meta + kMetaCntGate; ra.cnt_done = ws.cnt_done; }
 
   auto launch = [&](int cls, int64_t work) -> hipError_t {
@@ -511,8 +567,8 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
 
   // all tests, classes other than the 256-capacity one: the counting form for any coverage (rank_count_wide.hpp) is tried per class
   // when its probe finds the class event-like; the sorting form of the class then runs over the work list that is left
-  // (NMOD_NO_COUNT_WIDE=1 turns it off)
-  static const bool cw_off = []() { const char* e = getenv("NMOD_NO_COUNT_WIDE"); return e && *e && *e != '0'; }();
+  // (NMOD_FLAG_NO_COUNT_WIDE turns it off)
+  const bool cw_off = (prm->flags & NMOD_FLAG_NO_COUNT_WIDE) != 0;
   // (KS-only batches too — the form without the tie term and the moments — when a group of the batch can reach the size it takes)
   const bool cw_on = !counting_off && !cw_off && (all || std::max(max0, max1) >= kCwKsMinQ);
   CountWideWs cww;
@@ -543,12 +599,16 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   };
 
   DevScratch big_scratch;
+  int st_uniform_cls = -1, st_cnt256 = 0, st_cw = 0;          // for nmod_last_dispatch_stats
+  constexpr int kCls256 = kNumGeneralClasses + 2;
   if (uniform && !big_possible) {
     const int ucls = all ? launch_class_of(cmax0, cmax1) : kKsClassBase + std::min(cmax0, cmax1);
+    st_uniform_cls = ucls; st_cnt256 = (ucls == kCls256 && ra.cnt_gate) ? 1 : 0;
     const bool uwide = wide_f32 && wide_class(ucls);
     if (uwide && !meta_cleared && !f64) NMOD_HIP(hipMemsetAsync(ws.meta + kMetaWideRedo, 0, 4, stream));   // (the meta block is not cleared for uniform batches)
     ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_RANK_STATS, stream);
     const bool counted = cw_on && count_wide_rs_index(ucls) >= 0;
+    st_cw = counted ? 1 : 0;
     if (counted) NMOD_HIP(cw_run(std::vector<int>{ucls}));
     NMOD_HIP(launch_class(ucls, npos, counted));
     if (uwide) { const int rr = launch_wide_redo(); if (rr != NMOD_OK) return rr; }
@@ -572,7 +632,9 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
       for (int cls = 0; cls < kNumClasses; ++cls) if (wanted[cls] && count_wide_rs_index(cls) >= 0) counted_classes.push_back(cls);
       if (big_possible && all) for (int cs = 0; cs < kNumWideBig; ++cs) counted_classes.push_back(kWideBigBase + cs);
       NMOD_HIP(cw_run(counted_classes));
+      st_cw = counted_classes.empty() ? 0 : 1;
     }
+    st_cnt256 = (all && wanted[kCls256] && ra.cnt_gate) ? 1 : 0;
     for (int cls = 0; cls < kNumClasses; ++cls) {
       if (!wanted[cls]) continue;
       ra.pos_list = ws.order; ra.class_meta = ws.meta; ra.class_id = cls;
@@ -701,6 +763,13 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   if (want_comb) {
     int rc = launch_combine(prm, stream, npos, fa.out.ks_d, fa.out.ks_p, run_id, out->comb_st, out->comb_p);
     if (rc != NMOD_OK) return rc;
+  }
+  {
+    DispatchRec& d = g_dispatch;
+    d.valid = true; d.host = false; d.device = prm->device; d.stream = stream; d.npos = npos; d.ks_only = all ? 0 : 1;
+    d.args.npos = npos; d.args.uniform_cls = st_uniform_cls; d.args.meta = ws.meta; d.args.work_meta = ws.work_meta;
+    d.args.gates = ws.work_meta + 2 * kClassStride; d.args.cnt_done = ws.cnt_done; d.args.cnt256_ran = st_cnt256; d.args.cw_ran = st_cw;
+    d.args.f64 = f64 ? 1 : 0; d.args.acc = ws.stats;
   }
   return NMOD_OK;
 }
@@ -1002,11 +1071,11 @@ int nmod_synth_fill_csr(const nmod_params* prm, uint64_t seed, int64_t pos_begin
 
 int nmod_synth_fill_events(const nmod_params* prm, uint64_t seed, int64_t pos_begin, int64_t npos, int32_t group,
                            int32_t n_per_pos, const int64_t* off, int64_t plant_period, int32_t plant_shift_milli,
-                           int32_t spread_milli, void* sig_out) {
+                           int32_t spread_milli, int32_t outlier_permille, void* sig_out) {
   int rc = check_params(prm);
   if (rc != NMOD_OK) return rc;
   if (npos < 0 || !sig_out || (group != 0 && group != 1) || n_per_pos < 0 || (n_per_pos == 0 && !off)) return NMOD_ERR_INVALID_ARG;
-  if (spread_milli < 0 || spread_milli > 8000 || plant_shift_milli < -16000 || plant_shift_milli > 16000) return NMOD_ERR_INVALID_ARG;
+  if (spread_milli < 0 || spread_milli > 8000 || plant_shift_milli < -16000 || plant_shift_milli > 16000 || outlier_permille < 0 || outlier_permille > 1000) return NMOD_ERR_INVALID_ARG;
   if (prm->memspace != NMOD_MEM_DEVICE || (prm->dtype != NMOD_DTYPE_F32 && prm->dtype != NMOD_DTYPE_I16_MILLI)) return NMOD_ERR_INVALID_ARG;
   if (nmod_device_count() <= prm->device || prm->device < 0) return NMOD_ERR_NO_DEVICE;
   NMOD_HIP(hipSetDevice(prm->device));
@@ -1014,7 +1083,7 @@ int nmod_synth_fill_events(const nmod_params* prm, uint64_t seed, int64_t pos_be
   hipStream_t stream = (hipStream_t)prm->stream;
   SynthEventArgs sa;
   sa.seed = seed; sa.pos_begin = pos_begin; sa.npos = npos; sa.group = group; sa.n_per_pos = n_per_pos; sa.off = off;
-  sa.plant_period = plant_period; sa.plant_shift_milli = plant_shift_milli; sa.spread_milli = spread_milli; sa.dtype = prm->dtype; sa.out = sig_out;
+  sa.plant_period = plant_period; sa.plant_shift_milli = plant_shift_milli; sa.spread_milli = spread_milli; sa.dtype = prm->dtype; sa.outlier_permille = outlier_permille; sa.out = sig_out;
   unsigned blocks = (unsigned)std::min<int64_t>((npos + 3) / 4, 256 * 32);
   ScopedKernelTimer tm(prm->timer, NMOD_KERNEL_SYNTH, stream);
   hipLaunchKernelGGL(synth_event_kernel, dim3(blocks), dim3(256), 0, stream, sa);
@@ -1080,6 +1149,47 @@ int nmod_host_pipeline_config(int64_t chunk_bytes, int32_t slots, int32_t thread
 int nmod_last_host_stats(nmod_host_stats* st) {
   if (!st) return NMOD_ERR_INVALID_ARG;
   *st = g_host_stats;
+  return NMOD_OK;
+}
+
+
+static void assemble_dispatch_stats(const unsigned long long* raw, int64_t npos, nmod_dispatch_stats* st) {
+  memset(st, 0, sizeof(*st));
+  st->positions = npos;
+  constexpr int c256 = kNumGeneralClasses + 2;
+  int64_t placed = 0;
+  for (int c = 0; c < kNumPairs; ++c) {
+    const int64_t n = (int64_t)raw[kStatsClass + c];
+    if (n == 0) continue;
+    placed += n;
+    int64_t* sorting = c >= kWideBigBase ? &st->rank_hist_wide
+                     : (c == kBigClass || c == kBigHistClass) ? &st->big
+                     : c >= kKsClassBase ? &st->ks_rank
+                     : c >= kNumGeneralClasses ? &st->rank_hist
+                     : wide_class(c) ? &st->rank_hist_wide : &st->rank_pair;
+    const int64_t tried = (int64_t)raw[kStatsTried + c];
+    const int64_t counted = c == c256 ? (int64_t)raw[1] : tried - (int64_t)raw[kStatsLeft + c];
+    if (c == c256) st->rank_count += counted; else st->rank_count_wide += counted;
+    *sorting += n - counted;
+    st->count_tried += tried;
+    st->count_rejected += tried - counted;
+  }
+  st->skipped = npos - placed;
+  st->f64_redo = (int64_t)raw[2];
+}
+
+int nmod_last_dispatch_stats(nmod_dispatch_stats* st) {
+  if (!st) return NMOD_ERR_INVALID_ARG;
+  DispatchRec& d = g_dispatch;
+  if (!d.valid) { memset(st, 0, sizeof(*st)); return NMOD_ERR_INVALID_ARG; }
+  if (d.host) { assemble_dispatch_stats(d.host_totals, d.npos, st); return NMOD_OK; }
+  unsigned long long raw[kStatsWords];
+  NMOD_HIP(hipSetDevice(d.device));
+  NMOD_HIP(hipMemsetAsync(d.args.acc, 0, kStatsWords * 8, d.stream));
+  NMOD_HIP(enqueue_dispatch_stats(d.args, d.stream));
+  NMOD_HIP(hipMemcpyAsync(raw, d.args.acc, kStatsWords * 8, hipMemcpyDeviceToHost, d.stream));
+  NMOD_HIP(hipStreamSynchronize(d.stream));
+  assemble_dispatch_stats(raw, d.npos, st);
   return NMOD_OK;
 }
 

@@ -273,17 +273,27 @@ constexpr uint64_t kLevelSalt = 0xA5A5A5A5DEADBEEFull;
 __device__ __forceinline__ int synth_event_level(uint64_t seed, int64_t pos) {
   return (int)((synth_mix(seed ^ kLevelSalt, pos, 0, 0u) >> 40) % 6001ull) - 3000;
 }
-__device__ __forceinline__ int synth_event_key(uint64_t seed, int64_t pos, int32_t group, uint32_t read, int level, int spread_milli, int shift) {
+constexpr uint64_t kOutlierSalt = 0x0DDBA11C0FFEE123ull;
+// (the quotient's floor in 64 bits: 2 z spread reaches 2.1e9 at spread 8 000)
+__device__ __forceinline__ int synth_event_key(uint64_t seed, int64_t pos, int32_t group, uint32_t read, int level, int spread_milli, int shift,
+                                               int outlier_permille) {
   const uint64_t h = synth_mix(seed, pos, group, read);
   const int z = (int)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + (h >> 48)) - 131070;
-  constexpr int kBias = 4096;                                    // (floor division through a non-negative numerator)
-  const int q = (2 * z * spread_milli + 37837 + kBias * 75674) / 75674 - kBias;
-  return min(max(level + q + shift, -32767), 32767);
+  constexpr long long kBias = 32768;                             // (floor division through a non-negative numerator)
+  const int q = (int)((2ll * z * spread_milli + 37837 + kBias * 75674) / 75674 - kBias);
+  int k = level + q + shift;
+  if (outlier_permille > 0) {
+    // a read in `outlier_permille` of 1 000 is a mis-segmented event: a uniform draw over the +-5 unit clip range of the raw
+    // normalisation (myRefBaseSignalAnnotation.py:251-259), whatever the position's level
+    const uint64_t o = synth_mix(seed ^ kOutlierSalt, pos, group, read);
+    if ((int)((o >> 20) % 1000ull) < outlier_permille) k = (int)((o >> 32) % 10001ull) - 5000;
+  }
+  return min(max(k, -32767), 32767);
 }
 
 struct SynthEventArgs {
   uint64_t seed; int64_t pos_begin; int64_t npos; int32_t group; int32_t n_per_pos; const int64_t* off;
-  int64_t plant_period; int32_t plant_shift_milli; int32_t spread_milli; int32_t dtype; void* out;
+  int64_t plant_period; int32_t plant_shift_milli; int32_t spread_milli; int32_t dtype; int32_t outlier_permille; void* out;
 };
 
 // one wave per row (fixed stride or CSR)
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(256) void synth_event_kernel(SynthEventArgs a) {
     }
     const int level = synth_event_level(a.seed, pos);
     for (int read = lane; read < n; read += 64) {
-      const int k = synth_event_key(a.seed, pos, a.group, (uint32_t)read, level, a.spread_milli, shift);
+      const int k = synth_event_key(a.seed, pos, a.group, (uint32_t)read, level, a.spread_milli, shift, a.outlier_permille);
       if (a.dtype == NMOD_DTYPE_F32) reinterpret_cast<float*>(a.out)[o + read] = (float)((double)k / 1000.0);
       else reinterpret_cast<int16_t*>(a.out)[o + read] = (int16_t)k;
     }

@@ -313,6 +313,10 @@ class DeviceDetector:
         res['status'] = torch.empty(npos, dtype=torch.uint8, device=dev)
         return res
 
+    def dispatch_stats(self):
+        """which K1 form computed the positions of the last run() (nmod_last_dispatch_stats; synchronises the stream)"""
+        return L.last_dispatch_stats()
+
     def run(self, sig0, sig1, run_id, *, off0=None, off1=None, stride0=0, stride1=0, npos=None,
             max_n0=0, max_n1=0, out=None):
         """Enqueue the hot path on the current stream.  Either CSR offsets (int64 CUDA tensors)
@@ -353,13 +357,14 @@ class DeviceDetector:
         return out
 
     def synth_fill_events(self, out, seed, pos_begin, npos, group, n_per_pos=0, off=None, plant_period=0, plant_shift_milli=0,
-                          spread_milli=200):
+                          spread_milli=200, outlier_permille=0):
         """event-like rows (nmod_synth_fill_events): a level per position, reads spread `spread_milli` around it, on the
-        3-decimal grid; fixed stride (n_per_pos > 0) or ragged (`off` = int64 CUDA tensor of npos + 1 offsets)"""
+        3-decimal grid; fixed stride (n_per_pos > 0) or ragged (`off` = int64 CUDA tensor of npos + 1 offsets); `outlier_permille`
+        of 1 000 reads are replaced by a uniform draw over +-5 units (mis-segmented events)"""
         prm = self._params(self._dtype_of(out), 0, 0, 0, 0)
         rc = self.lib.nmod_synth_fill_events(C.byref(prm), seed, pos_begin, npos, group, n_per_pos,
                                              off.data_ptr() if off is not None else None, plant_period,
-                                             int(plant_shift_milli), int(spread_milli), out.data_ptr())
+                                             int(plant_shift_milli), int(spread_milli), int(outlier_permille), out.data_ptr())
         L.check(rc, 'nmod_synth_fill_events')
         return out
 

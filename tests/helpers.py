@@ -144,7 +144,7 @@ def _mix64(seed, pos, group, read):
     return x
 
 
-def synth_events_ref(seed, pos_begin, npos, group, n_per_pos, plant_period=0, plant_shift_milli=0, spread_milli=200, dtype='f32'):
+def synth_events_ref(seed, pos_begin, npos, group, n_per_pos, plant_period=0, plant_shift_milli=0, spread_milli=200, dtype='f32', outlier_permille=0):
     """numpy restatement of nmod_synth_fill_events (include/nanomod_hip.h) as an [npos, n_per_pos] array: a level per position
     (both groups), reads spread around it, everything on the milli-unit grid"""
     pos = (np.arange(npos, dtype=np.int64) + pos_begin)[:, None]
@@ -158,6 +158,10 @@ def synth_events_ref(seed, pos_begin, npos, group, n_per_pos, plant_period=0, pl
     if group == 1 and plant_period > 0:
         mm = pos % plant_period
         k = k + np.where((mm == 0) | (mm == 1) | (mm == plant_period - 1), int(plant_shift_milli), 0)
+    if outlier_permille > 0:       # a mis-segmented event: uniform over the +-5 unit clip range, whatever the level
+        o = _mix64(np.uint64(seed) ^ np.uint64(0x0DDBA11C0FFEE123), pos, group, read)
+        hit = ((o >> np.uint64(20)) % np.uint64(1000)).astype(np.int64) < int(outlier_permille)
+        k = np.where(hit, ((o >> np.uint64(32)) % np.uint64(10001)).astype(np.int64) - 5000, k)
     k = np.clip(k, -32767, 32767)
     if dtype == 'i16':
         return k.astype(np.int16)

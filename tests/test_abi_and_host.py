@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L._SIGNATURES), declared ^ set(L._SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.nmod_abi_version() == 3
+    assert lib.nmod_abi_version() == 4
     assert b'invalid' in lib.nmod_strerror(-1) and b'65535' in lib.nmod_strerror(-3)
 
 
@@ -34,7 +34,7 @@ def test_shipped_binary_is_a_product_build():
     import nanomod_amd._lib as L
     info = L.load().nmod_build_info().decode()
     parts = info.split(' | ')
-    assert parts[0].startswith('arch=gfx950 abi=3 ')
+    assert parts[0].startswith('arch=gfx950 abi=4 ')
     names = [p.split(':')[0] for p in parts[1:]]
     assert names == ['abi_tu', 'k1_f32_ks', 'k1_f32_all', 'k1_i16_ks', 'k1_i16_all']
     want = {'NMOD_SKIP': '0', 'NMOD_EXP': '0', 'NMOD_HIST_WAVES': '4', 'NMOD_WIDE_I16_WORDS': '2048',
@@ -71,15 +71,55 @@ def test_host_pipeline_config_validates():
 
 def test_struct_layout_matches_header():
     import nanomod_amd._lib as L
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu", sizeof(nmod_params), ' \
-          'offsetof(nmod_params, weights_dif), offsetof(nmod_params, max_n0), offsetof(nmod_params, timer), offsetof(nmod_params, flags), sizeof(nmod_out));return 0;}' % HEADER
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu", sizeof(nmod_params), ' \
+          'offsetof(nmod_params, weights_dif), offsetof(nmod_params, max_n0), offsetof(nmod_params, timer), offsetof(nmod_params, flags), sizeof(nmod_out), ' \
+          'sizeof(nmod_dispatch_stats), offsetof(nmod_dispatch_stats, rank_count_wide), offsetof(nmod_dispatch_stats, f64_redo));return 0;}' % HEADER
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, 't.c')
         open(c, 'w').write(src)
         subprocess.check_call(['gcc', c, '-o', os.path.join(d, 't')])
         got = [int(x) for x in subprocess.check_output([os.path.join(d, 't')]).split()]
     assert got == [C.sizeof(L.NmodParams), L.NmodParams.weights_dif.offset, L.NmodParams.max_n0.offset,
-                   L.NmodParams.timer.offset, L.NmodParams.flags.offset, C.sizeof(L.NmodOut)]
+                   L.NmodParams.timer.offset, L.NmodParams.flags.offset, C.sizeof(L.NmodOut),
+                   C.sizeof(L.NmodDispatchStats), L.NmodDispatchStats.rank_count_wide.offset, L.NmodDispatchStats.f64_redo.offset]
+
+
+def test_dispatch_stats_without_a_call_and_form_flags():
+    """nmod_last_dispatch_stats before the thread has run a batch: an error, not stale numbers; the kernel-form switches are
+    per-call flags (the library reads no environment variable: SURVEY.md 8b, no process-wide state behind the ABI)"""
+    import threading
+    import nanomod_amd._lib as L
+    lib = L.load()
+    out = {}
+
+    def fresh_thread():
+        st = L.NmodDispatchStats()
+        out['rc'] = lib.nmod_last_dispatch_stats(C.byref(st)); out['pos'] = st.positions
+        out['null'] = lib.nmod_last_dispatch_stats(None)
+    t = threading.Thread(target=fresh_thread); t.start(); t.join()
+    assert out == {'rc': -1, 'pos': 0, 'null': -1}
+    assert (L.FLAG_NO_COUNTING, L.FLAG_NO_COUNT_WIDE) == (4, 8)
+    prm = L.make_params(flags=16)
+    assert lib.nmod_workspace_bytes(C.byref(prm), 10) > 0 and lib.nmod_detect_batch(C.byref(prm), 1, None, None, None, None, None, None, 0, None) == -1
+    src = open(os.path.join(ROOT, 'nanomod_amd', 'csrc', 'nanomod_hip.hip')).read() + open(os.path.join(ROOT, 'nanomod_amd', 'csrc', 'rank_stats_inst.hip')).read()
+    assert 'getenv("NMOD_NO_COUNT' not in src
+
+
+def test_makefile_rebuilds_every_unit_when_a_header_changes():
+    """every translation unit depends on $(HDRS): touching radix_sort.hpp (included by rank_order.hip only) must put
+    rank_order.o into `make -n`'s plan (round 5 left it stale)"""
+    csrc = os.path.join(ROOT, 'nanomod_amd', 'csrc')
+    if not os.path.exists(os.path.join(csrc, 'build', 'rank_order.o')):
+        pytest.skip('no objects built here')
+    hdr = os.path.join(csrc, 'radix_sort.hpp')
+    st = os.stat(hdr)
+    try:
+        os.utime(hdr, None)
+        plan = subprocess.check_output(['make', '-n', '-C', csrc], text=True)
+    finally:
+        os.utime(hdr, ns=(st.st_atime_ns, st.st_mtime_ns))
+    for obj in ('rank_order.o', 'nanomod_hip.o', 'rank_stats_d0_a0.o', 'rank_stats_d1_a1.o'):
+        assert obj in plan, obj
 
 
 def test_no_gpu_fails_loudly_not_silently():

@@ -174,7 +174,7 @@ def test_error_returns_leak_nothing():
     # invalid arguments: rejected before any device work
     bad = det._params(L.DTYPE_F32, 0, 0, 0, 0); bad.nb = 65
     assert call(bad, ws, need) == -1
-    bad = det._params(L.DTYPE_F32, 0, 0, 0, 0); bad.flags = 4
+    bad = det._params(L.DTYPE_F32, 0, 0, 0, 0); bad.flags = 64
     assert call(bad, ws, need) == -1
     bad = det._params(L.DTYPE_F32, 0, 0, 0, 0); bad.device = 99
     assert call(bad, ws, need) == -5

@@ -377,26 +377,31 @@ def test_synth_fill_events_matches_the_numpy_restatement(nm):
     nmax = int(sizes.max())
     for tdt, name in ((torch.float32, 'f32'), (torch.int16, 'i16')):
         for g in (0, 1):
-            for spread in (0, 100, 200, 400):
-                ref = H.synth_events_ref(77, begin, P, g, nmax, 10000, 800, spread, dtype=name)
+            # (spread up to the bound the ABI accepts: the quotient's floor is taken in 64 bits; outliers: 0, 1 and 10 per mille and all)
+            for spread, outl in ((0, 0), (100, 0), (200, 0), (400, 0), (1183, 0), (8000, 0), (200, 1), (200, 10), (400, 1000)):
+                ref = H.synth_events_ref(77, begin, P, g, nmax, 10000, 800, spread, dtype=name, outlier_permille=outl)
                 out = torch.zeros(int(off[-1]), dtype=tdt, device='cuda:0')
-                det.synth_fill_events(out, 77, begin, P, g, off=d_off, plant_period=10000, plant_shift_milli=800, spread_milli=spread)
+                det.synth_fill_events(out, 77, begin, P, g, off=d_off, plant_period=10000, plant_shift_milli=800, spread_milli=spread, outlier_permille=outl)
                 exp = np.concatenate([ref[i, :sizes[i]] for i in range(P)])
-                assert np.array_equal(out.cpu().numpy(), exp), (name, g, spread, 'csr')
+                assert np.array_equal(out.cpu().numpy(), exp), (name, g, spread, outl, 'csr')
                 out = torch.zeros(P * 37, dtype=tdt, device='cuda:0')
-                det.synth_fill_events(out, 77, begin, P, g, n_per_pos=37, plant_period=10000, plant_shift_milli=800, spread_milli=spread)
-                assert np.array_equal(out.cpu().numpy().reshape(P, 37), ref[:, :37]), (name, g, spread, 'stride')
+                det.synth_fill_events(out, 77, begin, P, g, n_per_pos=37, plant_period=10000, plant_shift_milli=800, spread_milli=spread, outlier_permille=outl)
+                assert np.array_equal(out.cpu().numpy().reshape(P, 37), ref[:, :37]), (name, g, spread, outl, 'stride')
+                if outl == 10 and name == 'i16':        # the share of replaced reads is what the parameter says
+                    base = H.synth_events_ref(77, begin, P, g, nmax, 10000, 800, spread, dtype=name)
+                    assert 0.005 < np.mean(ref != base) < 0.015
     # both groups share the level; the float32 image is the stored 3-decimal value
     a = H.synth_events_ref(77, 0, 50, 0, 200, 0, 0, 100, 'i16'); b = H.synth_events_ref(77, 0, 50, 1, 200, 0, 0, 100, 'i16')
     assert np.all(np.abs(a.mean(axis=1) - b.mean(axis=1)) < 60) and a.mean(axis=1).std() > 1000
     f = H.synth_events_ref(77, 0, 50, 0, 200, 0, 0, 100, 'f32')
     assert np.array_equal(f, (a.astype(np.float64) / 1000.0).astype(np.float32))
     bad = L.make_params(device=0, memspace=L.MEM_DEVICE, dtype=L.DTYPE_F32)
-    assert L.load().nmod_synth_fill_events(bad, 1, 0, 10, 0, 5, None, 0, 0, 9000, 1) == -1
-    assert L.load().nmod_synth_fill_events(bad, 1, 0, 10, 0, 0, None, 0, 0, 100, 1) == -1
+    assert L.load().nmod_synth_fill_events(bad, 1, 0, 10, 0, 5, None, 0, 0, 9000, 0, 1) == -1
+    assert L.load().nmod_synth_fill_events(bad, 1, 0, 10, 0, 0, None, 0, 0, 100, 0, 1) == -1
+    assert L.load().nmod_synth_fill_events(bad, 1, 0, 10, 0, 5, None, 0, 0, 100, 1001, 1) == -1
 
 
-@pytest.mark.parametrize('spread', [100, 200, 400])
+@pytest.mark.parametrize('spread', [100, 200])
 @pytest.mark.parametrize('dtype', ['f32', 'i16', 'f64'])
 def test_event_like_batches_vs_oracle(nm, spread, dtype):
     """event-like rows (a level per position, reads spread 0.1 / 0.2 / 0.4 units around it, 3-decimal grid: most samples tie):
@@ -425,9 +430,26 @@ def test_event_like_batches_vs_oracle(nm, spread, dtype):
         kw = dict(stride0=200, stride1=200) if shape == 'stride' else {}
         got = nm.detect_host(sig0, None if shape == 'stride' else off0, sig1, None if shape == 'stride' else off1, rid, nb=2,
                              weights_dif=2.0, method='fisher', **kw)
+        st = L.last_dispatch_stats()
         H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(sig0, off0, sig1, off1))
         assert np.array_equal(got['status'], exp['status'])
+        # the counting forms took the batch (nmod_last_dispatch_stats): these numbers did not come from the sorting form
+        assert st['positions'] == P and st['skipped'] == 0
+        counted = st['rank_count'] + st['rank_count_wide']
+        # (ragged: the few positions whose groups both fit 128 samples are the eight-positions-per-wave class's, which has no counting form)
+        assert st['count_tried'] >= P - 12 and counted >= 0.95 * P and counted + st['count_rejected'] == st['count_tried'], (shape, st)
+        assert st['rank_hist'] + st['rank_hist_wide'] + st['rank_pair'] == P - counted and st['ks_rank'] == 0
+        # ... and the sorting forms alone (NMOD_FLAG_NO_COUNTING) give the same integers, so the same U, D and p bit for bit
+        srt = nm.detect_host(sig0, None if shape == 'stride' else off0, sig1, None if shape == 'stride' else off1, rid, nb=2,
+                             weights_dif=2.0, method='fisher', flags=L.FLAG_NO_COUNTING, **kw)
+        st0 = L.last_dispatch_stats()
+        assert st0['count_tried'] == 0 and st0['rank_count'] + st0['rank_count_wide'] == 0 and st0['rank_hist'] == P
+        for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p', 'comb_st', 'comb_p'):
+            assert np.array_equal(srt[k], got[k], equal_nan=True), (shape, k)
+        H.assert_close_p(srt['t_p'], got['t_p'], 1e-9, 't_p')
         got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='fisher', tests=L.TEST_KS)
+        st = L.last_dispatch_stats()
+        assert st['ks_rank'] == P and st['count_tried'] == 0            # (KS only at this coverage: ks_rank_kernel, eight / four positions per wave)
         assert np.array_equal(got['ks_d'], exp['ks_d'])
         H.assert_close_p(got['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
         H.assert_close_p(got['comb_p'], exp['comb_p'], 1e-9, 'comb_p')
@@ -478,6 +500,12 @@ def test_counting_form_edges(nm, dtype):
         s0 = k0.astype(np.float64) / 1000.0; s1 = k1.astype(np.float64) / 1000.0
     exp = orc.detect_batch(s0, off0, s1, off1, rid, 0, 2.0, orc.METHOD_FISHER)
     got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher')
+    st = L.last_dispatch_stats()
+    # exactly the positions the docstring lists are handed on: range 2 048, a group of 256, + the float32 sample off the grid; float64:
+    # + the all-equal position (0.5 is float32-exact, so its keys are the values themselves, not k: not the counting form's)
+    want_rejected = 2 if dtype == 'i16' else 3
+    assert st['count_tried'] == P and st['count_rejected'] == want_rejected and st['rank_count'] + st['rank_count_wide'] == P - want_rejected, st
+    assert st['rank_count'] >= 120 + 7 - (0 if dtype == 'i16' else 1)
     ident = (exp['status'] & L.STATUS_MWU_ALL_IDENTICAL) != 0
     assert ident[edge_at] and ident.sum() == 1 and np.array_equal(got['status'], exp['status'])
     assert np.isnan(got['mwu_u'][edge_at]) and got['ks_d'][edge_at] == 0.0 and got['ks_p'][edge_at] == 1.0
@@ -541,11 +569,28 @@ def test_count_wide_event_like_vs_oracle(nm, shape, dtype):
     exp = oracle_c.detect_batch(s0 if dtype == 'f32' else k0, off0, s1 if dtype == 'f32' else k1, off1, rid, 2, 2.0, 'stouffer', tests=7)
     kw = dict(stride0=600, stride1=90) if shape == 'stride600' else {}
     got = nm.detect_host(s0, None if kw else off0, s1, None if kw else off1, rid, nb=2, weights_dif=2.0, method='stouffer', **kw)
+    st = L.last_dispatch_stats()
     H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
     assert np.array_equal(got['status'], exp['status'])
+    # the form took the batch ('mixed': positions whose smaller group exceeds 1 024 samples, or whose groups fit 64 / 128 / 256 both, are not its)
+    share = st['rank_count_wide'] / P
+    assert st['skipped'] == 0 and share >= (0.45 if shape == 'mixed' else 0.95), (shape, st)
+    # ... and without it (NMOD_FLAG_NO_COUNT_WIDE) the sorting forms give the same integers: U, D, p bit for bit
+    srt = nm.detect_host(s0, None if kw else off0, s1, None if kw else off1, rid, nb=2, weights_dif=2.0, method='stouffer', flags=L.FLAG_NO_COUNT_WIDE, **kw)
+    assert L.last_dispatch_stats()['rank_count_wide'] == 0
+    for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p', 'comb_st', 'comb_p'):
+        assert np.array_equal(srt[k], got[k], equal_nan=True), (shape, k)
+    H.assert_close_p(srt['t_p'], got['t_p'], 1e-9, 't_p')
     got = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    st = L.last_dispatch_stats()
+    if shape in ('skew', 'skew_rev', '500v500', '1000v1000', 'stride600'):       # KS only: positions whose larger group holds >= 320 samples
+        assert st['rank_count_wide'] >= 0.8 * P and st['ks_rank'] + st['big'] == P - st['rank_count_wide'], (shape, st)
     assert np.array_equal(got['ks_d'], exp['ks_d'])
     H.assert_close_p(got['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
+    srt = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=L.FLAG_NO_COUNTING)
+    assert L.last_dispatch_stats()['rank_count_wide'] == 0
+    for k in ('ks_d', 'ks_p', 'comb_st', 'comb_p'):
+        assert np.array_equal(srt[k], got[k], equal_nan=True), (shape, k)
 
 
 @pytest.mark.parametrize('dtype', ['i16', 'f32', 'f64'])
@@ -593,11 +638,18 @@ def test_count_wide_edges(nm, dtype):
         s1[off1[off_grid_at + 1] + 3] = np.nextafter(s1[off1[off_grid_at + 1] + 3], np.float32(-9))
     exp = oracle_c.detect_batch(s0 if dtype == 'f32' else k0, off0, s1 if dtype == 'f32' else k1, off1, rid, 0, 2.0, 'fisher', tests=7)
     got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher')
+    st = L.last_dispatch_stats()
+    # the bulk (300 positions) is the form's; of the edge positions it hands on at most all
+    assert st['rank_count_wide'] >= 300 and st['count_rejected'] <= P - 300 and st['count_tried'] >= 300 and st['skipped'] == 0, st
     ident = (exp['status'] & L.STATUS_MWU_ALL_IDENTICAL) != 0
     assert ident[edge_at] and ident.sum() == 1 and np.array_equal(got['status'], exp['status'])
     for d in (got, exp):
         d['mwu_u'][ident] = 0.0; d['mwu_p'][ident] = 0.0
     H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
+    srt = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=L.FLAG_NO_COUNTING)
+    assert L.last_dispatch_stats()['count_tried'] == 0
+    for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p'):                  # the sorting forms alone: the same integers, so U, D and p bit for bit
+        assert np.array_equal(srt[k][~ident], got[k][~ident]), k
     lo = edge_at                                               # the edge positions alone: whatever the probes decide, the same numbers
     sub = nm.detect_host(s0[off0[lo]:], off0[lo:] - off0[lo], s1[off1[lo]:], off1[lo:] - off1[lo], rid[lo:], nb=0, weights_dif=2.0, method='fisher')
     for k in ('mwu_p', 'ks_d', 'ks_p'):
@@ -626,10 +678,14 @@ def test_random_batches_vs_oracle(nm, sizes, grid):
     sig0, off0, sig1, off1, rid = _random_batch(rng, npos, *sizes, grid=grid)
     for method in ('stouffer', 'fisher'):
         got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method=method)
+        st = nm._lib.last_dispatch_stats()
         exp = orc.detect_batch(sig0, off0, sig1, off1, rid, 2, 2.0,
                                orc.METHOD_STOUFFER if method == 'stouffer' else orc.METHOD_FISHER)
         H.compare_outputs(got, exp, True)
         assert np.array_equal(got['status'], exp['status'])
+        assert st['positions'] == npos and st['skipped'] == 0 and st['ks_rank'] == 0
+        if not grid:                 # continuous rows: the probes keep the counting forms out
+            assert st['count_tried'] == 0 and st['rank_count'] + st['rank_count_wide'] == 0, st
 
 
 @pytest.mark.parametrize('sizes', [(5, 64, 5, 64), (65, 128, 3, 30), (129, 256, 129, 256), (200, 200, 200, 200),
@@ -1611,7 +1667,7 @@ def test_ks_only_d_is_bit_exact_and_the_rational_flag_opts_out(nm):
     res = det.run(da, db, r, off0=o0, off1=o1, max_n0=900, max_n1=900)
     assert np.array_equal(res['ks_d'].cpu().numpy(), exp['ks_d'])
     with pytest.raises(L.NanomodLibraryError):
-        nm.DeviceDetector(0, tests=L.TEST_KS, flags=8).run(da, db, r, off0=o0, off1=o1, max_n0=900, max_n1=900)
+        nm.DeviceDetector(0, tests=L.TEST_KS, flags=64).run(da, db, r, off0=o0, off1=o1, max_n0=900, max_n1=900)
 
 
 @pytest.mark.parametrize('all_tests', [False, True])

@@ -15,11 +15,20 @@
 // Per streamed int16 sample 12.5 instructions (pairs: v_pk_sub_i16, v_pk_min_u16 against the window size, v_dot2 moment sums about the
 // window's centre, v_mad_u32_u16 with op_sel for the address) against 27 for the sorting form's binary search alone; float32 adds
 // the sample's key (grid_key, 9) and its fp64 moment sums (4).  KS only: the adds return nothing, no moments, no MWU sums.
+// Outliers (round 6).  Stored events are clipped at +-5 units (myRefBaseSignalAnnotation.py:251-259) and a mis-segmented read sits
+// anywhere in that range: one such sample in ~1 200 must not cost the position its form.  The window is centred on a robust centre
+// of S (its mean, then the mean of the samples within 1 024 of that); a sample of either group outside the window — a TAIL sample,
+// at most kCwTail = 64 per position — goes to a list in LDS instead of the table: key | group << 16, appended under an exec mask on
+// the rare path (int16 rows: one v_or per pair of samples keeps watch, the samples of a chunk group are looked at again only
+// when the wave saw one).  The samples below the window enter the scan as its carry-in, so every in-window look-up is the count
+// over the WHOLE group; the tail samples — one per lane — are finished exactly by an all-pairs pass over the list (readlane
+// broadcast): their counts at and just below their values (KS candidates and MWU terms of S's tail samples), their copies among
+// the tail (tie term), their true moment terms.
 // A position is left to the sorting forms (flag byte per list entry, compacted into a work list by cnt_compact_kernel; the sorting
 // kernel of the class walks that list where the class's gate is set: RankStatsArgs::alt_*) when a group is out of range, a float32
-// sample is off the milli-unit grid, S spans 2 047 values or more, or a sample of Q falls outside the window (it lands in a dump
-// entry and the table's total comes up short).  Whether a class of a batch is event-like at all is decided by
-// cnt_wide_probe_kernel on a sample of its positions (gate): continuous signals pay the probe and two empty launches.
+// sample is off the milli-unit grid, or more than kCwTail samples fall outside the window.  Whether a class of a batch is
+// event-like at all is decided by cnt_wide_probe_kernel on a sample of its positions (gate): continuous signals pay the probe
+// and two empty launches.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,7 +39,9 @@ namespace nmod {
 
 constexpr int kCwMaxQ = 4095;                                  // Q's half of a word, and |A nQ - B nS| through 16-bit dot products
 constexpr int kCwWindow = 2048;                                // values the table covers: 64 lane blocks of 32 entries
-constexpr int kCwWaveWords = 64 * 36 + 8;                      // a lane's block: 4 pad words + up to 32 entries; + the dump entry: 9 248 B per wave
+constexpr int kCwTail = 64;                                    // tail samples (outside the window) a position may have: one per lane
+constexpr int kCwTableWords = 64 * 36 + 8;                     // a lane's block: 4 pad words + up to 32 entries; + the dump entry
+constexpr int kCwWaveWords = kCwTableWords + kCwTail + 4;      // + the tail list and its counter: 9 536 B per wave, four blocks of four waves per CU
 __host__ __device__ constexpr size_t rank_count_wide_lds_bytes() { return (size_t)kWavesPerBlock * kCwWaveWords * 4; }
 
 struct CntWideArgs {
@@ -68,28 +79,39 @@ __global__ __launch_bounds__(1024) void cnt_wide_probe_kernel(CntWideProbeArgs a
     const int64_t li = (j * count) / nsamp;
     const int64_t pos = list ? (int64_t)list[li] : li;
     bool ok = true;
-    int lo = 0x7fffffff, hi = (int)0x80000000;
-    int nn[2];
+    int nn[2]; int64_t oo[2];
     for (int g = 0; g < 2; ++g) {
       const int64_t st = g ? a.stride1 : a.stride0;
       const int64_t* off = g ? a.off1 : a.off0;
-      const int64_t o = st > 0 ? pos * st : off[pos];
-      const int n = st > 0 ? (int)st : (int)(off[pos + 1] - o);
-      nn[g] = n;
-      const void* sig = g ? a.sig1 : a.sig0;
-      for (int i = lane; i < n && i <= kCwMaxQ; i += 64) {
-        int k;
-        if constexpr (DTYPE == 0) { if (!grid_key<true>(reinterpret_cast<const float*>(sig)[o + i], k)) ok = false; }
-        else if constexpr (DTYPE == 2) { if (!cnt_int_key(reinterpret_cast<const float*>(sig)[o + i], k)) ok = false; }
-        else k = (int)reinterpret_cast<const int16_t*>(sig)[o + i];
-        lo = min(lo, k); hi = max(hi, k);
-      }
+      oo[g] = st > 0 ? pos * st : off[pos];
+      nn[g] = st > 0 ? (int)st : (int)(off[pos + 1] - oo[g]);
     }
-    const int m = min(nn[0], nn[1]), q = max(nn[0], nn[1]);
+    auto key_at = [&](int g, int i, int& k) -> bool {
+      const void* sig = g ? a.sig1 : a.sig0;
+      if constexpr (DTYPE == 0) return grid_key<true>(reinterpret_cast<const float*>(sig)[oo[g] + i], k);
+      else if constexpr (DTYPE == 2) return cnt_int_key(reinterpret_cast<const float*>(sig)[oo[g] + i], k);
+      else { k = (int)reinterpret_cast<const int16_t*>(sig)[oo[g] + i]; return true; }
+    };
+    const int gs = nn[1] < nn[0] ? 1 : 0;                  // S = the smaller group (ties: group 1), as in cw_segment
+    const int m = nn[gs], q = nn[1 - gs];
     if (m < 1 || m > a.max_s[blockIdx.x] || q > kCwMaxQ) ok = false;
-    const int vmax = (int)(wave_max_u32((unsigned)hi ^ 0x80000000u) ^ 0x80000000u);
-    const int vmin = (int)(~wave_max_u32(~((unsigned)lo ^ 0x80000000u)) ^ 0x80000000u);
-    const bool fit = __ballot(!ok) == 0ull && (unsigned)(vmax - vmin) < 2048u;
+    // the window the kernel would pick: the mean of S, then the mean of S's samples within 1 024 of it
+    int tails = 0;
+    if (ok) {
+      long long s1 = 0;
+      for (int i = lane; i < m; i += 64) { int k; if (!key_at(gs, i, k)) ok = false; s1 += k; }
+      s1 = (long long)wave_sum_u64((unsigned long long)s1);
+      const int c0 = (int)__builtin_rintf((float)s1 / (float)m);
+      long long s2 = 0; unsigned c2 = 0;
+      for (int i = lane; i < m; i += 64) { int k; key_at(gs, i, k); const int d = k - c0; if ((unsigned)(d + 1024) < 2048u) { s2 += d; ++c2; } }
+      s2 = (long long)wave_sum_u64((unsigned long long)s2); c2 = (unsigned)wave_sum_u64((unsigned long long)c2);
+      const int c = c2 ? c0 + (int)__builtin_rintf((float)s2 / (float)c2) : c0;
+      const int base = max(-32768, min(c - 1024, 32768 - 2048));
+      for (int g = 0; g < 2; ++g)
+        for (int i = lane; i < nn[g] && i <= kCwMaxQ; i += 64) { int k; if (!key_at(g, i, k)) ok = false; tails += ((unsigned)(k - base) >= 2048u) ? 1 : 0; }
+      tails = (int)wave_sum_u64((unsigned long long)tails);
+    }
+    const bool fit = __ballot(!ok) == 0ull && tails <= kCwTail / 2;      // (half the list: the probe's window is only close to the kernel's)
     if (lane == 0) { atomicAdd(&looked, 1); if (q >= a.min_q) { atomicAdd(&seen, 1); if (fit) atomicAdd(&fits, 1); } }
   }
   __syncthreads();
@@ -312,24 +334,34 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         for (int r = 0; r < RS; ++r) ks[r] = (r * 64 + lane < mm) ? (int)raw[r] : ks0;
       }
     }
-    int smin, smax;
-    {
-      int kmx = ks[0], kmn = ks[0];
-#pragma unroll
-      for (int r = 1; r < RS; ++r) { kmx = max(kmx, ks[r]); kmn = min(kmn, ks[r]); }
-      const unsigned P = cw_wave_max_pk_u16(((unsigned)(kmx + 32768) & 0xffffu) | ((unsigned)(32767 - kmn) << 16));   // (a float32 key out of range: `bad`)
-      smax = (int)(P & 0xffffu) - 32768; smin = 32767 - (int)(P >> 16);
-    }
-    fit = fit && __ballot(bad) == 0ull && (smax - smin) < kCwWindow - 1;
-    // the window: 2 048 values centred on S (Q is 10-20 times S at skewed coverage and spreads a little further; a sample of Q outside
-    // the window lands in the dump entry, the table's total comes up short and the position goes to the sorting form); E = 1 << lgE
-    // entries per lane block.  (A window of 512 / 1 024 values where S's range allowed it — a shorter clear and scan — was measured:
-    // event-like rows at sigma >= 0.1 never took it, and its wave-uniform branches cost every position 4-8 %.)
+    fit = fit && __ballot(bad) == 0ull;
+    // the window: 2 048 values around a robust centre of S — its mean, then the mean of its samples within 1 024 of that (one
+    // mis-segmented read among ~57 moves the mean by ~90 milli-units and not the second estimate); samples of either group
+    // outside it are the position's tail (header comment).  E = 1 << lgE entries per lane block.  (A window of 512 / 1 024 values
+    // where S's range allowed it — a shorter clear and scan — was measured in round 5: event-like rows at sigma >= 0.1 never took
+    // it, and its wave-uniform branches cost every position 4-8 %.)
     constexpr int lgE = 5;
     constexpr int W = 64 << lgE;
-    int base = ((smin + smax) >> 1) - (W >> 1);
+    int centre;
+    {
+      int s1 = 0;
+#pragma unroll
+      for (int r = 0; r < RS; ++r) s1 += (r * 64 + lane < mm) ? ks[r] : 0;
+      const float rm_f = (float)rcp_m;
+      const int c0 = (int)__builtin_rintf((float)(int)cw_wave_sum_u32((unsigned)s1) * rm_f);
+      unsigned pk = 0u;                                    // count << 21 | sum of (k - c0 + 1 024) over the samples within 1 024 of c0
+#pragma unroll
+      for (int r = 0; r < RS; ++r) {
+        const unsigned dd = (unsigned)(ks[r] - c0 + 1024);
+        pk += (r * 64 + lane < mm && dd < 2048u) ? dd + (1u << 21) : 0u;
+      }
+      const unsigned P2 = cw_wave_sum_u32(pk);
+      const int cnt2 = (int)(P2 >> 21), sd2 = (int)(P2 & 0x1fffffu) - 1024 * cnt2;
+      centre = cnt2 > 0 ? c0 + (int)__builtin_rintf((float)sd2 * __builtin_amdgcn_rcpf((float)cnt2)) : c0;
+    }
+    int base = centre - (W >> 1);
     base = max(-32768, min(base, 32768 - W));             // (inside the int16 domain: k - base mod 2^16 cannot alias into the window)
-    const int c = base + (W >> 1);                         // moments are taken about the centre: |k - c| <= 1 024
+    const int c = base + (W >> 1);                         // moments are taken about the centre: |k - c| <= 1 024 inside the window
 
     unsigned sp = 0u, sp2 = 0u;                            // over the arrivals of both groups: p = earlier copies of the sample's value
     int is1 = 0, iq1 = 0; unsigned is2 = 0u, iq2 = 0u;     // int16 rows: exact sums of k - c
@@ -338,14 +370,24 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
     double dmax = 0.0;
     constexpr bool KEEPA = RS <= 8;                        // the samples' table addresses stay in registers (RS = 16: recomputed from the keys)
     unsigned addr[KEEPA ? RS : 1];
+    unsigned inmask = 0u;                                  // bit r: sample r of S exists and lies inside the window
+    int nt = 0, nt_q_pol = 0;                              // tail samples of the position (wave-uniform), those of Q; lane i < nt holds sample i:
+    bool t_val = false; int t_key = 0; unsigned t_grp = 0u, t_le = 0u, t_lt = 0u, t_p = 0u;
+    const unsigned tail_b = tb + (unsigned)kCwTableWords * 4u, tailcnt_b = tail_b + (unsigned)kCwTail * 4u;
+    // a sample outside the window: key | group << 16 to the tail list (called under a divergent exec mask, on the rare path)
+    auto tail_append = [&](int k, unsigned grp) {
+      const unsigned idx = __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)tailcnt_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (idx < (unsigned)kCwTail) *(CntLdsU32)(uintptr_t)(tail_b + (idx << 2)) = ((unsigned)k & 0xffffu) | (grp << 16);
+    };
     const CntS2 qm = {(short)q, (short)-m};
     constexpr int nch = 1 << (lgE - 2);                    // 16-byte chunks of a lane block
     uint4* blk = reinterpret_cast<uint4*>(__builtin_assume_aligned(reinterpret_cast<char*>(tbl) + lane * ((4 << lgE) + 16) + 16, 16));
     auto entry = [&](unsigned u) -> unsigned { return tbE + (u << 2) + ((u >> lgE) << 4); };
-    auto below_of = [&](int r, bool have) -> unsigned {      // LDS address of the word just below sample r's own (no sample: two zero words of block 0's pad)
-      if constexpr (KEEPA) return have ? addr[r] - 4u : tb + 8u;
-      else return have ? entry((unsigned)(ks[r] - base)) - 4u : tb + 8u;
+    auto below_of = [&](int r, bool have) -> unsigned {      // LDS address of the word just below sample r's own (no sample in the window: the two zero words at the head of block 0's pad)
+      if constexpr (KEEPA) return have ? addr[r] - 4u : tb;
+      else return have ? entry((unsigned)(ks[r] - base)) - 4u : tb;
     };
+    auto in_window = [&](int r) -> bool { return ((inmask >> r) & 1u) != 0u; };
     if (fit) {
       {                                                    // ---- clear
         unsigned z = 0u;
@@ -353,11 +395,14 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
 #pragma unroll
         for (int i = 0; i < 9; ++i) if (i <= nch) blk[i - 1] = make_uint4(z, z, z, z);
         *(CntLdsU32)(uintptr_t)entry((unsigned)W) = z;     // the dump entry
+        *(CntLdsU32)(uintptr_t)tailcnt_b = z;              // the tail list is empty
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
       // count one sample; the word that comes back holds the copies of its value counted before it (both groups): its arrival
-      // number p.  A sample that does not exist adds nothing to the dump entry, which stays 0 in a position that fits.
+      // number p.  A sample that does not exist, or lies outside the window, adds nothing: to the dump entry (float32 rows, S) —
+      // which then stays 0, p = 0 — or as 0x10000 to it (int16 rows of Q, where the add is unconditional: the arrival numbers the
+      // dump entry hands back are 0, 1, 2, ... and their share of the tie sums is taken out again below).
       // (Using the word four arrivals later, when it has long returned, changed nothing: measured, profiles/r5_count_wide_ab.txt.)
       auto arrive = [&](unsigned a, unsigned inc, bool have) {
         if constexpr (KS && DTYPE != 2) {                  // (KS only: no tie term — the add returns nothing)
@@ -371,13 +416,23 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         }
       };
       // ---- S
+      bool s_tail = false;
 #pragma unroll
       for (int r = 0; r < RS; ++r) {
         const bool have = r * 64 + lane < m;
-        const unsigned a_ = entry(have ? (unsigned)(ks[r] - base) : (unsigned)W);      // (no sample: the dump entry, one past the window)
+        const unsigned u = (unsigned)(ks[r] - base);
+        const bool in = have && u < (unsigned)W;
+        inmask |= in ? (1u << r) : 0u;
+        s_tail = s_tail || (have && !in);
+        const unsigned a_ = entry(in ? u : (unsigned)W);         // (no sample in the window: the dump entry, one past it; nothing is added)
         if constexpr (KEEPA) addr[r] = a_;
-        arrive(a_, 1u, have);
-        if constexpr (RDT == 1 && !KS) { const int d = have ? ks[r] - c : 0; is1 += d; is2 += (unsigned)__mul24(d, d); }
+        arrive(a_, 1u, in);
+        if constexpr (RDT == 1 && !KS) { const int d = in ? ks[r] - c : 0; is1 += d; is2 += (unsigned)__mul24(d, d); }
+      }
+      if (__ballot(s_tail) != 0ull) {                        // (rare; wave-uniform)
+#pragma unroll
+        for (int r = 0; r < RS; ++r)
+          if (r * 64 + lane < m && !in_window(r)) tail_append(ks[r], 0u);
       }
       // ---- Q, streamed once
       const double KQ = (double)xq0;
@@ -387,10 +442,12 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         const bool ok = key_of(x, k);
         bad = bad || !ok;
         if constexpr (DTYPE == 0 && !KS) { const double d = (double)x - KQ; mq1 += d; mq2 = __fma_rn(d, d, mq2); }
-        unsigned u = min((unsigned)(k - base), (unsigned)W);
-        u = have ? u : (unsigned)W;
-        arrive(entry(u), 0x10000u, have);
+        const unsigned u = min((unsigned)(k - base), (unsigned)W);
+        const bool in = have && u < (unsigned)W;
+        arrive(entry(in ? u : (unsigned)W), 0x10000u, in);
+        if (have && !in) tail_append(k, 1u);
       };
+      unsigned watch = 0u;                      // OR of the pairs' clamped values: bit 11 of a half <=> a sample outside the window
       auto q_pair16 = [&](unsigned kk) {        // two int16 samples of a full chunk
         const CntS2 d2 = __builtin_bit_cast(CntS2, kk) - __builtin_bit_cast(CntS2, cc);
         if constexpr (!KS) {
@@ -398,11 +455,17 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
           iq2 = (unsigned)__builtin_amdgcn_sdot2(d2, d2, (int)iq2, false);
         }
         const unsigned uu = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(CntU2, d2) + __builtin_bit_cast(CntU2, hw2), __builtin_bit_cast(CntU2, w2)));
+        watch |= uu;
         const unsigned x0 = ((uu & 0xffffu) >> lgE << 4) + tbE, x1 = ((uu >> 16) >> lgE << 4) + tbE;
         unsigned a0, a1;
         asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(a0) : "v"(uu), "v"(x0));
         asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(uu), "v"(x1));
         arrive(a0, 0x10000u, true); arrive(a1, 0x10000u, true);
+      };
+      auto tail_of_pair16 = [&](unsigned kk) {   // the rare path: which of the pair's samples lie outside the window
+        const int k0 = (int)(short)(kk & 0xffffu), k1 = (int)(short)(kk >> 16);
+        if ((unsigned)(k0 - base) >= (unsigned)W) tail_append(k0, 1u);
+        if ((unsigned)(k1 - base) >= (unsigned)W) tail_append(k1, 1u);
       };
 #pragma unroll 1
       for (int ch0 = 0; ch0 < full; ch0 += PF) {
@@ -424,6 +487,18 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
             }
           }
         }
+        if constexpr (RDT == 1) {
+          if (__ballot((watch & 0x08000800u) != 0u) != 0ull) {   // (wave-uniform) a sample of these chunks fell outside the window
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+              if (ch0 + j < full) {
+                const CntWU2 two = __builtin_bit_cast(CntWU2, qb[j]);
+                tail_of_pair16(two.x); tail_of_pair16(two.y);
+              }
+            }
+            watch = 0u;
+          }
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -440,12 +515,13 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
               iq1 = __builtin_amdgcn_sdot2(d2, sone2, iq1, false);
               iq2 = (unsigned)__builtin_amdgcn_sdot2(d2, d2, (int)iq2, false);
             }
-            unsigned uu = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(CntU2, d2) + __builtin_bit_cast(CntU2, hw2), __builtin_bit_cast(CntU2, w2)));
-            uu = have ? uu : (unsigned)W;
+            const unsigned uu = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(CntU2, d2) + __builtin_bit_cast(CntU2, hw2), __builtin_bit_cast(CntU2, w2)));
             const unsigned x0 = ((uu & 0xffffu) >> lgE << 4) + tbE;
             unsigned a0;
             asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(a0) : "v"(uu), "v"(x0));
-            arrive(a0, 0x10000u, have);
+            // (a sample that does not exist: a zero word of block 0's pad — the dump entry's arrival numbers are the tail samples')
+            arrive(have ? a0 : tb, 0x10000u, have);
+            if (have && (uu & 0xffffu) == (unsigned)W) tail_append((int)cur1, 1u);
           }
         }
       }
@@ -458,9 +534,33 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
       unsigned tot = 0u;
 #pragma unroll
       for (int i = 0; i < 8; ++i) if (i < nch) { const uint4 v = blk[i]; tot += (v.x + v.y) + (v.z + v.w); }
-      const unsigned below = seg_exscan_add_u32<64>(tot, lane);
-      const unsigned all_in = __builtin_amdgcn_readlane(below + tot, 63);
-      fit = __ballot(bad) == 0ull && all_in == ((unsigned)m | ((unsigned)q << 16));      // (short: a sample fell outside the window)
+      unsigned below = seg_exscan_add_u32<64>(tot, lane);
+      const unsigned all_in = __builtin_amdgcn_readlane(below + tot, 63);     // samples inside the window: S | Q << 16
+      // ---- the tail: what is missing from the window's total sits in the list (more than it holds: the position goes to the sorting form)
+      const int nt_s = m - (int)(all_in & 0xffffu), nt_q = q - (int)(all_in >> 16);
+      nt = nt_s + nt_q; nt_q_pol = nt_q;
+      const int listed = nt > 0 ? (int)__builtin_amdgcn_readfirstlane((int)*(CntLdsU32)(uintptr_t)tailcnt_b) : 0;
+      fit = __ballot(bad) == 0ull && nt <= kCwTail && listed == nt;
+      if (fit && nt > 0) {                                   // (wave-uniform) lane i < nt holds tail sample i
+        const unsigned e = *(CntLdsU32)(uintptr_t)(tail_b + ((unsigned)min(lane, kCwTail - 1) << 2));
+        t_val = lane < nt;
+        t_key = (int)(short)(e & 0xffffu); t_grp = (e >> 16) & 1u;
+        const bool low = t_val && t_key < base;
+        const unsigned low_s = (unsigned)__popcll(__ballot(low && t_grp == 0u)), low_q = (unsigned)__popcll(__ballot(low && t_grp != 0u));
+        below += low_s | (low_q << 16);                      // the samples below the window: every in-window count includes them
+        // every tail sample against every other: the tail samples at or below / strictly below it (S | Q << 16), its earlier copies
+#pragma unroll 1
+        for (int j = 0; j < nt; ++j) {
+          const int kj = __builtin_amdgcn_readlane(t_key, j);
+          const unsigned incj = __builtin_amdgcn_readlane((int)t_grp, j) != 0 ? 0x10000u : 1u;
+          t_le += (kj <= t_key) ? incj : 0u;
+          t_lt += (kj < t_key) ? incj : 0u;
+          t_p += (kj == t_key && j < lane) ? 1u : 0u;
+        }
+        // ... and everything inside or below the window for a sample above it
+        const unsigned under = (t_val && !low) ? all_in : 0u;
+        t_le += under; t_lt += under;
+      }
       if (fit) {
         blk[-1] = make_uint4(0u, 0u, 0u, below);
         unsigned carry = below;
@@ -483,7 +583,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         int xs[KEEP ? 2 * RS : 2];
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
-          const bool have = r * 64 + lane < m;
+          const bool have = in_window(r);
           const CntLdsU32 pw = (CntLdsU32)(uintptr_t)below_of(r, have);
           const unsigned w0 = pw[0], w1 = pw[1];
           if constexpr (!KS) {
@@ -495,6 +595,19 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
           if constexpr (KEEP) { xs[2 * r] = x0; xs[2 * r + 1] = x1; }
           vmax = max(vmax, max(x0, x1)); vmin = min(vmin, min(x0, x1));
         }
+        // the tail samples of S: the same two candidates and MWU terms from the all-pairs counts (a word per candidate, A | B << 16)
+        int tx0 = 0, tx1 = 0;
+        if (nt > 0) {                                        // (wave-uniform)
+          const bool ts = t_val && t_grp == 0u;
+          const unsigned w0 = ts ? t_lt : 0u, w1 = ts ? t_le : 0u;
+          if constexpr (!KS) {
+            mws = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, w0), hi1, mws, false);
+            mws = __builtin_amdgcn_udot2(__builtin_bit_cast(CntU2, w1), hi1, mws, false);
+          }
+          tx0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, w0), qm, 0, false);
+          tx1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, w1), qm, 0, false);
+          vmax = max(vmax, max(tx0, tx1)); vmin = min(vmin, min(tx0, tx1));
+        }
         best = cw_wave_max_u32((unsigned)max(vmax, -vmin));
         // D in the float form at the candidates that reach the maximum (few: their table words are read again)
         if (best != 0u && !(KS && args.ks_rational_d)) {
@@ -505,7 +618,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
             int xr[2];
             if constexpr (KEEP) { xr[0] = xs[2 * r]; xr[1] = xs[2 * r + 1]; }
             else {
-              const CntLdsU32 pw = (CntLdsU32)(uintptr_t)below_of(r, r * 64 + lane < m);
+              const CntLdsU32 pw = (CntLdsU32)(uintptr_t)below_of(r, in_window(r));
               xr[0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, pw[0]), qm, 0, false);
               xr[1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, pw[1]), qm, 0, false);
             }
@@ -513,11 +626,20 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
             for (int e = 0; e < 2; ++e) {
               const bool hit = xr[e] == (int)best || xr[e] == -(int)best;
               if (__ballot(hit) != 0ull) {
-                const bool have = r * 64 + lane < m;
-                const unsigned w = ((CntLdsU32)(uintptr_t)below_of(r, have))[e];
+                const unsigned w = ((CntLdsU32)(uintptr_t)below_of(r, in_window(r)))[e];
                 const double d = fabs(hist_exact_quot((int)(w & 0xffffu), dm_, rm_) - hist_exact_quot((int)(w >> 16), dq_, rq_));
                 dmax = hit ? fmax(dmax, d) : dmax;
               }
+            }
+          }
+          if (nt > 0) {                                      // (wave-uniform) the tail samples of S that reach the maximum
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int xe = e ? tx1 : tx0;
+              const bool hit = t_val && t_grp == 0u && (xe == (int)best || xe == -(int)best);
+              const unsigned w = e ? t_le : t_lt;
+              const double d = fabs(hist_exact_quot((int)(w & 0xffffu), dm_, rm_) - hist_exact_quot((int)(w >> 16), dq_, rq_));
+              dmax = hit ? fmax(dmax, d) : dmax;
             }
           }
         }
@@ -527,7 +649,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
     if (fit) {                                             // (wave-uniform)
       dmax = wave_max_f64(dmax);
       if constexpr (KS) {
-        const bool any_tie = DTYPE == 2 && __ballot(sp != 0u) != 0ull;
+        const bool any_tie = DTYPE == 2 && __ballot(sp != 0u || (t_val && t_p != 0u)) != 0ull;
         if (lane == 0) {
           args.ks_num[pos] = best;
           args.ks_d_ref[pos] = dmax;
@@ -537,7 +659,12 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         const double dm = (double)m, dq = (double)q;
         const double rm = rcp_m, rq = rcp_q;
         const unsigned MWS = cw_wave_sum_u32(mws);           // <= 2 m q
-        const unsigned long long TIE = 3ull * wave_sum_u64((unsigned long long)(sp2 + sp));      // sum_v t^3 - n = 3 sum (p^2 + p)
+        // sum_v t^3 - n = 3 sum (p^2 + p) over the arrivals: the table's, + the tail samples' earlier copies among the tail, - what
+        // the dump entry handed the tail samples of an int16 Q as arrival numbers (0, 1, ..., nt_q - 1: sum of p^2 + p = (n-1) n (n+1) / 3)
+        if (nt > 0) { const unsigned tp = t_val ? t_p : 0u; sp += tp; sp2 += tp * tp; }
+        unsigned long long arrivals = wave_sum_u64((unsigned long long)sp2 + (unsigned long long)sp);
+        if constexpr (RDT == 1) arrivals -= (unsigned long long)(nt_q_pol > 0 ? nt_q_pol - 1 : 0) * (unsigned long long)nt_q_pol * (unsigned long long)(nt_q_pol + 1) / 3ull;
+        const unsigned long long TIE = 3ull * arrivals;
         double mean_s = 0.0, m2_s = 0.0, mean_q = 0.0, m2_q = 0.0;
         if constexpr (DTYPE == 0) {
           const double s1 = wave_sum_f64(ms1), s2 = wave_sum_f64(ms2), t1 = wave_sum_f64(mq1), t2 = wave_sum_f64(mq2);
@@ -545,8 +672,23 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
           mean_q = (double)xq0 + t1 * rq; m2_q = t2 - t1 * t1 * rq;
         } else if constexpr (DTYPE == 1) {
           // exact integer sums about the centre: |sum d| <= 4 095 * 1 024, sum d^2 <= 4 095 * 2^20 < 2^32
-          const double s1 = (double)(int)cw_wave_sum_u32((unsigned)is1), s2 = (double)cw_wave_sum_u32(is2);
-          const double t1 = (double)(int)cw_wave_sum_u32((unsigned)iq1), t2 = (double)cw_wave_sum_u32(iq2);
+          double s1 = (double)(int)cw_wave_sum_u32((unsigned)is1), s2 = (double)cw_wave_sum_u32(is2);
+          unsigned t1u = cw_wave_sum_u32((unsigned)iq1), t2u = cw_wave_sum_u32(iq2);
+          double t2x = 0.0;
+          if (nt > 0) {                                      // (wave-uniform) the tail samples' own terms, about the same centre
+            // S's sums left its tail samples out; Q's stream saw theirs through 16-bit arithmetic: (k - c) mod 2^16 — taken out
+            // again as that, put in as the true distance (|d| < 2^16: d^2 < 2^32, summed as two 16-bit halves)
+            const int d = t_val ? t_key - c : 0;
+            const int dw = (int)(short)d;
+            const unsigned dd = (unsigned)d * (unsigned)d;
+            const bool ts = t_val && t_grp == 0u, tq = t_val && t_grp != 0u;
+            s1 += (double)(int)cw_wave_sum_u32((unsigned)(ts ? d : 0));
+            s2 += (double)cw_wave_sum_u32(ts ? dd >> 16 : 0u) * 65536.0 + (double)cw_wave_sum_u32(ts ? dd & 0xffffu : 0u);
+            t1u += cw_wave_sum_u32((unsigned)(tq ? d - dw : 0));
+            t2u -= cw_wave_sum_u32(tq ? (unsigned)(dw * dw) : 0u);
+            t2x = (double)cw_wave_sum_u32(tq ? dd >> 16 : 0u) * 65536.0 + (double)cw_wave_sum_u32(tq ? dd & 0xffffu : 0u);
+          }
+          const double t1 = (double)(int)t1u, t2 = (double)t2u + t2x;
           mean_s = ((double)c + s1 * rm) * 1e-3; m2_s = __fma_rn(dm, s2, -s1 * s1) * rm * 1e-6;
           mean_q = ((double)c + t1 * rq) * 1e-3; m2_q = __fma_rn(dq, t2, -t1 * t1) * rq * 1e-6;
         }

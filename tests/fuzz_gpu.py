@@ -23,8 +23,8 @@ def run_round(rng):
     hi1 = int(rng.choice([3, 8, 40, 64, 65, 130, 260, 600, 1100, 2048, 2500, 9000]))
     lo0 = int(rng.integers(1, hi0 + 1)) if rng.random() < 0.5 else 1
     lo1 = int(rng.integers(1, hi1 + 1)) if rng.random() < 0.5 else 1
-    mode = rng.choice(['cont', 'grid2', 'grid0', 'grid3', 'offt', 'gmix', 'i16', 'i16t', 'i16w', 'f64', 'f64near', 'nonf', 'evt', 'evt16', 'evt64'])
-    npos = int(rng.integers(1, (400 if max(hi0, hi1) <= 600 else 40) // (4 if mode.startswith('f64') or mode == 'evt64' else 1) + 1))
+    mode = rng.choice(['cont', 'grid2', 'grid0', 'grid3', 'offt', 'gmix', 'i16', 'i16t', 'i16w', 'f64', 'f64near', 'nonf', 'evt', 'evt16', 'evt64', 'evto', 'evto16', 'evto64'])
+    npos = int(rng.integers(1, (400 if max(hi0, hi1) <= 600 else 40) // (4 if mode.startswith('f64') or mode in ('evt64', 'evto64') else 1) + 1))
     n0 = rng.integers(lo0, hi0 + 1, npos); n1 = rng.integers(lo1, hi1 + 1, npos)
     off0 = np.zeros(npos + 1, np.int64); off0[1:] = np.cumsum(n0)
     off1 = np.zeros(npos + 1, np.int64); off1[1:] = np.cumsum(n1)
@@ -43,19 +43,24 @@ def run_round(rng):
         for v in (a, b):
             k = rng.random(len(v)) < rng.choice([0.0005, 0.01, 0.3])
             v[k] = rng.choice([1.0, 7.0, 33.0, 4e4]) * rng.normal(0, 1, int(k.sum()))
-    elif mode in ('evt', 'evt16', 'evt64'):   # event-like rows: a level per position, a narrow spread, the milli-unit grid (the counting form)
+    elif mode in ('evt', 'evt16', 'evt64', 'evto', 'evto16', 'evto64'):   # event-like rows: a level per position, a narrow spread, the milli-unit grid (the counting forms)
         lev = rng.uniform(-3, 3, npos)
         lev0 = np.repeat(lev, n0); lev1 = np.repeat(lev, n1)
         sp = float(rng.choice([0.02, 0.1, 0.2, 0.35, 0.6]))
         a = np.round(lev0 + sp * rng.normal(0, 1, len(a)), 3); b = np.round(lev1 + sp * rng.normal(rng.choice([0.0, 1.0]), 1, len(b)), 3)
+        if mode.startswith('evto'):           # ... with outliers: reads anywhere in the +-5 unit clip range (the counting forms' tail lists), some of them repeated
+            frac = float(rng.choice([0.001, 0.01, 0.05, 0.2]))
+            for v in (a, b):
+                hit = rng.random(len(v)) < frac
+                v[hit] = np.round(rng.uniform(-5, 5, int(hit.sum())), int(rng.choice([3, 1, 0])))
     if mode == 'i16t':                        # int16 with heavy ties: up to hundreds of copies of a value (8-bit counters wrap)
         a, b = np.round(a, 1), np.round(b, int(rng.integers(0, 3)))
     elif mode == 'i16w':                      # int16 over most of the domain: many count windows
         a, b = np.clip(a * 8, -32.7, 32.7), np.clip(b * 8, -32.7, 32.7)
-    if mode.startswith('i16') or mode == 'evt16':
+    if mode.startswith('i16') or mode in ('evt16', 'evto16'):
         s0 = np.round(a * 1000).astype(np.int16); s1 = np.round(b * 1000).astype(np.int16)
         r0, r1 = s0.astype(np.float64) / 1000, s1.astype(np.float64) / 1000
-    elif mode == 'evt64':                     # the reference's own rows: float64 values k / 1000.0 (the float64 front end: integer keys)
+    elif mode in ('evt64', 'evto64'):         # the reference's own rows: float64 values k / 1000.0 (the float64 front end: integer keys)
         s0 = np.round(a * 1000) / 1000.0; s1 = np.round(b * 1000) / 1000.0
         r0, r1 = s0, s1
     elif mode in ('f64', 'f64near'):

@@ -664,6 +664,95 @@ def test_count_wide_edges(nm, dtype):
     assert np.all(np.abs(kr['ks_d'] - exp['ks_d']) <= 4.5e-16)
 
 
+@pytest.mark.parametrize('dtype', ['i16', 'f32', 'f64'])
+def test_count_wide_outliers_vs_oracle(nm, dtype):
+    """rank_count_wide.hpp's tail list (samples outside the 2 048-value window: mis-segmented reads anywhere in +-5 units,
+    myRefBaseSignalAnnotation.py:251-259): positions with 1, 2, 63, 64 and 65 such samples below / above the window, in the smaller /
+    the larger / both groups, repeated outlier values (ties among the tail), outliers at the ends of the int16 domain, an outlier
+    as the row's first sample; then random contamination at 1 / 10 / 50 per mille.  Every number against the oracle, all tests and
+    KS only; the form keeps every position with at most 64 tail samples (nmod_last_dispatch_stats)"""
+    import oracle_c
+    L = nm._lib
+    rng = np.random.default_rng(zlib.crc32(('cw-outliers' + dtype).encode()))
+    rows0, rows1 = [], []
+
+    def add(a, b):
+        rows0.append(np.asarray(a, dtype=np.int64)); rows1.append(np.asarray(b, dtype=np.int64))
+
+    def ev(n, lev=0, s=150):
+        return lev + np.clip(np.rint(s * rng.normal(0, 1, n)), -700, 700).astype(np.int64)
+
+    def out(n, side, lev=0):                                 # n outliers on one side (or either) of a window around lev, in the clip range
+        lo = rng.integers(-5000, lev - 1100, n) if lev - 1100 > -5000 else np.full(n, -5000)
+        hi = rng.integers(lev + 1100, 5001, n) if lev + 1100 < 5000 else np.full(n, 5000)
+        return lo if side < 0 else hi if side > 0 else np.where(rng.random(n) < 0.5, lo, hi)
+    for _ in range(500):                                     # the bulk (the probes look at 64 positions per class and want 7 of 8 to fit): skewed and 400 v 400
+        lev = int(rng.integers(-3000, 3000)); add(ev(int(rng.integers(700, 1400)), lev), ev(int(rng.integers(30, 65)), lev))
+        lev = int(rng.integers(-3000, 3000)); add(ev(int(rng.integers(300, 513)), lev), ev(int(rng.integers(300, 513)), lev))
+    edge_at = len(rows0)
+    kept = []                                                # edge positions the form must keep / hand on
+    for big, small in ((900, 50), (400, 400)):
+        for n_out in (1, 2, 63, 64, 65):
+            for side in (-1, 1, 0):
+                lev = int(rng.integers(-2500, 2500))
+                add(np.r_[ev(big - n_out, lev), out(n_out, side, lev)], ev(small, lev)); kept.append(n_out <= 64)       # in the larger group
+                if n_out < small - 8:
+                    add(ev(big, lev), np.r_[out(n_out, side, lev), ev(small - n_out, lev)]); kept.append(True)           # in the smaller group, first in its row
+        lev = 0
+        add(np.r_[ev(big - 40, lev), out(20, -1, lev), out(20, 1, lev)], np.r_[ev(small - 6, lev), out(3, -1, lev), out(3, 1, lev)]); kept.append(True)   # both groups, both sides
+        add(np.r_[ev(big - 30, lev), [4000] * 30], np.r_[ev(small - 4, lev), [4000] * 2, [-4000] * 2]); kept.append(True)           # the same value 32 times over both groups
+        add(np.r_[ev(big - 4, lev), [32767, 32767, -32768, -32767]], np.r_[ev(small - 2, lev), [32767, -32768]]); kept.append(True)  # the ends of the int16 domain
+        add(np.r_[ev(big - 1, 30000), [-32768]], ev(small, 30000)); kept.append(True)                                               # a window clamped at the domain's end
+        add(np.r_[ev(big - 1, -30000), [32767]], ev(small, -30000)); kept.append(True)
+    for frac, npos_f in ((0.001, 40), (0.01, 40), (0.05, 16)):   # random contamination of both groups
+        for _ in range(npos_f):
+            lev = int(rng.integers(-3000, 3000)); n0, n1 = int(rng.integers(700, 1400)), int(rng.integers(30, 65))
+            a, b = ev(n0, lev), ev(n1, lev)
+            for v in (a, b):
+                hit = rng.random(len(v)) < frac
+                v[hit] = rng.integers(-5000, 5001, int(hit.sum()))
+            add(a, b)
+    P = len(rows0)
+    off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum([len(r) for r in rows0])
+    off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum([len(r) for r in rows1])
+    k0 = np.concatenate(rows0).astype(np.int16); k1 = np.concatenate(rows1).astype(np.int16)
+    rid = np.zeros(P, np.int32)
+    s0, s1 = _as_dtype(k0, dtype), _as_dtype(k1, dtype)
+    exp = oracle_c.detect_batch(s0 if dtype == 'f32' else k0, off0, s1 if dtype == 'f32' else k1, off1, rid, 0, 2.0, 'fisher', tests=7)
+    # (one chunk: the host-resident entry probes every chunk's classes on their own, and a chunk made of the edge positions alone —
+    # they sit together — would keep its classes on the sorting forms)
+    assert L.load().nmod_host_pipeline_config(1 << 30, 0, 0, 0) == 0
+    try:
+        _count_wide_outlier_checks(nm, dtype, s0, off0, s1, off1, rid, exp, kept, P)
+    finally:
+        assert L.load().nmod_host_pipeline_config(0, 0, 0, 0) == 0
+
+
+def _count_wide_outlier_checks(nm, dtype, s0, off0, s1, off1, rid, exp, kept, P):
+    L = nm._lib
+    got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher')
+    st = L.last_dispatch_stats()
+    H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
+    assert np.array_equal(got['status'], exp['status'])
+    n_rej = kept.count(False)
+    assert st['skipped'] == 0 and st['count_tried'] == P, st
+    # the positions with 65 outliers are handed on; of the randomly contaminated ones at 50 per mille (~55 outliers of ~1 100) a few more
+    assert n_rej <= st['count_rejected'] <= n_rej + 25 and st['rank_count_wide'] == P - st['count_rejected'], (n_rej, st)
+    # the sorting forms alone: the same integers
+    srt = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=L.FLAG_NO_COUNTING)
+    assert L.last_dispatch_stats()['count_tried'] == 0
+    for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p'):
+        assert np.array_equal(srt[k], got[k]), k
+    H.assert_close_p(srt['t_p'], got['t_p'], 1e-9, 't_p')
+    # KS only (no tie term, no moments), D bit for bit; the exact-rational flag
+    ks = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    st = L.last_dispatch_stats()
+    assert np.array_equal(ks['ks_d'], exp['ks_d']) and st['rank_count_wide'] >= P - n_rej - 25
+    H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
+    kr = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=L.FLAG_KS_RATIONAL_D)
+    assert np.all(np.abs(kr['ks_d'] - exp['ks_d']) <= 4.5e-16)
+
+
 # general (64 lanes per group) and packed (two positions per wave) kernels, every capacity class
 @pytest.mark.parametrize('sizes', [(5, 64, 5, 64), (65, 128, 3, 30), (65, 128, 65, 128), (129, 256, 129, 256),
                                    (100, 128, 129, 220), (257, 512, 257, 512), (300, 512, 20, 256),

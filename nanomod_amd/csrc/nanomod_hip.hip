@@ -64,7 +64,7 @@ struct Workspace {
   uint32_t* ks_num; uint64_t* mwu_s; uint64_t* tie; double* moments;
   double* tmp_ks_d; double* tmp_ks_p; double* ks_d_ref;
   int32_t* order; int32_t* redo; uint8_t* cls; uint8_t* tied; uint8_t* cnt_done; uint8_t* nonfinite; int32_t* meta;
-  int32_t* work_list; int32_t* work_meta; uint8_t* cw_done;      // counting form for any coverage (rank_count_wide.hpp)   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
+  int32_t* work_list; int32_t* work_meta;      // counting form for any coverage (rank_count_wide.hpp)   // meta: [c] counts, [56 + c] offsets, [112 + c] cursors, [168..169] max n0/n1
   unsigned long long* stats;                                     // nmod_last_dispatch_stats: kStatsWords counters, written only on request
   int64_t bytes;
 };
@@ -107,8 +107,8 @@ static Workspace carve(void* base, int64_t npos) {
   w.nonfinite = (uint8_t*)take(npos);             // NMOD_FLAG_CHECK_FINITE: nonfinite_scan_kernel's flags
   w.meta = (int32_t*)take(kMetaInts * 4);
   w.work_list = (int32_t*)take(4 * npos);          // rank_count_wide.hpp: what the sorting forms still have to do, per class
-  w.work_meta = (int32_t*)take(kMetaInts * 4);      // [c] counts, [kClassStride + c] offsets, [2 kClassStride + c] the probes' gates
-  w.cw_done = (uint8_t*)take(npos + 16);
+  w.work_meta = (int32_t*)take(kMetaInts * 4);      // [c] counts, [kClassStride + c] offsets, [2 kClassStride + c] the probes' gates, [3 kClassStride ...] the classes tried
+  static_assert(3 * kClassStride + 1 + kClassStride <= kMetaInts, "work_meta: counts, offsets, gates, 1 + one class id per probe block");
   w.stats = (unsigned long long*)take(kStatsWords * 8);
   w.bytes = o;
   return w;
@@ -572,7 +572,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
   // (KS-only batches too — the form without the tie term and the moments — when a group of the batch can reach the size it takes)
   const bool cw_on = !counting_off && !cw_off && (all || std::max(max0, max1) >= kCwKsMinQ);
   CountWideWs cww;
-  cww.gates = ws.work_meta + 2 * kClassStride; cww.done = ws.cw_done; cww.work_list = ws.work_list; cww.work_meta = ws.work_meta;
+  cww.gates = ws.work_meta + 2 * kClassStride; cww.work_list = ws.work_list; cww.work_meta = ws.work_meta;
   auto cw_prepare = [&](const std::vector<int>& classes) -> hipError_t {
     if (classes.empty()) return hipSuccess;
     if (prm->dtype == NMOD_DTYPE_F32)

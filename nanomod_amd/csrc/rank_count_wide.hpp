@@ -35,20 +35,25 @@
 #include "rank_count.hpp"
 #include "rank_stats_launch.hpp"
 
+#ifndef NMOD_CW_OR3
+#define NMOD_CW_OR3 1        // 1: one v_or3_b32 per two pairs of int16 samples keeps watch for samples outside the window
+#endif
+
 namespace nmod {
 
 constexpr int kCwMaxQ = 4095;                                  // Q's half of a word, and |A nQ - B nS| through 16-bit dot products
 constexpr int kCwWindow = 2048;                                // values the table covers: 64 lane blocks of 32 entries
 constexpr int kCwTail = 64;                                    // tail samples (outside the window) a position may have: one per lane
 constexpr int kCwTableWords = 64 * 36 + 8;                     // a lane's block: 4 pad words + up to 32 entries; + the dump entry
-constexpr int kCwWaveWords = kCwTableWords + kCwTail + 4;      // + the tail list and its counter: 9 536 B per wave, four blocks of four waves per CU
+constexpr int kCwWaveWords = kCwTableWords + kCwTail;          // + the tail list: 9 504 B per wave, four blocks of four waves per CU
 __host__ __device__ constexpr size_t rank_count_wide_lds_bytes() { return (size_t)kWavesPerBlock * kCwWaveWords * 4; }
 
 struct CntWideArgs {
   RankStatsArgs rs;                                            // rows, class lists, outputs (cnt_gate / cnt_done unused here)
   const int32_t* gates;                                        // [class] the probe's verdict (cnt_wide_probe_kernel)
   const int32_t* segs;                                         // [0] number of classes to try, [1 + i] their ids
-  uint8_t* done;                                               // one byte per entry of the class lists
+  int32_t* work_list; int32_t* work_meta;                      // what the form hands on to the class's sorting form: the layout of pos_list / class_meta
+                                                               // (work_meta[c] = count — zeroed by the probe —, [kClassStride + c] = the list's offset)
 };
 
 typedef unsigned CntWU2 __attribute__((ext_vector_type(2)));
@@ -124,42 +129,13 @@ __global__ __launch_bounds__(1024) void cnt_wide_probe_kernel(CntWideProbeArgs a
   }
 }
 
-// ---- the work list of the sorting form that follows, for a class whose gate is set: the entries rank_count_wide_kernel left
-// (done == 0).  work_list / work_meta have the layout of pos_list / class_meta; a class whose gate is clear keeps its own list.
-struct CntCompactArgs {
-  int64_t npos; const int32_t* pos_list; const int32_t* class_meta;
-  const int32_t* gates; const int32_t* segs; const uint8_t* done; int32_t* work_list; int32_t* work_meta;       // work_meta[c] = count, [kClassStride + c] = offset
-};
-template <int DT, bool KS>
-__global__ __launch_bounds__(256) void cnt_compact_kernel(CntCompactArgs a) {
-  const int lane = threadIdx.x & 63;
-  __shared__ int base_s;
-  __shared__ int wcnt[4];
-  const int nseg = a.segs[0];
-  for (int sg = 0; sg < nseg; ++sg) {
-    const int cls = a.segs[1 + sg];
-    if (a.gates[cls] == 0) continue;                             // the form was not tried: the work list is the class list
-    int64_t count = a.npos, off = 0;
-    const int32_t* list = nullptr;
-    if (a.pos_list) { count = a.class_meta[cls]; off = a.class_meta[kClassStride + cls]; list = a.pos_list + off; }
-    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < count; i0 += (int64_t)gridDim.x * 256) {
-      const int64_t i = i0 + threadIdx.x;
-      const bool keep = i < count && a.done[off + i] == 0;
-      const unsigned long long m = __ballot(keep);
-      if (lane == 0) wcnt[threadIdx.x >> 6] = __popcll(m);
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        base_s = tot ? atomicAdd(&a.work_meta[cls], tot) : 0;
-      }
-      __syncthreads();
-      int at = base_s + __popcll(m & ((1ull << lane) - 1ull));
-      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) at += wcnt[w];
-      if (keep) a.work_list[off + at] = list ? list[i] : (int32_t)i;
-      __syncthreads();
-    }
-  }
-}
+// ---- the work list of the sorting form that follows, for a class whose gate is set: the positions rank_count_wide_kernel hands on.
+// The waves append them themselves: the positions whose SIZES are not the form's where the headers are loaded, 64 at a time (one
+// atomicAdd per batch of headers), a position whose samples turn out not to fit by one atomicAdd of its own (the probe saw 7 of 8
+// fit; usually far fewer are handed on).  (Queues of 64 rejected positions per wave, in a register or in LDS, flushed inside the
+// loop made the float32 instances spill 1.2 KB per lane.)  (Round 5 wrote a flag byte per position and ran
+// cnt_compact_kernel over them — a serial loop over the classes, 0.43 ms per 10 M positions, 4 % of the ragged KS pass.)  The
+// list's order is whatever order the waves flush in; every position's numbers are its own.
 
 // ---- wave-wide helpers of this form: four DPP steps inside each 16-lane row, two row broadcasts into lane 63, one v_readlane
 // (wave_ops.hpp's reductions read four row results and combine them with scalar instructions: eleven operations instead of seven)
@@ -201,7 +177,7 @@ static __device__ const CwRcpTable kCwRcp = CwRcpTable();
 
 // one class of the batch (a segment of the class lists): positions start, start + stride, ... of its list
 template <int DTYPE, int RS, bool KS>
-__device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* done, unsigned* tbl, int64_t count, int64_t loff, const int32_t* list,
+__device__ __forceinline__ void cw_segment(const RankStatsArgs& args, int32_t* work_list, int32_t* work_cnt, unsigned* tbl, int64_t count, int64_t loff, const int32_t* list,
                                            int64_t start, int64_t wave_stride, int lane) {
   constexpr int RDT = (DTYPE == 1) ? 1 : 0;
   using Q4Raw = typename std::conditional<RDT == 0, KsF4, KsS4>::type;
@@ -236,6 +212,17 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
     const bool ok = mr >= 1 && mr <= 64 * RS && qr >= 4 && qr <= kCwMaxQ && (!KS || qr >= kCwKsMinQ);   // (otherwise: left to the sorting form)
     const Q1Raw* dummy = reinterpret_cast<const Q1Raw*>(kKsBig4);                                       // (read as a row of one / four samples)
     hb_pos = (int)p;
+    {
+      // positions whose sizes are not this form's (KS only: the larger group below kCwKsMinQ — up to half of a class) go to the class's
+      // work list here, 64 headers at a time: one atomicAdd reserves the slots of the batch
+      const unsigned long long mk = __ballot(itj < count && !ok);
+      if (mk != 0ull) {                                      // (wave-uniform)
+        int at = 0;
+        if (lane == 0) at = atomicAdd(work_cnt, (int)__popcll(mk));
+        at = __builtin_amdgcn_readfirstlane(at);
+        if (itj < count && !ok) work_list[loff + at + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] = (int)p;
+      }
+    }
     hb_mq = (unsigned)(ok ? mr : 1) | ((unsigned)(ok ? qr : 4) << 12) | (sw ? 1u << 24 : 0u) | (ok ? 1u << 25 : 0u);
     hb_rs = (uint64_t)(uintptr_t)(ok ? reinterpret_cast<const Q1Raw*>(sw ? args.sig1 : args.sig0) + (sw ? o1 : o0) : dummy);
     hb_rq = (uint64_t)(uintptr_t)(ok ? reinterpret_cast<const Q1Raw*>(sw ? args.sig0 : args.sig1) + (sw ? o0 : o1) : dummy);
@@ -335,15 +322,26 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
       }
     }
     fit = fit && __ballot(bad) == 0ull;
-    // the window: 2 048 values around a robust centre of S — its mean, then the mean of its samples within 1 024 of that (one
-    // mis-segmented read among ~57 moves the mean by ~90 milli-units and not the second estimate); samples of either group
-    // outside it are the position's tail (header comment).  E = 1 << lgE entries per lane block.  (A window of 512 / 1 024 values
+    // the window: 2 048 values around a robust centre of S — its mid-range where S spans less than half a window (no outlier in S:
+    // the common case), else its mean, then the mean of its samples within 1 024 of that (one mis-segmented read among ~57 moves
+    // the mean by ~90 milli-units and not the second estimate); samples of either group outside it are the position's tail
+    // (header comment).  E = 1 << lgE entries per lane block.  (A window of 512 / 1 024 values
     // where S's range allowed it — a shorter clear and scan — was measured in round 5: event-like rows at sigma >= 0.1 never took
     // it, and its wave-uniform branches cost every position 4-8 %.)
     constexpr int lgE = 5;
     constexpr int W = 64 << lgE;
     int centre;
+    bool s_narrow;
     {
+      int kmx = ks[0], kmn = ks[0];
+#pragma unroll
+      for (int r = 1; r < RS; ++r) { kmx = max(kmx, ks[r]); kmn = min(kmn, ks[r]); }
+      const unsigned P = cw_wave_max_pk_u16(((unsigned)(kmx + 32768) & 0xffffu) | ((unsigned)(32767 - kmn) << 16));   // (a float32 key out of range: `bad`)
+      const int smax = (int)(P & 0xffffu) - 32768, smin = 32767 - (int)(P >> 16);
+      s_narrow = (smax - smin) < kCwWindow / 2;
+      centre = (smin + smax) >> 1;                         // S within 1 024 values: no outlier in it, the window sits on its mid-range
+    }
+    if (!s_narrow) {                                       // (wave-uniform) an outlier in S: its mean, then the mean of the samples within 1 024 of that
       int s1 = 0;
 #pragma unroll
       for (int r = 0; r < RS; ++r) s1 += (r * 64 + lane < mm) ? ks[r] : 0;
@@ -373,21 +371,31 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
     unsigned inmask = 0u;                                  // bit r: sample r of S exists and lies inside the window
     int nt = 0, nt_q_pol = 0;                              // tail samples of the position (wave-uniform), those of Q; lane i < nt holds sample i:
     bool t_val = false; int t_key = 0; unsigned t_grp = 0u, t_le = 0u, t_lt = 0u, t_p = 0u;
-    const unsigned tail_b = tb + (unsigned)kCwTableWords * 4u, tailcnt_b = tail_b + (unsigned)kCwTail * 4u;
-    // a sample outside the window: key | group << 16 to the tail list (called under a divergent exec mask, on the rare path)
-    auto tail_append = [&](int k, unsigned grp) {
-      const unsigned idx = __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)tailcnt_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      if (idx < (unsigned)kCwTail) *(CntLdsU32)(uintptr_t)(tail_b + (idx << 2)) = ((unsigned)k & 0xffffu) | (grp << 16);
+    int nt_s_ = 0;                                         // ... those of S
+    int ts_d = 0, tq_d = 0; unsigned tq_dw2 = 0u; unsigned long long ts_dd = 0ull, tq_dd = 0ull;   // the tail's moment terms (wave-uniform, int16 rows)
+    const unsigned tail_b = tb + (unsigned)kCwTableWords * 4u;
+    int listed = 0;                                        // samples in the tail list so far (wave-uniform: a scalar register, not a counter in LDS)
+    // the lanes whose sample lies outside the window append key | group << 16 to the tail list: called by the whole wave; the
+    // compare's lane mask is the ballot, a lane's slot is the list's length + the tail lanes below it (v_mbcnt) — no atomic, no
+    // round trip to LDS on the way (one ds_add_rtn per appended sample, each waiting for the LDS queue to drain, was 600 wave
+    // cycles per tail sample)
+    auto tail_push = [&](bool is_tail, int k, unsigned grp) {
+      const unsigned long long mk = __ballot(is_tail);
+      if (mk != 0ull) {                                    // (wave-uniform)
+        const unsigned idx = (unsigned)listed + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+        if (is_tail && idx < (unsigned)kCwTail) *(CntLdsU32)(uintptr_t)(tail_b + (idx << 2)) = ((unsigned)k & 0xffffu) | (grp << 16);
+        listed += (int)__popcll(mk);
+      }
     };
     const CntS2 qm = {(short)q, (short)-m};
     constexpr int nch = 1 << (lgE - 2);                    // 16-byte chunks of a lane block
     uint4* blk = reinterpret_cast<uint4*>(__builtin_assume_aligned(reinterpret_cast<char*>(tbl) + lane * ((4 << lgE) + 16) + 16, 16));
     auto entry = [&](unsigned u) -> unsigned { return tbE + (u << 2) + ((u >> lgE) << 4); };
     auto below_of = [&](int r, bool have) -> unsigned {      // LDS address of the word just below sample r's own (no sample in the window: the two zero words at the head of block 0's pad)
-      if constexpr (KEEPA) return have ? addr[r] - 4u : tb;
+      if constexpr (KEEPA) return addr[r] - 4u;              // (tb + 4 for a sample that is not in the window)
       else return have ? entry((unsigned)(ks[r] - base)) - 4u : tb;
     };
-    auto in_window = [&](int r) -> bool { return ((inmask >> r) & 1u) != 0u; };
+    auto in_window = [&](int r) -> bool { if constexpr (KEEPA) return true; else return ((inmask >> r) & 1u) != 0u; };   // (RS = 16: the addresses are not kept)
     if (fit) {
       {                                                    // ---- clear
         unsigned z = 0u;
@@ -395,7 +403,6 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
 #pragma unroll
         for (int i = 0; i < 9; ++i) if (i <= nch) blk[i - 1] = make_uint4(z, z, z, z);
         *(CntLdsU32)(uintptr_t)entry((unsigned)W) = z;     // the dump entry
-        *(CntLdsU32)(uintptr_t)tailcnt_b = z;              // the tail list is empty
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
@@ -416,24 +423,19 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         }
       };
       // ---- S
-      bool s_tail = false;
 #pragma unroll
       for (int r = 0; r < RS; ++r) {
         const bool have = r * 64 + lane < m;
         const unsigned u = (unsigned)(ks[r] - base);
         const bool in = have && u < (unsigned)W;
         inmask |= in ? (1u << r) : 0u;
-        s_tail = s_tail || (have && !in);
-        const unsigned a_ = entry(in ? u : (unsigned)W);         // (no sample in the window: the dump entry, one past it; nothing is added)
+        tail_push(have && !in, ks[r], 0u);
+        const unsigned a_ = in ? entry(u) : tb + 4u;             // (no sample in the window: a zero word of block 0's pad; nothing is added, nothing comes back)
         if constexpr (KEEPA) addr[r] = a_;
         arrive(a_, 1u, in);
         if constexpr (RDT == 1 && !KS) { const int d = in ? ks[r] - c : 0; is1 += d; is2 += (unsigned)__mul24(d, d); }
       }
-      if (__ballot(s_tail) != 0ull) {                        // (rare; wave-uniform)
-#pragma unroll
-        for (int r = 0; r < RS; ++r)
-          if (r * 64 + lane < m && !in_window(r)) tail_append(ks[r], 0u);
-      }
+
       // ---- Q, streamed once
       const double KQ = (double)xq0;
       const unsigned cc = ((unsigned)c & 0xffffu) * 0x10001u, hw2 = (unsigned)(W >> 1) * 0x10001u, w2 = (unsigned)W * 0x10001u;
@@ -445,7 +447,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         const unsigned u = min((unsigned)(k - base), (unsigned)W);
         const bool in = have && u < (unsigned)W;
         arrive(entry(in ? u : (unsigned)W), 0x10000u, in);
-        if (have && !in) tail_append(k, 1u);
+        tail_push(have && !in, k, 1u);
       };
       unsigned watch = 0u;                      // OR of the pairs' clamped values: bit 11 of a half <=> a sample outside the window
       auto q_pair16 = [&](unsigned kk) {        // two int16 samples of a full chunk
@@ -455,17 +457,21 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
           iq2 = (unsigned)__builtin_amdgcn_sdot2(d2, d2, (int)iq2, false);
         }
         const unsigned uu = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(CntU2, d2) + __builtin_bit_cast(CntU2, hw2), __builtin_bit_cast(CntU2, w2)));
+#if !NMOD_CW_OR3
         watch |= uu;
+#endif
         const unsigned x0 = ((uu & 0xffffu) >> lgE << 4) + tbE, x1 = ((uu >> 16) >> lgE << 4) + tbE;
         unsigned a0, a1;
         asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(a0) : "v"(uu), "v"(x0));
         asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(uu), "v"(x1));
         arrive(a0, 0x10000u, true); arrive(a1, 0x10000u, true);
+        return uu;
       };
       auto tail_of_pair16 = [&](unsigned kk) {   // the rare path: which of the pair's samples lie outside the window
-        const int k0 = (int)(short)(kk & 0xffffu), k1 = (int)(short)(kk >> 16);
-        if ((unsigned)(k0 - base) >= (unsigned)W) tail_append(k0, 1u);
-        if ((unsigned)(k1 - base) >= (unsigned)W) tail_append(k1, 1u);
+        const CntS2 d2 = __builtin_bit_cast(CntS2, kk) - __builtin_bit_cast(CntS2, cc);
+        const unsigned uu = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(CntU2, d2) + __builtin_bit_cast(CntU2, hw2), __builtin_bit_cast(CntU2, w2)));
+        tail_push((uu & 0x00000800u) != 0u, (int)(short)(kk & 0xffffu), 1u);
+        tail_push(uu >= 0x08000000u, (int)(short)(kk >> 16), 1u);
       };
 #pragma unroll 1
       for (int ch0 = 0; ch0 < full; ch0 += PF) {
@@ -483,7 +489,12 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
               q_f32(qb[j].x, true); q_f32(qb[j].y, true); q_f32(qb[j].z, true); q_f32(qb[j].w, true);
             } else {
               const CntWU2 two = __builtin_bit_cast(CntWU2, qb[j]);
-              q_pair16(two.x); q_pair16(two.y);
+              const unsigned ua = q_pair16(two.x), ub = q_pair16(two.y);
+#if NMOD_CW_OR3
+              asm("v_or3_b32 %0, %1, %2, %3" : "=v"(watch) : "v"(watch), "v"(ua), "v"(ub));
+#else
+              (void)ua; (void)ub;
+#endif
             }
           }
         }
@@ -521,7 +532,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
             asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(a0) : "v"(uu), "v"(x0));
             // (a sample that does not exist: a zero word of block 0's pad — the dump entry's arrival numbers are the tail samples')
             arrive(have ? a0 : tb, 0x10000u, have);
-            if (have && (uu & 0xffffu) == (unsigned)W) tail_append((int)cur1, 1u);
+            tail_push(have && (uu & 0xffffu) == (unsigned)W, (int)cur1, 1u);
           }
         }
       }
@@ -538,27 +549,37 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
       const unsigned all_in = __builtin_amdgcn_readlane(below + tot, 63);     // samples inside the window: S | Q << 16
       // ---- the tail: what is missing from the window's total sits in the list (more than it holds: the position goes to the sorting form)
       const int nt_s = m - (int)(all_in & 0xffffu), nt_q = q - (int)(all_in >> 16);
-      nt = nt_s + nt_q; nt_q_pol = nt_q;
-      const int listed = nt > 0 ? (int)__builtin_amdgcn_readfirstlane((int)*(CntLdsU32)(uintptr_t)tailcnt_b) : 0;
+      nt = nt_s + nt_q; nt_q_pol = nt_q; nt_s_ = nt_s;
       fit = __ballot(bad) == 0ull && nt <= kCwTail && listed == nt;
       if (fit && nt > 0) {                                   // (wave-uniform) lane i < nt holds tail sample i
         const unsigned e = *(CntLdsU32)(uintptr_t)(tail_b + ((unsigned)min(lane, kCwTail - 1) << 2));
         t_val = lane < nt;
         t_key = (int)(short)(e & 0xffffu); t_grp = (e >> 16) & 1u;
-        const bool low = t_val && t_key < base;
-        const unsigned low_s = (unsigned)__popcll(__ballot(low && t_grp == 0u)), low_q = (unsigned)__popcll(__ballot(low && t_grp != 0u));
-        below += low_s | (low_q << 16);                      // the samples below the window: every in-window count includes them
-        // every tail sample against every other: the tail samples at or below / strictly below it (S | Q << 16), its earlier copies
+        // every tail sample against every other: the tail samples at or below / strictly below it (S | Q << 16), its earlier copies.
+        // What depends on sample j alone is scalar arithmetic on the broadcast key (the SALU runs beside the vector work): how many
+        // lie below the window, and the samples' own moment terms about the window's centre — S's sums left its tail samples out,
+        // Q's int16 stream saw theirs through 16-bit arithmetic, (k - c) mod 2^16: taken out again as that, put in as the true
+        // distance (|d| < 2^16: d^2 < 2^32)
+        unsigned low_cnt = 0u;
 #pragma unroll 1
         for (int j = 0; j < nt; ++j) {
           const int kj = __builtin_amdgcn_readlane(t_key, j);
-          const unsigned incj = __builtin_amdgcn_readlane((int)t_grp, j) != 0 ? 0x10000u : 1u;
+          const bool qj = __builtin_amdgcn_readlane((int)t_grp, j) != 0;
+          const unsigned incj = qj ? 0x10000u : 1u;
           t_le += (kj <= t_key) ? incj : 0u;
           t_lt += (kj < t_key) ? incj : 0u;
           t_p += (kj == t_key && j < lane) ? 1u : 0u;
+          low_cnt += kj < base ? incj : 0u;
+          if constexpr (RDT == 1 && !KS) {
+            const int d = kj - c, dw = (int)(short)d;
+            const unsigned dd = (unsigned)d * (unsigned)d;
+            if (!qj) { ts_d += d; ts_dd += (unsigned long long)dd; }
+            else { tq_d += d - dw; tq_dw2 += (unsigned)(dw * dw); tq_dd += (unsigned long long)dd; }
+          }
         }
+        below += low_cnt;                                    // the samples below the window: every in-window count includes them
         // ... and everything inside or below the window for a sample above it
-        const unsigned under = (t_val && !low) ? all_in : 0u;
+        const unsigned under = (t_val && t_key >= base) ? all_in : 0u;
         t_le += under; t_lt += under;
       }
       if (fit) {
@@ -597,7 +618,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         }
         // the tail samples of S: the same two candidates and MWU terms from the all-pairs counts (a word per candidate, A | B << 16)
         int tx0 = 0, tx1 = 0;
-        if (nt > 0) {                                        // (wave-uniform)
+        if (nt_s_ > 0) {                                     // (wave-uniform)
           const bool ts = t_val && t_grp == 0u;
           const unsigned w0 = ts ? t_lt : 0u, w1 = ts ? t_le : 0u;
           if constexpr (!KS) {
@@ -632,14 +653,16 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
               }
             }
           }
-          if (nt > 0) {                                      // (wave-uniform) the tail samples of S that reach the maximum
+          if (nt_s_ > 0) {                                   // (wave-uniform) the tail samples of S that reach the maximum
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               const int xe = e ? tx1 : tx0;
               const bool hit = t_val && t_grp == 0u && (xe == (int)best || xe == -(int)best);
-              const unsigned w = e ? t_le : t_lt;
-              const double d = fabs(hist_exact_quot((int)(w & 0xffffu), dm_, rm_) - hist_exact_quot((int)(w >> 16), dq_, rq_));
-              dmax = hit ? fmax(dmax, d) : dmax;
+              if (__ballot(hit) != 0ull) {
+                const unsigned w = e ? t_le : t_lt;
+                const double d = fabs(hist_exact_quot((int)(w & 0xffffu), dm_, rm_) - hist_exact_quot((int)(w >> 16), dq_, rq_));
+                dmax = hit ? fmax(dmax, d) : dmax;
+              }
             }
           }
         }
@@ -675,18 +698,10 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
           double s1 = (double)(int)cw_wave_sum_u32((unsigned)is1), s2 = (double)cw_wave_sum_u32(is2);
           unsigned t1u = cw_wave_sum_u32((unsigned)iq1), t2u = cw_wave_sum_u32(iq2);
           double t2x = 0.0;
-          if (nt > 0) {                                      // (wave-uniform) the tail samples' own terms, about the same centre
-            // S's sums left its tail samples out; Q's stream saw theirs through 16-bit arithmetic: (k - c) mod 2^16 — taken out
-            // again as that, put in as the true distance (|d| < 2^16: d^2 < 2^32, summed as two 16-bit halves)
-            const int d = t_val ? t_key - c : 0;
-            const int dw = (int)(short)d;
-            const unsigned dd = (unsigned)d * (unsigned)d;
-            const bool ts = t_val && t_grp == 0u, tq = t_val && t_grp != 0u;
-            s1 += (double)(int)cw_wave_sum_u32((unsigned)(ts ? d : 0));
-            s2 += (double)cw_wave_sum_u32(ts ? dd >> 16 : 0u) * 65536.0 + (double)cw_wave_sum_u32(ts ? dd & 0xffffu : 0u);
-            t1u += cw_wave_sum_u32((unsigned)(tq ? d - dw : 0));
-            t2u -= cw_wave_sum_u32(tq ? (unsigned)(dw * dw) : 0u);
-            t2x = (double)cw_wave_sum_u32(tq ? dd >> 16 : 0u) * 65536.0 + (double)cw_wave_sum_u32(tq ? dd & 0xffffu : 0u);
+          if (nt > 0) {                                      // (wave-uniform) the tail samples' own terms, summed beside the all-pairs pass
+            s1 += (double)ts_d; s2 += (double)ts_dd;
+            t1u += (unsigned)tq_d; t2u -= tq_dw2;
+            t2x = (double)tq_dd;
           }
           const double t1 = (double)(int)t1u, t2 = (double)t2u + t2x;
           mean_s = ((double)c + s1 * rm) * 1e-3; m2_s = __fma_rn(dm, s2, -s1 * s1) * rm * 1e-6;
@@ -705,7 +720,9 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, uint8_t* d
         }
       }
     }
-    if (lane == 0) done[loff + it] = fit ? 1 : 0;
+    if (!fit && cur.fit) {                                 // (wave-uniform) its sizes were this form's, its samples are not: left to the class's sorting form
+      if (lane == 0) work_list[loff + atomicAdd(work_cnt, 1)] = (int)pos;
+    }
   }
 }
 
@@ -733,11 +750,11 @@ void rank_count_wide_kernel(CntWideArgs cw) {
     if (start < 0) start += nw;
     rot = (rot + count) % nw;
     switch (count_wide_rs_index(cls)) {
-      case 0: cw_segment<DTYPE, 1, KS>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
-      case 1: cw_segment<DTYPE, 2, KS>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
-      case 2: cw_segment<DTYPE, 4, KS>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
-      case 3: cw_segment<DTYPE, 8, KS>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
-      case 4: cw_segment<DTYPE, 16, KS>(args, cw.done, tbl, count, loff, list, start, nw, lane); break;
+      case 0: cw_segment<DTYPE, 1, KS>(args, cw.work_list, cw.work_meta + cls, tbl, count, loff, list, start, nw, lane); break;
+      case 1: cw_segment<DTYPE, 2, KS>(args, cw.work_list, cw.work_meta + cls, tbl, count, loff, list, start, nw, lane); break;
+      case 2: cw_segment<DTYPE, 4, KS>(args, cw.work_list, cw.work_meta + cls, tbl, count, loff, list, start, nw, lane); break;
+      case 3: cw_segment<DTYPE, 8, KS>(args, cw.work_list, cw.work_meta + cls, tbl, count, loff, list, start, nw, lane); break;
+      case 4: cw_segment<DTYPE, 16, KS>(args, cw.work_list, cw.work_meta + cls, tbl, count, loff, list, start, nw, lane); break;
       default: break;
     }
   }

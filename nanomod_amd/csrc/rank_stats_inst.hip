@@ -220,6 +220,7 @@ namespace nmod {
 
 hipError_t NMOD_CW_PREP_NAME(const int* classes, int nclasses, hipStream_t stream, const RankStatsArgs& a, const CountWideWs& w) {
   if (nclasses <= 0) return hipSuccess;
+  if (nclasses > kClassStride) return hipErrorInvalidValue;        // (cls[] / max_s[] / the segs area hold one entry per class)
   CntWideProbeArgs pa;
   pa.sig0 = a.sig0; pa.sig1 = a.sig1; pa.off0 = a.off0; pa.off1 = a.off1; pa.stride0 = a.stride0; pa.stride1 = a.stride1; pa.npos = a.npos;
   pa.pos_list = a.pos_list; pa.class_meta = a.class_meta; pa.nclasses = nclasses; pa.gate = w.gates; pa.segs = w.gates + kClassStride; pa.work_meta = w.work_meta; pa.min_q = NMOD_INST_ALL ? 0 : kCwKsMinQ;
@@ -259,15 +260,10 @@ hipError_t NMOD_CW_RUN_NAME(int num_cus, int64_t work_items, hipStream_t stream,
     if (cacheable) per_cu[dev][slot].store(pc, std::memory_order_relaxed);
   }
   CntWideArgs ca;
-  ca.rs = a; ca.gates = w.gates; ca.segs = w.gates + kClassStride; ca.done = w.done;
+  ca.rs = a; ca.gates = w.gates; ca.segs = w.gates + kClassStride; ca.work_list = w.work_list; ca.work_meta = w.work_meta;
   int64_t blocks = std::min<int64_t>((work_items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)num_cus * pc);
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream, ca);
-  CntCompactArgs cp;
-  cp.npos = a.npos; cp.pos_list = a.pos_list; cp.class_meta = a.class_meta; cp.gates = w.gates; cp.segs = w.gates + kClassStride; cp.done = w.done;
-  cp.work_list = w.work_list; cp.work_meta = w.work_meta;
-  const unsigned cb = (unsigned)std::min<int64_t>((work_items + 255) / 256, 1024);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(cnt_compact_kernel<DT, NMOD_INST_ALL == 0>), dim3(cb ? cb : 1), dim3(256), 0, stream, cp);
   return hipGetLastError();
 }
 

@@ -129,14 +129,14 @@ __host__ __device__ inline int count_wide_rs_index(int cls) {
 // KS-only mode: a class holds every position whose SMALLER group has the class's capacity; the form takes those whose larger group has at
 // least this many samples (200 v 200 and below stay with ks_rank_kernel, four or eight positions per wave)
 constexpr int kCwKsMinQ = 320;
-struct CountWideWs { int32_t* gates; uint8_t* done; int32_t* work_list; int32_t* work_meta; };
+struct CountWideWs { int32_t* gates; int32_t* work_list; int32_t* work_meta; };
 // once per batch: one probe block per class in `classes` (gates[class]), then the work lists as copies of the class lists
 hipError_t launch_count_wide_prepare_d0_a1(const int* classes, int nclasses, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w);
 hipError_t launch_count_wide_prepare_d1_a1(const int* classes, int nclasses, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w);
 hipError_t launch_count_wide_prepare_d0_a0(const int* classes, int nclasses, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w);   // (KS-only)
 hipError_t launch_count_wide_prepare_d1_a0(const int* classes, int nclasses, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w);
-// then, before the classes' sorting launches: rank_count_wide_kernel over every class whose gate is set, and the compaction of what it
-// left into the work lists
+// then, before the classes' sorting launches: rank_count_wide_kernel over every class whose gate is set; it appends what it hands on
+// to the work lists itself
 hipError_t launch_count_wide_run_d0_a1(int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w);
 hipError_t launch_count_wide_run_d1_a1(int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w);
 hipError_t launch_count_wide_run_d0_a0(int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w);

@@ -263,7 +263,7 @@ def oracle_run(a, off0, b, off1, npos, method, tests, threads):
     return out, time.perf_counter() - t0
 
 
-def cpu_baseline(rows, what, method, tests, threads, target_seconds=12.0, refpy=None):
+def cpu_baseline(rows, what, method, tests, threads, target_seconds=6.0, refpy=None):
     """The oracle timed on this box's host cores on a bounded sample of the same workload (the first rows of rank 0's
     device-resident input, copied back): all usable cores, and one core."""
     import numpy as np
@@ -275,7 +275,7 @@ def cpu_baseline(rows, what, method, tests, threads, target_seconds=12.0, refpy=
     sample = int(min(cap, max(probe, rate * target_seconds)))
     reps = max(1, int(round(rate * target_seconds / sample)))
     dt = sum(oracle_run(a, off0, b, off1, sample, method, tests, threads)[1] for _ in range(reps))
-    one = int(min(cap, max(2000, rate / max(threads, 1) * 4.0)))                      # ~4 s on one core
+    one = int(min(cap, max(2000, rate / max(threads, 1) * 2.0)))                      # ~2 s on one core
     dt1 = oracle_run(a, off0, b, off1, one, method, tests, 1)[1]
     # the reference's own shape of the computation — one scipy-style call sequence per position in Python, all three tests as
     # getKStest always computes them — on every usable core: one process per core, >= 20 000 positions each
@@ -524,7 +524,8 @@ def _host_path_leg(nm, torch, dev_index, blocks, n0, n1, nb, wdif, method, tests
         st = L.NmodHostStats(); lib.nmod_last_host_stats(ctypes.byref(st))
         same = bool(np.array_equal(r64['ks_d'][:nq - nb], ref16['ks_d'][:nq - nb].cpu().numpy()) and
                     np.allclose(r64['ks_p'][:nq - nb], ref16['ks_p'][:nq - nb].cpu().numpy(), rtol=1e-12, atol=0))
-        out['float64_grid'] = {'input': 'pageable numpy float64, k / 1000.0 (the first quarter of the positions)', 'positions': nq,
+        out['float64_grid'] = {'input': 'pageable numpy float64, k / 1000.0 (the first quarter of the positions): narrowed to int16 by the threads that fill the bounce slots',
+                               'narrowed_chunks': int(st.narrowed_chunks), 'copy_threads': int(st.copy_threads), 'positions': nq,
                                'positions_per_s': nq / best, 'seconds': best, 'h2d_GBps': st.h2d_bytes / best / 1e9,
                                'frac_of_pinned_h2d': st.h2d_bytes / best / 1e9 / h2d_gbs, 'h2d_bytes': int(st.h2d_bytes), 'chunks': int(st.chunks),
                                'equals_int16_pass': same}
@@ -581,9 +582,9 @@ def rank_plan(args, world, rank):
 
 SIDE_FILE_DEFAULT = os.path.join(ROOT, 'bench_side.json')
 LAST_LINE_CAP = 8000            # the driver keeps an 8 KB tail of stdout: the record must fit it whole (target < 4 KB)
-DEFAULT_SIDE_LEGS = ('all_tests', 'int16', 'real_spread', 'outliers', 'presets')
+DEFAULT_SIDE_LEGS = ('all_tests', 'int16', 'real_spread', 'outliers', 'presets', 'host_path', 'drop_in_200')
 ALL_SIDE_LEGS = ('all_tests', 'int16', 'rational_d', 'real_ties', 'real_spread', 'real_spread_sweep', 'outliers', 'presets', 'presets_event',
-                 'host_path', 'drop_in')
+                 'host_path', 'drop_in', 'drop_in_200')
 
 
 def _sig(x, digits=6):
@@ -775,7 +776,7 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=0, help='cap on positions for the CPU baseline / verification (0 = 1 M)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline (the verification still runs)')
     ap.add_argument('--refpy-positions', type=int, default=20000, help='reference-shaped Python CPU leg: at least this many positions per process')
-    ap.add_argument('--refpy-seconds', type=float, default=6.0, help='reference-shaped Python CPU leg: at least this many seconds per process')
+    ap.add_argument('--refpy-seconds', type=float, default=4.0, help='reference-shaped Python CPU leg: at least this many seconds per process')
     ap.add_argument('--no-side', '--no-real-ties', dest='no_side', action='store_true',
                     help='skip the side measurements of the default run (all tests, int16, rational D, tie-heavy input)')
     ap.add_argument('--side-legs', default='default', help='comma list of side measurements to run, `default` (%s) or `all` (%s)'
@@ -1351,8 +1352,9 @@ def main():
 
     # ---- the function-level drop-in on the reference's dict shape (host glue + PCIe + kernels + table), a tenth of E. coli
     drop_in = None
-    if headline_default and not args.no_host_path and not args.positions and 'drop_in' in legs:
-        drop_in = drop_in_leg(nm, local_rank)
+    if headline_default and not args.no_host_path and not args.positions and ('drop_in' in legs or 'drop_in_200' in legs):
+        # (`drop_in`: 20 v 20 reads, per-position arrays and lists of numpy.float64; `drop_in_200`: only the leg below)
+        drop_in = drop_in_leg(nm, local_rank) if 'drop_in' in legs else {}
         # ... and at the north-star coverage: 460 000 positions x 200 v 200 reads (1.5 GB of float64 rows as per-position arrays),
         # with the stages of mtest2 timed one by one
         drop_in['at_200v200'] = drop_in_leg(nm, local_rank, 460_000, 200, shapes=('arrays',), split=True, event_like=True)

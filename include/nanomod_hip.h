@@ -139,6 +139,12 @@ typedef struct nmod_params {
  * NMOD_FLAG_NO_COUNT_WIDE only those outside the 256-capacity class. */
 #define NMOD_FLAG_NO_COUNTING 4
 #define NMOD_FLAG_NO_COUNT_WIDE 8
+/* NMOD_MEM_HOST with NMOD_DTYPE_F64: the threads that fill the pinned bounce slots write a chunk as int16 milli-units where every
+ * sample of it is k / 1000.0 with |k| <= 32 767 (what NanoMod's stored events are: myRefBaseSignalAnnotation.py:1108) — 2 bytes
+ * per sample over PCIe instead of 8, the chunk then runs as NMOD_DTYPE_I16_MILLI; any other chunk is sent as float64.  The rank
+ * statistics are the same bit for bit, the Welch moments come from exact integer sums instead of the two-pass float64 sums
+ * (both within 1e-11 of the reference's t).  This flag sends every chunk as float64 (A/B, parity tests). */
+#define NMOD_FLAG_NO_HOST_NARROW 16
 
 /* Caller-allocated SoA outputs, npos elements each; a NULL member is skipped.
  * One (stat, p) pair per test = the tuples getKStest returns
@@ -204,6 +210,7 @@ typedef struct nmod_host_stats {
   int64_t pinned_bytes;      /* pinned host ring */
   int64_t h2d_bytes;         /* bytes copied host -> device */
   int64_t d2h_bytes;         /* bytes copied device -> host */
+  int64_t narrowed_chunks;   /* NMOD_DTYPE_F64: chunks sent as int16 milli-units (see NMOD_FLAG_NO_HOST_NARROW) */
 } nmod_host_stats;
 int nmod_last_host_stats(nmod_host_stats* st);
 
@@ -321,6 +328,11 @@ int nmod_write_sign_test(const char* path, int64_t npos, const int32_t* chrom_id
                          const int32_t* n0, const int32_t* n1, const double* mwu_u, const double* mwu_p,
                          const double* t_t, const double* t_p, const double* ks_d, const double* ks_p,
                          const double* comb_st, const double* comb_p, int32_t with_comb);
+
+/* Test hook for the float64 -> int16 narrowing of the host-resident entry: out[i] = k where v[i] == k / 1000.0 with |k| <= 32 767;
+ * returns 1 when every one of the n values narrowed, 0 when one refused (out is then unspecified), negative on bad arguments.
+ * Host-only. */
+int nmod_narrow_probe(const double* v, int64_t n, int16_t* out);
 
 /* Test hook for the table writer's number formats: v[i] formatted as '%.3f' (sci = 0) or '%.3E' (sci = 1) the way
  * nmod_write_sign_test does, NUL-separated, into out (capacity cap bytes; at most 420 bytes per value). */

@@ -17,7 +17,7 @@ DTYPE_F32, DTYPE_I16_MILLI, DTYPE_F64 = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 METHOD_KS, METHOD_STOUFFER, METHOD_FISHER = 0, 1, 2
 TEST_KS, TEST_MWU, TEST_WELCH, TEST_ALL = 1, 2, 4, 7
-FLAG_KS_RATIONAL_D, FLAG_CHECK_FINITE, FLAG_NO_COUNTING, FLAG_NO_COUNT_WIDE = 1, 2, 4, 8
+FLAG_KS_RATIONAL_D, FLAG_CHECK_FINITE, FLAG_NO_COUNTING, FLAG_NO_COUNT_WIDE, FLAG_NO_HOST_NARROW = 1, 2, 4, 8, 16
 STATUS_MWU_ALL_IDENTICAL, STATUS_T_NAN, STATUS_EMPTY, STATUS_TOO_LARGE, STATUS_NONFINITE = 1, 2, 4, 8, 16
 KERNEL_RANK_STATS, KERNEL_FINALIZE, KERNEL_COMBINE, KERNEL_SYNTH = 0, 1, 2, 3
 MAX_GROUP = 2048          # largest group of the wave-resident kernels; larger ones (<= MAX_RANKED) take big_rank_kernel
@@ -44,7 +44,7 @@ class NmodOut(C.Structure):
 
 class NmodHostStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ('chunks', 'slots', 'copy_threads', 'pinned_input', 'chunk_positions',
-                                         'device_bytes', 'pinned_bytes', 'h2d_bytes', 'd2h_bytes')]
+                                         'device_bytes', 'pinned_bytes', 'h2d_bytes', 'd2h_bytes', 'narrowed_chunks')]
 
 
 class NmodDispatchStats(C.Structure):
@@ -86,6 +86,7 @@ _SIGNATURES = {
     'nmod_evtimer_read': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     'nmod_evtimer_destroy': (C.c_int, [C.c_void_p]),
     'nmod_selftest': (C.c_int, [C.c_int32]),
+    'nmod_narrow_probe': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     'nmod_format_probe': (C.c_int, [C.POINTER(C.c_double), C.c_int64, C.c_int32, C.c_char_p, C.c_int64]),
     'nmod_trim_scratch': (C.c_int, [C.c_int32]),
     'nmod_host_pipeline_config': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),

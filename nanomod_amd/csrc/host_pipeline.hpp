@@ -45,6 +45,66 @@ static int usable_cpus() {
   return n;
 }
 
+// ---------------------------------------------------------------- float64 on the milli-unit grid -> int16, on the way into the bounce slot
+// The reference holds its samples as lists of numpy.float64 (myDetect.py:124) and every stored event value is a 3-decimal number
+// (myRefBaseSignalAnnotation.py:1108): x = k / 1000.0 with a small integer k.  The threads that fill a bounce slot touch every
+// sample anyway; where ALL samples of a chunk are such values with |k| <= 32 767 they write k as int16 instead of copying the
+// double — 2 bytes per sample over PCIe instead of 8, and the chunk runs as NMOD_DTYPE_I16_MILLI (the keys the float64 front end
+// would have picked on the device: the same rank statistics bit for bit; the Welch moments as exact integer sums).  A chunk with
+// any other sample (off the grid, |k| > 32 767, NaN, infinite) is sent as float64 as before.
+// x == k / 1000.0 is tested without a division: q = fl(k / 1000) by one Newton step on k * fl(1 / 1000) — correctly rounded for
+// every |k| <= 32 767 (checked exhaustively on the host: tests/test_abi_and_host.py through nmod_narrow_probe).
+static inline bool narrow_one(double x, int16_t& out) {
+  const double k = nearbyint(x * 1000.0);
+  const double q0 = k * 0.001;
+  const double q = fma(fma(-q0, 1000.0, k), 0.001, q0);
+  out = (int16_t)(int)k;
+  return q == x && fabs(k) <= 32767.0;                   // (NaN: false)
+}
+static bool narrow_scalar(const double* src, int16_t* dst, size_t n) {
+  bool ok = true;
+  for (size_t i = 0; i < n && ok; ++i) {
+    int16_t v = 0;
+    if (fabs(src[i]) <= 33.0) ok = narrow_one(src[i], v); else ok = false;     // (the cast of an out-of-range k is undefined: refuse first)
+    dst[i] = v;
+  }
+  return ok;
+}
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+__attribute__((target("avx2,fma"))) static bool narrow_avx2(const double* src, int16_t* dst, size_t n) {
+  const __m256d k1000 = _mm256_set1_pd(1000.0), r = _mm256_set1_pd(0.001), lim = _mm256_set1_pd(32767.0);
+  const __m256d absmask = _mm256_castsi256_pd(_mm256_set1_epi64x(0x7fffffffffffffffll));
+  size_t i = 0;
+  while (i + 8 <= n) {
+    const size_t stop = std::min(n, i + 8192) & ~(size_t)7;              // a verdict per 8 192 samples: an off-grid batch gives up early
+    __m256d good = _mm256_castsi256_pd(_mm256_set1_epi64x(-1));
+    for (; i + 8 <= stop; i += 8) {
+      __m128i kk[2];
+      for (int h = 0; h < 2; ++h) {
+        const __m256d x = _mm256_loadu_pd(src + i + 4 * h);
+        const __m256d k = _mm256_round_pd(_mm256_mul_pd(x, k1000), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+        const __m256d q0 = _mm256_mul_pd(k, r);
+        const __m256d q = _mm256_fmadd_pd(_mm256_fnmadd_pd(q0, k1000, k), r, q0);
+        const __m256d ok = _mm256_and_pd(_mm256_cmp_pd(q, x, _CMP_EQ_OQ), _mm256_cmp_pd(_mm256_and_pd(k, absmask), lim, _CMP_LE_OQ));
+        good = _mm256_and_pd(good, ok);
+        kk[h] = _mm256_cvtpd_epi32(k);                                    // (garbage for a refused sample: the chunk is then not used)
+      }
+      _mm_storeu_si128((__m128i*)(dst + i), _mm_packs_epi32(kk[0], kk[1]));
+    }
+    if (_mm256_movemask_pd(good) != 0xf) return false;
+  }
+  return narrow_scalar(src + i, dst + i, n - i);
+}
+#endif
+static bool narrow_f64_to_i16(const double* src, int16_t* dst, size_t n) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  static const bool have_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+  if (have_avx2) return narrow_avx2(src, dst, n);
+#endif
+  return narrow_scalar(src, dst, n);
+}
+
 // ---------------------------------------------------------------- copy team
 // T - 1 helper threads + the caller copy one range each; created per call (a call that needs it moves >= tens of MB).
 class CopyTeam {
@@ -60,20 +120,34 @@ class CopyTeam {
   void copy(void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return;
     if (n_ == 1 || bytes < (size_t)(256 << 10)) { memcpy(dst, src, bytes); return; }
+    run(dst, src, bytes, false);
+  }
+  // `n` doubles -> int16 milli-units (narrow_f64_to_i16), a range per thread; false when a sample refuses (dst is then unspecified)
+  bool narrow(int16_t* dst, const double* src, size_t n) {
+    if (n == 0) return true;
+    if (n_ == 1 || n < (size_t)(32 << 10)) return narrow_f64_to_i16(src, dst, n);
+    ok_.store(true);
+    run(dst, src, n * 8, true);
+    return ok_.load();
+  }
+ private:
+  void run(void* dst, const void* src, size_t bytes, bool narrowing) {
     {
       std::lock_guard<std::mutex> l(m_);
-      dst_ = (char*)dst; src_ = (const char*)src; bytes_ = bytes; pending_ = n_ - 1; ++gen_;
+      dst_ = (char*)dst; src_ = (const char*)src; bytes_ = bytes; narrow_ = narrowing; pending_ = n_ - 1; ++gen_;
     }
     cv_.notify_all();
     slice(0);
     std::unique_lock<std::mutex> l(m_);
     done_.wait(l, [this] { return pending_ == 0; });
   }
- private:
   void slice(int t) {
-    const size_t per = ((bytes_ + n_ - 1) / n_ + 4095) & ~(size_t)4095;
+    const size_t per = ((bytes_ + n_ - 1) / n_ + 4095) & ~(size_t)4095;       // (bytes of the SOURCE: a multiple of 8 for doubles)
     const size_t lo = (size_t)t * per, hi = std::min(bytes_, lo + per);
-    if (lo < hi) memcpy(dst_ + lo, src_ + lo, hi - lo);
+    if (lo >= hi) return;
+    if (!narrow_) memcpy(dst_ + lo, src_ + lo, hi - lo);
+    else if (ok_.load(std::memory_order_relaxed) &&
+             !narrow_f64_to_i16((const double*)(src_ + lo), (int16_t*)dst_ + lo / 8, (hi - lo) / 8)) ok_.store(false);
   }
   void worker(int t) {
     uint64_t seen = 0;
@@ -92,7 +166,8 @@ class CopyTeam {
   std::vector<std::thread> th_;
   std::mutex m_;
   std::condition_variable cv_, done_;
-  char* dst_ = nullptr; const char* src_ = nullptr; size_t bytes_ = 0;
+  char* dst_ = nullptr; const char* src_ = nullptr; size_t bytes_ = 0; bool narrow_ = false;
+  std::atomic<bool> ok_{true};
   int pending_ = 0; uint64_t gen_ = 0; bool stop_ = false;
 };
 
@@ -264,7 +339,11 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
   const int64_t o_sig0 = o_off1 + (csr1 ? align256((cap_pos + 1) * 8) : 0);
   const int64_t o_sig1 = o_sig0 + align256(cap_b0 + 256);          // (+256: the kernels' 16-byte row loads may run past a row's end)
   const int64_t in_slot = o_sig1 + align256(cap_b1 + 256);
-  const bool pinned_in = g_hp_mode.load() != 2 && hp_is_pinned((const char*)sig0 + row0(0) * esz, (size_t)((row0(npos) - row0(0)) * (int64_t)esz)) &&
+  // float64 input: the bounce fill narrows a chunk to int16 milli-units where every sample allows it (above); such a batch always
+  // goes through the bounce slots
+  const bool try_narrow = prm->dtype == NMOD_DTYPE_F64 && (prm->flags & NMOD_FLAG_NO_HOST_NARROW) == 0;
+  std::vector<char> narrowed(nchunks, 0);
+  const bool pinned_in = !try_narrow && g_hp_mode.load() != 2 && hp_is_pinned((const char*)sig0 + row0(0) * esz, (size_t)((row0(npos) - row0(0)) * (int64_t)esz)) &&
                          hp_is_pinned((const char*)sig1 + row1(0) * esz, (size_t)((row1(npos) - row1(0)) * (int64_t)esz));
   const int64_t in_bounce = pinned_in ? o_sig0 : in_slot;          // a pinned caller's rows are copied from where they are
   const int64_t out_slab = align256(cap_pos * (8 * (int64_t)ntr + 1));
@@ -298,7 +377,7 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
   if (want_comb && prm->nb > 0) NMOD_HIP(hipMemcpyAsync(f_run, run_id, (size_t)npos * 4, hipMemcpyHostToDevice, res.s_in));
 
   int threads = g_hp_threads.load();
-  if (threads <= 0) threads = (int)env_i64("NMOD_HOST_THREADS", 4);
+  if (threads <= 0) threads = (int)env_i64("NMOD_HOST_THREADS", try_narrow ? 8 : 4);     // (narrowing reads 8 bytes per sample it sends: more readers)
   threads = std::max(1, std::min(threads, usable_cpus()));
   if (pinned_in || total_bytes < (8 << 20)) threads = 1;
   CopyTeam team(threads);
@@ -325,7 +404,7 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
     }
     char* pb = in_pin(s);
     const int64_t e0 = row0(lo), e1 = row1(lo);
-    const int64_t b0 = (row0(hi) - e0) * (int64_t)esz, b1 = (row1(hi) - e1) * (int64_t)esz;
+    int64_t b0 = (row0(hi) - e0) * (int64_t)esz, b1 = (row1(hi) - e1) * (int64_t)esz;
     if (csr0) { int64_t* d = (int64_t*)(pb + o_off0); for (int64_t i = 0; i <= n; ++i) d[i] = off0[lo + i] - e0; }
     if (csr1) { int64_t* d = (int64_t*)(pb + o_off1); for (int64_t i = 0; i <= n; ++i) d[i] = off1[lo + i] - e1; }
     if (pinned_in) {
@@ -333,8 +412,14 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
       NMOD_HIP(hipMemcpyAsync(in_dev(s) + o_sig0, (const char*)sig0 + e0 * esz, (size_t)b0, hipMemcpyHostToDevice, res.s_in));
       NMOD_HIP(hipMemcpyAsync(in_dev(s) + o_sig1, (const char*)sig1 + e1 * esz, (size_t)b1, hipMemcpyHostToDevice, res.s_in));
     } else {
-      team.copy(pb + o_sig0, (const char*)sig0 + e0 * esz, (size_t)b0);
-      team.copy(pb + o_sig1, (const char*)sig1 + e1 * esz, (size_t)b1);
+      if (try_narrow && team.narrow((int16_t*)(pb + o_sig0), (const double*)sig0 + e0, (size_t)(b0 / 8)) &&
+          team.narrow((int16_t*)(pb + o_sig1), (const double*)sig1 + e1, (size_t)(b1 / 8))) {
+        narrowed[c] = 1; b0 /= 4; b1 /= 4;
+        ++g_host_stats.narrowed_chunks;
+      } else {
+        team.copy(pb + o_sig0, (const char*)sig0 + e0 * esz, (size_t)b0);
+        team.copy(pb + o_sig1, (const char*)sig1 + e1 * esz, (size_t)b1);
+      }
       // one copy when the slot is nearly full, else the parts (a short last chunk does not move the whole slot)
       if (o_sig1 - o_sig0 - b0 <= 4096) {
         NMOD_HIP(hipMemcpyAsync(in_dev(s), pb, (size_t)(o_sig1 + b1), hipMemcpyHostToDevice, res.s_in));
@@ -372,7 +457,12 @@ static int detect_host_pipelined(const nmod_params* prm, int64_t npos, const voi
     dout.status = (uint8_t*)(slab + (int64_t)ntr * n * 8);
     const char* di = in_dev(s);
     int r;
-    if (prm->dtype == NMOD_DTYPE_F64) {
+    if (narrowed[c]) {                              // the chunk arrived as int16 milli-units
+      nmod_params dp16 = dp;
+      dp16.dtype = NMOD_DTYPE_I16_MILLI;
+      r = detect_device(&dp16, n, di + o_sig0, csr0 ? (const int64_t*)(di + o_off0) : nullptr, di + o_sig1,
+                        csr1 ? (const int64_t*)(di + o_off1) : nullptr, nullptr, ws_dev(s), wsb, &dout);
+    } else if (prm->dtype == NMOD_DTYPE_F64) {
       const int64_t t0 = row0(cut[c + 1]) - row0(lo), t1 = row1(cut[c + 1]) - row1(lo);
       const int64_t bounds[4] = {0, t0, 0, t1};
       r = detect_f64(&dp, n, di + o_sig0, csr0 ? (const int64_t*)(di + o_off0) : nullptr, di + o_sig1,

@@ -390,7 +390,7 @@ static int check_params(const nmod_params* prm) {
   if (prm->method < NMOD_METHOD_KS || prm->method > NMOD_METHOD_FISHER) return NMOD_ERR_INVALID_ARG;
   if (prm->nb < 0 || prm->nb > NMOD_MAX_NB) return NMOD_ERR_INVALID_ARG;
   if ((prm->tests & ~NMOD_TEST_ALL) != 0) return NMOD_ERR_INVALID_ARG;
-  if ((prm->flags & ~(NMOD_FLAG_KS_RATIONAL_D | NMOD_FLAG_CHECK_FINITE | NMOD_FLAG_NO_COUNTING | NMOD_FLAG_NO_COUNT_WIDE)) != 0 || prm->reserved != 0) return NMOD_ERR_INVALID_ARG;
+  if ((prm->flags & ~(NMOD_FLAG_KS_RATIONAL_D | NMOD_FLAG_CHECK_FINITE | NMOD_FLAG_NO_COUNTING | NMOD_FLAG_NO_COUNT_WIDE | NMOD_FLAG_NO_HOST_NARROW)) != 0 || prm->reserved != 0) return NMOD_ERR_INVALID_ARG;
   return NMOD_OK;
 }
 
@@ -1144,6 +1144,11 @@ int nmod_host_pipeline_config(int64_t chunk_bytes, int32_t slots, int32_t thread
   if (chunk_bytes < 0 || slots < 0 || slots > kHpMaxSlots || threads < 0 || threads > 256 || mode < 0 || mode > 2) return NMOD_ERR_INVALID_ARG;
   g_hp_chunk_bytes.store(chunk_bytes); g_hp_slots.store(slots); g_hp_threads.store(threads); g_hp_mode.store(mode);
   return NMOD_OK;
+}
+
+int nmod_narrow_probe(const double* v, int64_t n, int16_t* out) {
+  if (!v || !out || n < 0) return NMOD_ERR_INVALID_ARG;
+  return narrow_f64_to_i16(v, out, (size_t)n) ? 1 : 0;
 }
 
 int nmod_last_host_stats(nmod_host_stats* st) {

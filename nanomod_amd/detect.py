@@ -330,11 +330,28 @@ class SignTestRecords(collections.abc.Sequence):
         place the reference's way (`sign_test[i][1].append(...)`, myDetect.py:377: the records are kept once built, so such an
         edit persists in the sequence).  save_test then writes the table from the records, not from the arrays."""
         root = self._parent if self._parent is not None else self
-        return any(rec != root._build(i) for i, rec in root._cache.items())
+        return any(not _same_record(rec, root._build(i)) for i, rec in root._cache.items())
 
     def permuted(self, order):
         """the same records in another order (the ranking)"""
         return SignTestRecords(self._meta, self._res, self._with_comb, order=np.asarray(order), parent=self if self._parent is None else self._parent)
+
+
+def _same_record(a, b):
+    """record equality in which a NaN equals a NaN: a position with a NaN statistic (zero variance, a flagged position) rebuilt from the
+    arrays holds a different float object each time, and `!=` on the tuples would call an untouched record edited"""
+    if a[0] != b[0] or len(a[1]) != len(b[1]):
+        return False
+    for x, y in zip(a[1], b[1]):
+        try:
+            if len(x) != len(y):
+                return False
+            for u, v in zip(x, y):
+                if not (u == v or (u != u and v != v)):
+                    return False
+        except TypeError:                                     # (an edit that put something else than a (stat, p) pair there)
+            return False
+    return True
 
 
 def _join_strand_py(d0, d1, b0, b1, sk, quiet):
@@ -524,6 +541,11 @@ def mtest2(moptions):
     # moptions['nmod_strict'] makes them an error instead; either way they are listed in moptions['nmod_flagged'].
     flagged = np.flatnonzero(res['status'] & (L.STATUS_TOO_LARGE | L.STATUS_NONFINITE)) if npos else np.zeros(0, np.int64)
     moptions['nmod_flagged'] = [(str(meta['chrom'][i]), str(meta['strand'][i]), int(meta['pos'][i]), int(res['status'][i])) for i in flagged]
+    if len(flagged) and moptions.get('outLevel', OUTPUT_ERROR) <= OUTPUT_ERROR and not moptions.get('nmod_quiet', 0):
+        # (the rows of these positions hold NaN statistics where the reference would have computed numbers: say so once)
+        print('nanomod_amd: %d position(s) could not be tested (a group beyond %d samples, or non-finite samples) and carry NaN statistics; '
+              'first: %r; all of them: moptions[\'nmod_flagged\'] (nmod_strict=1 makes this an error)'
+              % (len(flagged), L.MAX_RANKED, moptions['nmod_flagged'][0]), file=sys.stderr)
     if len(flagged) and moptions.get('nmod_strict', 0):
         raise ValueError('%d position(s) could not be tested (group beyond %d samples, or non-finite samples); first: %r'
                          % (len(flagged), L.MAX_RANKED, moptions['nmod_flagged'][0]))

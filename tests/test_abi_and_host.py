@@ -105,6 +105,32 @@ def test_dispatch_stats_without_a_call_and_form_flags():
     assert 'getenv("NMOD_NO_COUNT' not in src
 
 
+def test_host_narrowing_accepts_exactly_the_int16_grid():
+    """nmod_narrow_probe (the float64 -> int16 narrowing of the host-resident entry, host_pipeline.hpp): every k / 1000.0 with
+    |k| <= 32 767 narrows to k — the division-free quotient test is exact for all 65 535 of them, through the vector loop and its
+    scalar tail — and nothing else does: a neighbouring double, |k| = 32 768, NaN, infinities, huge values, half a milli-unit"""
+    import nanomod_amd._lib as L
+    lib = L.load()
+    k = np.arange(-32767, 32768, dtype=np.int64)
+    v = k.astype(np.float64) / 1000.0
+    for n in (len(v), len(v) - 3, 13, 8, 7, 1, 0):            # (whole vectors, a ragged tail, only the tail, nothing)
+        out = np.full(len(v), 77, np.int16)
+        assert lib.nmod_narrow_probe(v.ctypes.data, n, out.ctypes.data) == 1
+        assert np.array_equal(out[:n], k[:n]) and np.all(out[n:] == 77)
+    rng = np.random.default_rng(3)
+    big = rng.integers(-32767, 32768, 300_001)
+    w = big / 1000.0
+    out = np.empty(len(w), np.int16)
+    assert lib.nmod_narrow_probe(w.ctypes.data, len(w), out.ctypes.data) == 1 and np.array_equal(out, big)
+    for bad in (np.nextafter(7.233, 9.0), np.nextafter(-0.001, -9.0), 32.768, -32.768, np.nan, np.inf, -np.inf, 1e300, -4e9, 0.0005, 1e-320):
+        for at in (0, 5, len(w) - 1, 123_456):
+            x = w.copy(); x[at] = bad
+            assert lib.nmod_narrow_probe(x.ctypes.data, len(x), out.ctypes.data) == 0, (bad, at)
+    assert lib.nmod_narrow_probe(None, 4, out.ctypes.data) == -1 and lib.nmod_narrow_probe(w.ctypes.data, -1, out.ctypes.data) == -1
+    z = np.array([0.0, -0.0, 0.001, -0.001])                   # a signed zero is the value zero
+    assert lib.nmod_narrow_probe(z.ctypes.data, 4, out.ctypes.data) == 1 and list(out[:4]) == [0, 0, 1, -1]
+
+
 def test_makefile_rebuilds_every_unit_when_a_header_changes():
     """every translation unit depends on $(HDRS): touching radix_sort.hpp (included by rank_order.hip only) must put
     rank_order.o into `make -n`'s plan (round 5 left it stale)"""
@@ -367,6 +393,15 @@ def test_sign_test_records_behave_like_the_reference_list():
     assert type(back) is list and back == [as_list[i] for i in order]
     with pytest.raises(TypeError):
         hash(st)
+    # records holding NaN statistics (zero variance, a flagged position) are not "edited" just because NaN != NaN; a real edit is
+    assert not st.edited()
+    res2 = {k: v.copy() for k, v in res.items()}
+    res2['t_t'][4] = np.nan; res2['t_p'][4] = np.nan; res2['mwu_u'][9] = np.nan
+    st2 = D.SignTestRecords(meta, res2, True)
+    _ = [st2[i] for i in (3, 4, 9)]
+    assert not st2.edited()
+    st2[4][1].append((1.0, 0.5))                              # the reference's own way of adding a pair (myDetect.py:377)
+    assert st2.edited()
 
 
 def test_float_form_quotient_is_correctly_rounded_for_every_count():

@@ -108,4 +108,4 @@ def test_drop_in_leg_on_the_reference_dict_shape():
     big = di['at_200v200']
     assert big['reads_per_group'] == 200 and big['arrays']['verify_ok'] and big['arrays']['table_lines'] == 460000
     st = big['arrays']['stages']
-    assert st['h2d_bytes'] >= 460000 * 400 * 8 and all(st[k] > 0 for k in ('build_csr_s', 'detect_host_s', 'rank_order_s', 'write_table_s'))
+    assert st['h2d_bytes'] >= 460000 * 400 * 2 and all(st[k] > 0 for k in ('build_csr_s', 'detect_host_s', 'rank_order_s', 'write_table_s'))      # (float64 rows on the 0.001 grid: narrowed to int16 on the way)

@@ -80,19 +80,31 @@ def test_chunked_equals_device_resident_csr(dtype, tests_mask, method):
     rid = _runs(rng, npos)
     ref = _device_reference(sig0, off0, sig1, off1, rid, nb=2, method=method, tests=tests_mask)
     names = [k for k in ref if k != 'status'] + ['status']
+    flags = L.FLAG_NO_HOST_NARROW if dtype == np.float64 else 0
     row_bytes = (off0[-1] + off1[-1]) * sig0.itemsize / npos
     # chunk cuts: ~7 positions per chunk (cuts inside runs and on run edges), ~300 per chunk, and one position per chunk
     for chunk_bytes, slots in ((int(7 * row_bytes), 2), (int(300 * row_bytes), 3), (1, 4)):
         assert lib.nmod_host_pipeline_config(chunk_bytes, slots, 2, 0) == 0
-        got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method=method, tests=tests_mask)
+        # (float64 rows on the 0.01 grid: sent as float64 here, like the device-resident reference; narrowed to int16 below)
+        got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method=method, tests=tests_mask, flags=flags)
         st = _stats()
-        assert st.chunks >= npos // 400 and st.slots == slots and st.pinned_input == 0
+        assert st.chunks >= npos // 400 and st.slots == slots and st.pinned_input == 0 and st.narrowed_chunks == 0
         if chunk_bytes == 1:
             assert st.chunks == npos and st.chunk_positions == 1
         _same(got, ref, [k for k in names if k in got])
+        if dtype == np.float64:
+            # the bounce fill narrows every chunk to int16 milli-units: a quarter of the bytes over the bus, the rank statistics and
+            # their p-values bit for bit, the Welch pair from exact integer sums (within the gates every path is held to)
+            nar = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method=method, tests=tests_mask)
+            st2 = _stats()
+            assert st2.narrowed_chunks == st2.chunks == st.chunks and st2.h2d_bytes < 0.3 * st.h2d_bytes + 16 * (npos + st.chunks) + 4 * npos
+            _same(nar, ref, [k for k in names if k in nar and k not in ('t_t', 't_p')])
+            if 't_t' in nar:
+                H.assert_close_stat(nar['t_t'], ref['t_t'], 1e-11, H.t_abs_gate(sig0, off0, sig1, off1), 't_t')
+                H.assert_close_p(nar['t_p'], ref['t_p'], 1e-9, 't_p')
     # the default configuration: a small batch is cut into ~32 chunks of >= 1 MiB (here: one or two chunks)
     assert lib.nmod_host_pipeline_config(0, 0, 0, 0) == 0
-    got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method=method, tests=tests_mask)
+    got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method=method, tests=tests_mask, flags=flags)
     _same(got, ref, [k for k in names if k in got])
 
 
@@ -116,6 +128,54 @@ def test_chunked_equals_device_resident_stride_and_oracle(dtype):
     off0 = np.arange(0, (npos + 1) * n0, n0, dtype=np.int64); off1 = np.arange(0, (npos + 1) * n1, n1, dtype=np.int64)
     exp = oracle_c.detect_batch(a, off0, b, off1, rid, 2, 2.0, 'stouffer', tests=7)
     H.compare_outputs(got, exp)
+
+
+def test_float64_chunks_narrow_only_where_every_sample_allows():
+    """float64 rows as the reference holds them (myDetect.py:124), a batch of four kinds of positions — 3-decimal events, continuous
+    doubles, 3-decimal values beyond the int16 range (|k| up to 40 000), 3-decimal events with a NaN — cut into chunks that are
+    pure or mixed: a chunk is narrowed to int16 on the host only when EVERY sample of it is k / 1000.0 with |k| <= 32 767, and the
+    results are those of the all-float64 path (NMOD_FLAG_NO_HOST_NARROW): rank statistics, p-values and status bits bit for bit,
+    the Welch pair within its gate; all against the oracle"""
+    import nanomod_amd as nm
+    import nanomod_oracle as orc
+    L, lib = _lib()
+    rng = np.random.default_rng(23)
+    per, n = 400, 60                                              # positions per kind, samples per group
+    kinds = []
+    kinds.append(np.round(rng.normal(0, 1, (per, 2, n)) * 0.3 + rng.uniform(-3, 3, (per, 1, 1)), 3))                  # events
+    kinds.append(rng.normal(0, 1, (per, 2, n)))                                                                       # continuous
+    kinds.append(np.round(rng.normal(0, 1, (per, 2, n)) * 12.0, 3))                                                   # |k| up to ~40 000
+    ev = np.round(rng.normal(0, 1, (per, 2, n)) * 0.3, 3); ev[per // 2, 1, 7] = np.nan; kinds.append(ev)              # a NaN in one position
+    x = np.concatenate(kinds)                                     # [4 per, 2, n]
+    npos = x.shape[0]
+    a = np.ascontiguousarray(x[:, 0, :]).reshape(-1); b = np.ascontiguousarray(x[:, 1, :]).reshape(-1)
+    rid = np.zeros(npos, np.int32)
+    # 100 positions per chunk: 4 pure chunks per kind (the NaN spoils one of the last kind's)
+    assert lib.nmod_host_pipeline_config(100 * 2 * n * 8, 3, 2, 0) == 0
+    got = nm.detect_host(a, None, b, None, rid, nb=2, weights_dif=2.0, method='stouffer', stride0=n, stride1=n, flags=L.FLAG_CHECK_FINITE)
+    st = _stats()
+    assert st.chunks == 16 and st.narrowed_chunks == 4 + 3, (st.chunks, st.narrowed_chunks)
+    ref = nm.detect_host(a, None, b, None, rid, nb=2, weights_dif=2.0, method='stouffer', stride0=n, stride1=n, flags=L.FLAG_CHECK_FINITE | L.FLAG_NO_HOST_NARROW)
+    st0 = _stats()
+    assert st0.narrowed_chunks == 0 and st.h2d_bytes == st0.h2d_bytes - 7 * 100 * 2 * n * 6
+    nanpos = 3 * per + per // 2
+    assert (got['status'][nanpos] & L.STATUS_NONFINITE) and np.array_equal(got['status'], ref['status'])
+    keep = np.ones(npos, bool); keep[nanpos - 2:nanpos + 3] = False                 # (the NaN position's own numbers are unspecified, its window's combined pair with them)
+    for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p', 'comb_st', 'comb_p'):
+        assert np.array_equal(got[k][keep], ref[k][keep]), k
+    H.assert_close_p(got['t_p'][keep], ref['t_p'][keep], 1e-9, 't_p')
+    # mixed chunks (150 positions per chunk: every second chunk holds two kinds) narrow only where both kinds allow
+    assert lib.nmod_host_pipeline_config(150 * 2 * n * 8, 3, 2, 0) == 0
+    mix = nm.detect_host(a, None, b, None, rid, nb=2, weights_dif=2.0, method='stouffer', stride0=n, stride1=n, flags=L.FLAG_CHECK_FINITE)
+    assert 1 <= _stats().narrowed_chunks <= 4
+    for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p', 'comb_st', 'comb_p'):
+        assert np.array_equal(mix[k][keep], ref[k][keep]), k
+    off = np.arange(0, (npos + 1) * n, n, dtype=np.int64)
+    fin = np.arange(npos) < 3 * per
+    exp = orc.detect_batch(a[:3 * per * n], off[:3 * per + 1], b[:3 * per * n], off[:3 * per + 1], rid[:3 * per], 2, 2.0, orc.METHOD_STOUFFER)
+    inner = slice(0, 3 * per - 2)
+    H.compare_outputs({k: v[fin][inner] for k, v in got.items()}, {k: v[inner] for k, v in exp.items()}, True,
+                      t_abs=H.t_abs_gate(a[:3 * per * n], off[:3 * per + 1], b[:3 * per * n], off[:3 * per + 1])[inner])
 
 
 def test_pinned_input_is_copied_from_where_it_is():

@@ -369,10 +369,9 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, int32_t* w
     constexpr bool KEEPA = RS <= 8;                        // the samples' table addresses stay in registers (RS = 16: recomputed from the keys)
     unsigned addr[KEEPA ? RS : 1];
     unsigned inmask = 0u;                                  // bit r: sample r of S exists and lies inside the window
-    int nt = 0, nt_q_pol = 0;                              // tail samples of the position (wave-uniform), those of Q; lane i < nt holds sample i:
+    int nt = 0, nt_q_pol = 0, nt_s_ = 0;                   // tail samples of the position (wave-uniform), those of Q, those of S; lane i < nt holds sample i:
     bool t_val = false; int t_key = 0; unsigned t_grp = 0u, t_le = 0u, t_lt = 0u, t_p = 0u;
-    int nt_s_ = 0;                                         // ... those of S
-    int ts_d = 0, tq_d = 0; unsigned tq_dw2 = 0u; unsigned long long ts_dd = 0ull, tq_dd = 0ull;   // the tail's moment terms (wave-uniform, int16 rows)
+    int ts_d = 0, tq_d = 0; unsigned tq_dw2 = 0u; unsigned long long ts_dd = 0ull, tq_dd = 0ull;   // the tail's moment terms (wave-uniform scalars, int16 rows)
     const unsigned tail_b = tb + (unsigned)kCwTableWords * 4u;
     int listed = 0;                                        // samples in the tail list so far (wave-uniform: a scalar register, not a counter in LDS)
     // the lanes whose sample lies outside the window append key | group << 16 to the tail list: called by the whole wave; the
@@ -672,7 +671,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, int32_t* w
     if (fit) {                                             // (wave-uniform)
       dmax = wave_max_f64(dmax);
       if constexpr (KS) {
-        const bool any_tie = DTYPE == 2 && __ballot(sp != 0u || (t_val && t_p != 0u)) != 0ull;
+        const bool any_tie = DTYPE == 2 && __ballot(sp != 0u || (nt > 0 && t_val && t_p != 0u)) != 0ull;
         if (lane == 0) {
           args.ks_num[pos] = best;
           args.ks_d_ref[pos] = dmax;
@@ -685,7 +684,7 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, int32_t* w
         // sum_v t^3 - n = 3 sum (p^2 + p) over the arrivals: the table's, + the tail samples' earlier copies among the tail, - what
         // the dump entry handed the tail samples of an int16 Q as arrival numbers (0, 1, ..., nt_q - 1: sum of p^2 + p = (n-1) n (n+1) / 3)
         if (nt > 0) { const unsigned tp = t_val ? t_p : 0u; sp += tp; sp2 += tp * tp; }
-        unsigned long long arrivals = wave_sum_u64((unsigned long long)sp2 + (unsigned long long)sp);
+        unsigned long long arrivals = wave_sum_u64((unsigned long long)(sp2 + sp));
         if constexpr (RDT == 1) arrivals -= (unsigned long long)(nt_q_pol > 0 ? nt_q_pol - 1 : 0) * (unsigned long long)nt_q_pol * (unsigned long long)(nt_q_pol + 1) / 3ull;
         const unsigned long long TIE = 3ull * arrivals;
         double mean_s = 0.0, m2_s = 0.0, mean_q = 0.0, m2_q = 0.0;

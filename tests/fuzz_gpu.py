@@ -85,13 +85,15 @@ def run_round(rng):
         exp = orc.detect_batch(r0, off0, r1, off1, rid, nb, 2.0, orc.METHOD_STOUFFER if method == 'stouffer' else orc.METHOD_FISHER)
     else:
         exp = oracle_c.detect_batch(s0, off0, s1, off1, rid, nb, 2.0, method, threads=0)
-    got = nm.detect_host(s0, off0, s1, off1, rid, nb=nb, weights_dif=2.0, method=method)
+    # float64 rows: through the device's float64 front end, or (where every sample of a chunk is k / 1000.0) narrowed to int16 on the host
+    hf = L.FLAG_NO_HOST_NARROW if (s0.dtype == np.float64 and rng.random() < 0.5) else 0
+    got = nm.detect_host(s0, off0, s1, off1, rid, nb=nb, weights_dif=2.0, method=method, flags=hf)
     ident = (exp['status'] & 1) != 0          # MWU all identical: U / p NaN on both sides
     assert np.all(np.isnan(got['mwu_u'][ident])) and np.all(np.isnan(exp['mwu_u'][ident]))
     got['mwu_u'][ident] = 0.0; exp['mwu_u'][ident] = 0.0
     H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
     assert np.array_equal(got['status'], exp['status'])
-    ks = nm.detect_host(s0, off0, s1, off1, rid, nb=nb, weights_dif=2.0, method=method, tests=L.TEST_KS)
+    ks = nm.detect_host(s0, off0, s1, off1, rid, nb=nb, weights_dif=2.0, method=method, tests=L.TEST_KS, flags=hf)
     H.assert_close_stat(ks['ks_d'], exp['ks_d'], 0, 0.0, 'ks_d')
     H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
     H.assert_close_p(ks['comb_p'], exp['comb_p'], 1e-9, 'comb_p')

@@ -121,3 +121,35 @@ def test_cpu_leg_generator_is_the_device_generator():
         a = bench.synth_event_rows(bench.SEED, 9990, 30, group, 57, bench.PLANT_PERIOD, 800, spread, i16)
         b = H.synth_events_ref(bench.SEED, 9990, 30, group, 57, bench.PLANT_PERIOD, 800, spread, 'i16' if i16 else 'f32')
         assert a.shape == (30, 57) and np.array_equal(a, b) and a.dtype == b.dtype
+
+
+def test_last_line_is_a_compact_record_the_driver_can_keep():
+    """the driver keeps an 8 KB tail of stdout and parses the LAST line; round 5's 32 KB line was lost.  The
+    compact form of a real default run's full record (tests/golden/bench_full_record.json: the side file of a run on the GPU box)
+    stays under 8 000 bytes — under 4 000 for the default legs —, is one line of valid JSON, and carries the contract's keys with
+    `roofline` and `cpu_baseline`; a record swollen with extra legs sheds the optional maps instead of growing past the cap."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_full_record.json')))
+    side, host_path, drop_in = full['side_legs'], full.get('host_path'), full.get('drop_in_mtest2')
+    rec, text = bench.compact_record(full, side, host_path, drop_in, 'bench_side.json')
+    assert '\n' not in text and len(text) < 4000, len(text)
+    back = json.loads(text)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+              'config', 'roofline', 'valu', 'verify', 'cpu_baseline', 'build_info', 'side_legs_file', 'form_share'):
+        assert k in back, k
+    assert back['config']['workload'].startswith('BASELINE.json configs[1]') and 'model' not in back['config']
+    r = back['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-5
+    assert 'traffic' in r and 'traffic_attached_from' in r and r['kernel'].startswith('ks_rank_kernel')
+    cb = back['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'positions/s' and cb['sample']
+    assert back['value'] == float('%.6g' % full['value']) and back['verify']['ok'] is True
+    assert set(back['side']) >= {'all_tests', 'int16', 'outliers.all_tests_i16_10_permille', 'ragged_event_outliers.ragged_i16_10_permille'}
+    # a run with many more legs: the optional maps go, the contract's keys stay, the line stays under the cap
+    fat = dict(side)
+    for i in range(400):
+        fat['extra_leg_%d' % i] = {'value': 1.0e9 + i, 'verify': {'ok': True}}
+    rec2, text2 = bench.compact_record(full, fat, host_path, drop_in, 'bench_side.json')
+    assert len(text2) < bench.LAST_LINE_CAP and 'side' not in rec2 and 'roofline' in rec2 and 'cpu_baseline' in rec2
+    assert bench.short_build_info(full['build_info']).endswith('experiment switches: none')

@@ -428,8 +428,10 @@ def test_event_like_batches_vs_oracle(nm, spread, dtype):
         if dtype == 'f64':
             sig0 = sig0.astype(np.float64) / 1000.0; sig1 = sig1.astype(np.float64) / 1000.0
         kw = dict(stride0=200, stride1=200) if shape == 'stride' else {}
+        # ('f64': through the device's float64 front end — whole-number keys — not the host-side narrowing to int16)
+        f64 = L.FLAG_NO_HOST_NARROW if dtype == 'f64' else 0
         got = nm.detect_host(sig0, None if shape == 'stride' else off0, sig1, None if shape == 'stride' else off1, rid, nb=2,
-                             weights_dif=2.0, method='fisher', **kw)
+                             weights_dif=2.0, method='fisher', flags=f64, **kw)
         st = L.last_dispatch_stats()
         H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(sig0, off0, sig1, off1))
         assert np.array_equal(got['status'], exp['status'])
@@ -441,13 +443,13 @@ def test_event_like_batches_vs_oracle(nm, spread, dtype):
         assert st['rank_hist'] + st['rank_hist_wide'] + st['rank_pair'] == P - counted and st['ks_rank'] == 0
         # ... and the sorting forms alone (NMOD_FLAG_NO_COUNTING) give the same integers, so the same U, D and p bit for bit
         srt = nm.detect_host(sig0, None if shape == 'stride' else off0, sig1, None if shape == 'stride' else off1, rid, nb=2,
-                             weights_dif=2.0, method='fisher', flags=L.FLAG_NO_COUNTING, **kw)
+                             weights_dif=2.0, method='fisher', flags=L.FLAG_NO_COUNTING | f64, **kw)
         st0 = L.last_dispatch_stats()
         assert st0['count_tried'] == 0 and st0['rank_count'] + st0['rank_count_wide'] == 0 and st0['rank_hist'] == P
         for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p', 'comb_st', 'comb_p'):
             assert np.array_equal(srt[k], got[k], equal_nan=True), (shape, k)
         H.assert_close_p(srt['t_p'], got['t_p'], 1e-9, 't_p')
-        got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='fisher', tests=L.TEST_KS)
+        got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=2, weights_dif=2.0, method='fisher', tests=L.TEST_KS, flags=f64)
         st = L.last_dispatch_stats()
         assert st['ks_rank'] == P and st['count_tried'] == 0            # (KS only at this coverage: ks_rank_kernel, eight / four positions per wave)
         assert np.array_equal(got['ks_d'], exp['ks_d'])
@@ -499,7 +501,8 @@ def test_counting_form_edges(nm, dtype):
     else:
         s0 = k0.astype(np.float64) / 1000.0; s1 = k1.astype(np.float64) / 1000.0
     exp = orc.detect_batch(s0, off0, s1, off1, rid, 0, 2.0, orc.METHOD_FISHER)
-    got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher')
+    f64 = L.FLAG_NO_HOST_NARROW if dtype == 'f64' else 0           # (the device's float64 front end, not the host-side narrowing)
+    got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=f64)
     st = L.last_dispatch_stats()
     # exactly the positions the docstring lists are handed on: range 2 048, a group of 256, + the float32 sample off the grid; float64:
     # + the all-equal position (0.5 is float32-exact, so its keys are the values themselves, not k: not the counting form's)
@@ -514,7 +517,7 @@ def test_counting_form_edges(nm, dtype):
     H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
     # the same positions alone (a batch of twelve edge cases: whatever the probe decides, the numbers are the same)
     lo = edge_at
-    sub = nm.detect_host(s0[off0[lo]:], off0[lo:] - off0[lo], s1[off1[lo]:], off1[lo:] - off1[lo], rid[lo:], nb=0, weights_dif=2.0, method='fisher')
+    sub = nm.detect_host(s0[off0[lo]:], off0[lo:] - off0[lo], s1[off1[lo]:], off1[lo:] - off1[lo], rid[lo:], nb=0, weights_dif=2.0, method='fisher', flags=f64)
     for k in ('mwu_p', 'ks_d', 'ks_p'):                      # (exact integers into the same K2: bit-equal whichever form produced them)
         assert np.array_equal(sub[k][1:], got[k][lo + 1:], equal_nan=True), k
     H.assert_close_p(sub['t_p'][1:], got['t_p'][lo + 1:], 1e-9, 't_p')
@@ -547,6 +550,7 @@ def test_count_wide_event_like_vs_oracle(nm, shape, dtype):
     batch; all tests and KS-only (the latter never takes the form)"""
     import oracle_c
     L = nm._lib
+    f64 = L.FLAG_NO_HOST_NARROW if dtype == 'f64' else 0           # ('f64': the device's float64 front end — whole-number keys —, not the host-side narrowing)
     rng = np.random.default_rng(zlib.crc32((shape + dtype).encode()))
     P = 700
     if shape in ('skew', 'skew_rev'):
@@ -568,7 +572,7 @@ def test_count_wide_event_like_vs_oracle(nm, shape, dtype):
     s0, s1 = _as_dtype(k0, dtype), _as_dtype(k1, dtype)
     exp = oracle_c.detect_batch(s0 if dtype == 'f32' else k0, off0, s1 if dtype == 'f32' else k1, off1, rid, 2, 2.0, 'stouffer', tests=7)
     kw = dict(stride0=600, stride1=90) if shape == 'stride600' else {}
-    got = nm.detect_host(s0, None if kw else off0, s1, None if kw else off1, rid, nb=2, weights_dif=2.0, method='stouffer', **kw)
+    got = nm.detect_host(s0, None if kw else off0, s1, None if kw else off1, rid, nb=2, weights_dif=2.0, method='stouffer', **kw, flags=f64)
     st = L.last_dispatch_stats()
     H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
     assert np.array_equal(got['status'], exp['status'])
@@ -576,18 +580,18 @@ def test_count_wide_event_like_vs_oracle(nm, shape, dtype):
     share = st['rank_count_wide'] / P
     assert st['skipped'] == 0 and share >= (0.45 if shape == 'mixed' else 0.95), (shape, st)
     # ... and without it (NMOD_FLAG_NO_COUNT_WIDE) the sorting forms give the same integers: U, D, p bit for bit
-    srt = nm.detect_host(s0, None if kw else off0, s1, None if kw else off1, rid, nb=2, weights_dif=2.0, method='stouffer', flags=L.FLAG_NO_COUNT_WIDE, **kw)
+    srt = nm.detect_host(s0, None if kw else off0, s1, None if kw else off1, rid, nb=2, weights_dif=2.0, method='stouffer', flags=f64 | L.FLAG_NO_COUNT_WIDE, **kw)
     assert L.last_dispatch_stats()['rank_count_wide'] == 0
     for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p', 'comb_st', 'comb_p'):
         assert np.array_equal(srt[k], got[k], equal_nan=True), (shape, k)
     H.assert_close_p(srt['t_p'], got['t_p'], 1e-9, 't_p')
-    got = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    got = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=f64)
     st = L.last_dispatch_stats()
     if shape in ('skew', 'skew_rev', '500v500', '1000v1000', 'stride600'):       # KS only: positions whose larger group holds >= 320 samples
         assert st['rank_count_wide'] >= 0.8 * P and st['ks_rank'] + st['big'] == P - st['rank_count_wide'], (shape, st)
     assert np.array_equal(got['ks_d'], exp['ks_d'])
     H.assert_close_p(got['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
-    srt = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=L.FLAG_NO_COUNTING)
+    srt = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=f64 | L.FLAG_NO_COUNTING)
     assert L.last_dispatch_stats()['rank_count_wide'] == 0
     for k in ('ks_d', 'ks_p', 'comb_st', 'comb_p'):
         assert np.array_equal(srt[k], got[k], equal_nan=True), (shape, k)
@@ -601,6 +605,7 @@ def test_count_wide_edges(nm, dtype):
     keys at the ends of the int16 domain; a float32 sample off the grid in either group; a smaller group of one"""
     import oracle_c
     L = nm._lib
+    f64 = L.FLAG_NO_HOST_NARROW if dtype == 'f64' else 0           # ('f64': the device's float64 front end — whole-number keys —, not the host-side narrowing)
     rng = np.random.default_rng(91)
     rows0, rows1 = [], []
 
@@ -637,7 +642,7 @@ def test_count_wide_edges(nm, dtype):
         s0[off0[off_grid_at] + 700] = np.nextafter(s0[off0[off_grid_at] + 700], np.float32(9))
         s1[off1[off_grid_at + 1] + 3] = np.nextafter(s1[off1[off_grid_at + 1] + 3], np.float32(-9))
     exp = oracle_c.detect_batch(s0 if dtype == 'f32' else k0, off0, s1 if dtype == 'f32' else k1, off1, rid, 0, 2.0, 'fisher', tests=7)
-    got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher')
+    got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=f64)
     st = L.last_dispatch_stats()
     # the bulk (300 positions) is the form's; of the edge positions it hands on at most all
     assert st['rank_count_wide'] >= 300 and st['count_rejected'] <= P - 300 and st['count_tried'] >= 300 and st['skipped'] == 0, st
@@ -646,21 +651,21 @@ def test_count_wide_edges(nm, dtype):
     for d in (got, exp):
         d['mwu_u'][ident] = 0.0; d['mwu_p'][ident] = 0.0
     H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
-    srt = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=L.FLAG_NO_COUNTING)
+    srt = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=f64 | L.FLAG_NO_COUNTING)
     assert L.last_dispatch_stats()['count_tried'] == 0
     for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p'):                  # the sorting forms alone: the same integers, so U, D and p bit for bit
         assert np.array_equal(srt[k][~ident], got[k][~ident]), k
     lo = edge_at                                               # the edge positions alone: whatever the probes decide, the same numbers
-    sub = nm.detect_host(s0[off0[lo]:], off0[lo:] - off0[lo], s1[off1[lo]:], off1[lo:] - off1[lo], rid[lo:], nb=0, weights_dif=2.0, method='fisher')
+    sub = nm.detect_host(s0[off0[lo]:], off0[lo:] - off0[lo], s1[off1[lo]:], off1[lo:] - off1[lo], rid[lo:], nb=0, weights_dif=2.0, method='fisher', flags=f64)
     for k in ('mwu_p', 'ks_d', 'ks_p'):
         assert np.array_equal(sub[k][1:], got[k][lo + 1:], equal_nan=True), k
     H.assert_close_p(sub['t_p'][1:], got['t_p'][lo + 1:], 1e-9, 't_p')
     # KS only (the form without the tie term; positions whose larger group is below its size stay with ks_rank_kernel), D bit for bit
     # and as the exact rational (NMOD_FLAG_KS_RATIONAL_D: within 2 ulp)
-    ks = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    ks = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=f64)
     assert np.array_equal(ks['ks_d'], exp['ks_d'])
     H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
-    kr = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=L.FLAG_KS_RATIONAL_D)
+    kr = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=f64 | L.FLAG_KS_RATIONAL_D)
     assert np.all(np.abs(kr['ks_d'] - exp['ks_d']) <= 4.5e-16)
 
 
@@ -730,7 +735,8 @@ def test_count_wide_outliers_vs_oracle(nm, dtype):
 
 def _count_wide_outlier_checks(nm, dtype, s0, off0, s1, off1, rid, exp, kept, P):
     L = nm._lib
-    got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher')
+    f64 = L.FLAG_NO_HOST_NARROW if dtype == 'f64' else 0           # ('f64': the device's float64 front end — whole-number keys —, not the host-side narrowing)
+    got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=f64)
     st = L.last_dispatch_stats()
     H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
     assert np.array_equal(got['status'], exp['status'])
@@ -739,17 +745,17 @@ def _count_wide_outlier_checks(nm, dtype, s0, off0, s1, off1, rid, exp, kept, P)
     # the positions with 65 outliers are handed on; of the randomly contaminated ones at 50 per mille (~55 outliers of ~1 100) a few more
     assert n_rej <= st['count_rejected'] <= n_rej + 25 and st['rank_count_wide'] == P - st['count_rejected'], (n_rej, st)
     # the sorting forms alone: the same integers
-    srt = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=L.FLAG_NO_COUNTING)
+    srt = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=f64 | L.FLAG_NO_COUNTING)
     assert L.last_dispatch_stats()['count_tried'] == 0
     for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p'):
         assert np.array_equal(srt[k], got[k]), k
     H.assert_close_p(srt['t_p'], got['t_p'], 1e-9, 't_p')
     # KS only (no tie term, no moments), D bit for bit; the exact-rational flag
-    ks = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS)
+    ks = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=f64)
     st = L.last_dispatch_stats()
     assert np.array_equal(ks['ks_d'], exp['ks_d']) and st['rank_count_wide'] >= P - n_rej - 25
     H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
-    kr = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=L.FLAG_KS_RATIONAL_D)
+    kr = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=f64 | L.FLAG_KS_RATIONAL_D)
     assert np.all(np.abs(kr['ks_d'] - exp['ks_d']) <= 4.5e-16)
 
 

@@ -362,6 +362,27 @@ int nmod_region_rank(const nmod_params* prm, int64_t npos, const int32_t* strand
                      const int64_t* pos, const char* base, const double* value, int32_t w, int32_t movesize,
                      char na, double percentile, int32_t wind_ovlp, int32_t* ranked_out, int64_t* n_ranked);
 
+/* ---- position shards across the GPUs of a node without any host framework (BASELINE.json north_star: "an RCCL
+ * all-gather over xGMI to reassemble the per-base p-value track").  The reference has no counterpart (one CPU process).  One
+ * process (or thread) per GPU computes a contiguous block of positions (+- nb recomputed neighbours) with
+ * nmod_detect_batch and calls nmod_allgather_tracks: rank r's block of `block_len` doubles of every track lands at
+ * full[t] + r * block_len on every rank (blocks of equal length: pad the last one).  The library does not link RCCL: it binds
+ * librccl.so at the first call — the copy the process has already loaded if there is one (a PyTorch process: torch's), else
+ * librccl.so.1 from the loader path — and returns NMOD_ERR_NO_RCCL when there is none.
+ *   rank 0:      nmod_comm_unique_id(id)  -> hand the NMOD_COMM_ID_BYTES bytes to the other ranks (file, socket, MPI, ...)
+ *   every rank:  nmod_comm_init_rank(id, nranks, rank, device, &comm)           (collective: all ranks must call it)
+ *                nmod_allgather_tracks(comm, stream, block_len, ntracks, local, full)   enqueued on `stream`, no synchronisation
+ *                nmod_comm_destroy(comm) */
+#define NMOD_COMM_ID_BYTES 128
+#define NMOD_ERR_NO_RCCL (-6)      /* librccl.so could not be bound */
+#define NMOD_ERR_RCCL (-7)         /* an RCCL call failed; see nmod_strerror */
+typedef struct nmod_comm nmod_comm;
+int nmod_comm_unique_id(void* id_out);
+int nmod_comm_init_rank(const void* unique_id, int32_t nranks, int32_t rank, int32_t device, nmod_comm** comm_out);
+int nmod_allgather_tracks(nmod_comm* comm, void* stream, int64_t block_len, int32_t ntracks,
+                          const double* const* local, double* const* full);
+int nmod_comm_destroy(nmod_comm* comm);
+
 /* Lane-permutation self test of the wave primitives the sort is built from
  * (runs tiny kernels; returns NMOD_OK or the number of the first failing primitive). */
 int nmod_selftest(int32_t device);

@@ -23,6 +23,8 @@ KERNEL_RANK_STATS, KERNEL_FINALIZE, KERNEL_COMBINE, KERNEL_SYNTH = 0, 1, 2, 3
 MAX_GROUP = 2048          # largest group of the wave-resident kernels; larger ones (<= MAX_RANKED) take big_rank_kernel
 MAX_RANKED = 65535
 MAX_NB = 64
+COMM_ID_BYTES = 128
+ERR_NO_RCCL, ERR_RCCL = -6, -7
 
 METHOD_BY_NAME = {'ks': METHOD_KS, 'stouffer': METHOD_STOUFFER, 'fisher': METHOD_FISHER}
 
@@ -86,6 +88,10 @@ _SIGNATURES = {
     'nmod_evtimer_read': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     'nmod_evtimer_destroy': (C.c_int, [C.c_void_p]),
     'nmod_selftest': (C.c_int, [C.c_int32]),
+    'nmod_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'nmod_comm_init_rank': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    'nmod_allgather_tracks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    'nmod_comm_destroy': (C.c_int, [C.c_void_p]),
     'nmod_narrow_probe': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     'nmod_format_probe': (C.c_int, [C.POINTER(C.c_double), C.c_int64, C.c_int32, C.c_char_p, C.c_int64]),
     'nmod_trim_scratch': (C.c_int, [C.c_int32]),

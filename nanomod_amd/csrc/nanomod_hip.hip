@@ -14,6 +14,7 @@
 #include <thread>
 #include <functional>
 #include <condition_variable>
+#include <dlfcn.h>
 
 #include "../../include/nanomod_hip.h"
 #include "rank_stats.hpp"
@@ -959,6 +960,54 @@ static int selftest_sort(int code) {
 // =================================================================== C ABI
 using namespace nmod;
 
+namespace nmod {
+// ---------------------------------------------------------------- RCCL, bound at run time (nmod_comm_*, nmod_allgather_tracks)
+// No link-time dependency: a PyTorch process already holds torch's librccl.so (its "nccl" backend) and a second copy beside it
+// would be a second set of communicator state; a process without one takes librccl.so.1 from the loader path.
+struct IdByValue { char internal[NMOD_COMM_ID_BYTES]; };      // ncclUniqueId is passed by value
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, IdByValue, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+thread_local int g_last_rccl = 0;
+thread_local const char* g_last_rccl_text = nullptr;
+static RcclApi* rccl_api() {
+  static std::once_flag once;
+  static RcclApi api;
+  static bool ok = false;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    for (const char* n : names) { api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (api.handle) break; }     // a copy the process already holds
+    if (!api.handle) for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.handle) break; }
+    if (!api.handle) return;
+    auto sym = [&](const char* n) { return dlsym(api.handle, n); };
+    api.GetUniqueId = (int (*)(void*))sym("ncclGetUniqueId");
+    api.CommInitRank = (int (*)(void**, int, IdByValue, int))sym("ncclCommInitRank");
+    api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))sym("ncclAllGather");
+    api.GroupStart = (int (*)())sym("ncclGroupStart");
+    api.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    api.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+    api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    ok = api.GetUniqueId && api.CommInitRank && api.AllGather && api.GroupStart && api.GroupEnd && api.CommDestroy;
+  });
+  return ok ? &api : nullptr;
+}
+#define NMOD_RCCL(api, call)                                                                         \
+  do {                                                                                               \
+    const int r_ = (call);                                                                           \
+    if (r_ != 0) { g_last_rccl = r_; g_last_rccl_text = (api)->GetErrorString ? (api)->GetErrorString(r_) : nullptr; return NMOD_ERR_RCCL; } \
+  } while (0)
+constexpr int kNcclFloat64 = 8;                  // ncclDataType_t: ncclFloat64 / ncclDouble
+
+}  // namespace nmod
+struct nmod_comm { void* comm; int nranks, rank, device; };
+
 extern "C" {
 
 int nmod_abi_version(void) { return NMOD_ABI_VERSION; }
@@ -979,6 +1028,10 @@ const char* nmod_strerror(int rc) {
     case NMOD_ERR_TOO_LARGE: return "a position has more samples in a group than NMOD_MAX_RANKED (65535)";
     case NMOD_ERR_WORKSPACE: return "workspace missing or smaller than nmod_workspace_bytes()";
     case NMOD_ERR_NO_DEVICE: return "no HIP device";
+    case NMOD_ERR_NO_RCCL: return "librccl.so could not be bound (neither loaded in this process nor on the loader path)";
+    case NMOD_ERR_RCCL:
+      snprintf(g_errbuf, sizeof(g_errbuf), "RCCL error %d: %s", g_last_rccl, g_last_rccl_text ? g_last_rccl_text : "?");
+      return g_errbuf;
     default: return "unknown error code";
   }
 }
@@ -1524,6 +1577,59 @@ int nmod_write_sign_test(const char* path, int64_t npos, const int32_t* chrom_id
   }
   const bool closed = fclose(f) == 0;
   return (ok && closed) ? NMOD_OK : NMOD_ERR_INVALID_ARG;
+}
+
+int nmod_comm_unique_id(void* id_out) {
+  if (!id_out) return NMOD_ERR_INVALID_ARG;
+  RcclApi* api = rccl_api();
+  if (!api) return NMOD_ERR_NO_RCCL;
+  NMOD_RCCL(api, api->GetUniqueId(id_out));
+  return NMOD_OK;
+}
+
+int nmod_comm_init_rank(const void* unique_id, int32_t nranks, int32_t rank, int32_t device, nmod_comm** comm_out) {
+  if (!unique_id || !comm_out || nranks < 1 || rank < 0 || rank >= nranks) return NMOD_ERR_INVALID_ARG;
+  *comm_out = nullptr;
+  if (nmod_device_count() <= device || device < 0) return NMOD_ERR_NO_DEVICE;
+  RcclApi* api = rccl_api();
+  if (!api) return NMOD_ERR_NO_RCCL;
+  NMOD_HIP(hipSetDevice(device));
+  IdByValue id;
+  memcpy(id.internal, unique_id, NMOD_COMM_ID_BYTES);
+  void* c = nullptr;
+  NMOD_RCCL(api, api->CommInitRank(&c, nranks, id, rank));
+  nmod_comm* h = new nmod_comm();
+  h->comm = c; h->nranks = nranks; h->rank = rank; h->device = device;
+  *comm_out = h;
+  return NMOD_OK;
+}
+
+int nmod_allgather_tracks(nmod_comm* comm, void* stream, int64_t block_len, int32_t ntracks, const double* const* local, double* const* full) {
+  if (!comm || !comm->comm || block_len < 0 || ntracks < 0 || ntracks > 64 || (ntracks > 0 && (!local || !full))) return NMOD_ERR_INVALID_ARG;
+  for (int t = 0; t < ntracks; ++t) if (!local[t] || !full[t]) return NMOD_ERR_INVALID_ARG;
+  if (block_len == 0 || ntracks == 0) return NMOD_OK;
+  RcclApi* api = rccl_api();
+  if (!api) return NMOD_ERR_NO_RCCL;
+  NMOD_HIP(hipSetDevice(comm->device));
+  // one group: the tracks' gathers are fused into one launch on the caller's stream; nothing is synchronised here
+  NMOD_RCCL(api, api->GroupStart());
+  int first_bad = 0;
+  for (int t = 0; t < ntracks; ++t) {
+    const int r = api->AllGather(local[t], full[t], (size_t)block_len, kNcclFloat64, comm->comm, (hipStream_t)stream);
+    if (r != 0 && first_bad == 0) first_bad = r;
+  }
+  const int rend = api->GroupEnd();
+  if (first_bad != 0 || rend != 0) { g_last_rccl = first_bad ? first_bad : rend; g_last_rccl_text = api->GetErrorString ? api->GetErrorString(g_last_rccl) : nullptr; return NMOD_ERR_RCCL; }
+  return NMOD_OK;
+}
+
+int nmod_comm_destroy(nmod_comm* comm) {
+  if (!comm) return NMOD_ERR_INVALID_ARG;
+  RcclApi* api = rccl_api();
+  int rc = NMOD_OK;
+  if (api && comm->comm) { const int r = api->CommDestroy(comm->comm); if (r != 0) { g_last_rccl = r; g_last_rccl_text = api->GetErrorString ? api->GetErrorString(r) : nullptr; rc = NMOD_ERR_RCCL; } }
+  delete comm;
+  return rc;
 }
 
 int nmod_selftest(int32_t device) {

@@ -183,3 +183,53 @@ def pipelined_detect(compute, state, nb, group=None, gather=True, force_collecti
             else:                                        # one rank, no process group: the "gather" is a copy
                 dst[:B].copy_(src)
     return state if gather else local
+
+
+# ---------------------------------------------------------------- the same collective without torch.distributed
+class CAbiComm:
+    """The all-gather of the per-base tracks through the C ABI alone (include/nanomod_hip.h: nmod_comm_*, nmod_allgather_tracks):
+    what a caller without torch.distributed — the reference is plain Python / numpy — uses to shard positions over the GPUs of a
+    node.  Rank 0 makes the id (`CAbiComm.unique_id()`) and hands its 128 bytes to the others by any means; every rank then
+    constructs CAbiComm(id, nranks, rank, device) (collective) and calls allgather() with device pointers.  torch tensors are
+    accepted for convenience (their data_ptr() is taken); nothing here needs torch."""
+
+    def __init__(self, unique_id, nranks, rank, device):
+        import ctypes as C
+        from . import _lib as L
+        self._L, self._lib = L, L.load()
+        if len(unique_id) != L.COMM_ID_BYTES:
+            raise ValueError('unique_id must be %d bytes' % L.COMM_ID_BYTES)
+        self._h = C.c_void_p()
+        L.check(self._lib.nmod_comm_init_rank(C.c_char_p(bytes(unique_id)), int(nranks), int(rank), int(device), C.byref(self._h)),
+                'nmod_comm_init_rank')
+        self.nranks, self.rank, self.device = int(nranks), int(rank), int(device)
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib as L
+        buf = C.create_string_buffer(L.COMM_ID_BYTES)
+        L.check(L.load().nmod_comm_unique_id(buf), 'nmod_comm_unique_id')
+        return buf.raw
+
+    def allgather(self, local, full, block_len, stream=0):
+        """local[t]: this rank's block (block_len doubles, device memory); full[t]: nranks * block_len doubles on every rank;
+        enqueued on `stream` (a hipStream_t value, 0 = the default stream), not synchronised"""
+        import ctypes as C
+        ptr = lambda x: x.data_ptr() if hasattr(x, 'data_ptr') else int(x)
+        n = len(local)
+        if len(full) != n:
+            raise ValueError('one full track per local track')
+        la = (C.c_void_p * n)(*[ptr(x) for x in local]); fa = (C.c_void_p * n)(*[ptr(x) for x in full])
+        self._L.check(self._lib.nmod_allgather_tracks(self._h, C.c_void_p(int(stream) or None), int(block_len), n, la, fa), 'nmod_allgather_tracks')
+
+    def close(self):
+        if self._h:
+            self._L.check(self._lib.nmod_comm_destroy(self._h), 'nmod_comm_destroy')
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

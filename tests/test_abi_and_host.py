@@ -105,6 +105,32 @@ def test_dispatch_stats_without_a_call_and_form_flags():
     assert 'getenv("NMOD_NO_COUNT' not in src
 
 
+def test_cabi_collective_argument_plumbing_without_a_gpu():
+    """nmod_comm_* / nmod_allgather_tracks (the torch-free all-gather, include/nanomod_hip.h): RCCL is bound at run time — the ids of
+    two calls differ —, bad arguments are refused before any device or RCCL work, and a rank cannot be made without a device"""
+    import nanomod_amd._lib as L
+    from nanomod_amd import sharding
+    lib = L.load()
+    buf = C.create_string_buffer(L.COMM_ID_BYTES)
+    rc = lib.nmod_comm_unique_id(buf)
+    if rc == L.ERR_NO_RCCL:
+        pytest.skip('no librccl.so on this machine')
+    assert rc == 0 and sharding.CAbiComm.unique_id() != sharding.CAbiComm.unique_id() and len(sharding.CAbiComm.unique_id()) == 128
+    h = C.c_void_p()
+    assert lib.nmod_comm_unique_id(None) == -1
+    assert lib.nmod_comm_init_rank(None, 1, 0, 0, C.byref(h)) == -1 and lib.nmod_comm_init_rank(buf, 0, 0, 0, C.byref(h)) == -1
+    assert lib.nmod_comm_init_rank(buf, 2, 2, 0, C.byref(h)) == -1 and lib.nmod_comm_init_rank(buf, 2, -1, 0, C.byref(h)) == -1
+    assert lib.nmod_comm_init_rank(buf, 1, 0, 0, None) == -1
+    assert lib.nmod_allgather_tracks(None, None, 4, 1, None, None) == -1 and lib.nmod_comm_destroy(None) == -1
+    if lib.nmod_device_count() == 0:
+        assert lib.nmod_comm_init_rank(buf, 1, 0, 0, C.byref(h)) == -5 and not h.value
+        with pytest.raises(L.NanomodLibraryError, match='no HIP device'):
+            sharding.CAbiComm(buf.raw, 1, 0, 0)
+    with pytest.raises(ValueError):
+        sharding.CAbiComm(b'short', 1, 0, 0)
+    assert b'librccl' in lib.nmod_strerror(-6)
+
+
 def test_host_narrowing_accepts_exactly_the_int16_grid():
     """nmod_narrow_probe (the float64 -> int16 narrowing of the host-resident entry, host_pipeline.hpp): every k / 1000.0 with
     |k| <= 32 767 narrows to k — the division-free quotient test is exact for all 65 535 of them, through the vector loop and its

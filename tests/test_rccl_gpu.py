@@ -103,3 +103,71 @@ def test_rccl_allgather_one_rank_per_gpu(world):
     for p in procs:
         p.join(timeout=60)
     assert all(v == 'ok' for v in results.values()), results
+
+
+def _cabi_rank(rank, world, id_bytes, P, n, nb):
+    """one rank of the torch.distributed-free path: its block through nmod_detect_batch, the tracks through nmod_allgather_tracks"""
+    import torch
+    import nanomod_amd as nm
+    from nanomod_amd import sharding
+    dev = 'cuda:%d' % rank
+    torch.cuda.set_device(rank)
+    det, compute = _problem(P, n, nb, dev, nm)
+    full_ref = compute(0, P)
+    B = (P + world - 1) // world
+    lo, hi = min(rank * B, P), min((rank + 1) * B, P)
+    lo_h, hi_h = sharding.halo_bounds(lo, hi, nb, P)
+    part = compute(lo_h, hi_h) if hi > lo else None
+    tracks = ('ks_p', 'comb_p')
+    local = [torch.zeros(B, dtype=torch.float64, device=dev) for _ in tracks]
+    if part is not None:
+        for t, k in zip(local, tracks):
+            t[:hi - lo] = part[k][lo - lo_h: lo - lo_h + hi - lo]
+    full = [torch.full((B * world,), -1.0, dtype=torch.float64, device=dev) for _ in tracks]
+    comm = sharding.CAbiComm(id_bytes, world, rank, rank)
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    for _ in range(2):                                                    # twice: the communicator is reusable, the buffers are rewritten
+        comm.allgather(local, full, B, stream=s.cuda_stream)
+    s.synchronize()
+    comm.close()
+    for t, k in zip(full, tracks):
+        assert torch.equal(t[:P], full_ref[k]), (rank, k)
+
+
+@pytest.mark.timeout(300)
+def test_cabi_allgather_world1_without_torch_distributed():
+    """nmod_comm_* / nmod_allgather_tracks (RCCL bound at run time, no process group): one rank, a side stream, two tracks"""
+    import torch.distributed as dist
+    from nanomod_amd import sharding
+    assert not dist.is_initialized()
+    _cabi_rank(0, 1, sharding.CAbiComm.unique_id(), 5003, 64, 3)
+
+
+def _cabi_child(rank, world, id_bytes, q):
+    try:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        _cabi_rank(rank, world, id_bytes, 20011, 64, 2)
+        q.put((rank, 'ok'))
+    except Exception as e:                                                # noqa: BLE001 — reported to the parent
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('world', [2, 8])
+def test_cabi_allgather_one_rank_per_gpu(world):
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip('needs %d GPUs on this box' % world)
+    import torch.multiprocessing as mp
+    from nanomod_amd import sharding
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    id_bytes = sharding.CAbiComm.unique_id()                              # (made before any child starts; handed over as an argument)
+    procs = [ctx.Process(target=_cabi_child, args=(r, world, id_bytes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(v == 'ok' for v in results.values()), results

@@ -639,7 +639,8 @@ def compact_record(full, side, host_path, drop_in, side_file):
                        'traffic': r['traffic'], 'traffic_attached_from': r['traffic_source'], 'limited_by': 'valu-issue',
                        'kernel': r['kernel'], 'kernel_avg_ms': r['kernel_avg_ms'], 'path_avg_ms': r['path_avg_ms'],
                        'launches_timed': r['launches_timed'], 'algorithmic_bytes_per_position': r['algorithmic_bytes_per_position'],
-                       'positions_per_launch': r['positions_per_launch'], 'measured_copy_GBps': r['measured_copy_GBps']}
+                       'positions_per_launch': r['positions_per_launch'], 'measured_copy_GBps': r['measured_copy_GBps'],
+                       'profile_key': r.get('profile_key')}
     rec['valu'] = {'instr_per_position': full['valu']['instr_per_position'], 'issue_util': full['valu']['issue_util'],
                    'attached_from': full['valu']['source']}
     if full.get('form_share') is not None:
@@ -688,7 +689,7 @@ def short_build_info(info):
     parts = info.split(' | ')
     head = parts[0]
     shipped = {'NMOD_SKIP': '0', 'NMOD_EXP': '0', 'NMOD_SWZ_MASK': '0', 'NMOD_PK_SELECT': '0', 'NMOD_CE_BUILTIN': '0', 'NMOD_XOR4_BANKS': '0',
-               'NMOD_NO_GRID': '0', 'NMOD_CNT_SKIP': '0', 'NMOD_CW_OR3': '1'}
+               'NMOD_NO_GRID': '0', 'NMOD_CNT_SKIP': '0', 'NMOD_CW_OR3': '1', 'NMOD_CNT_TAILS': '1'}
     odd = set()
     for tu in parts[1:]:
         name, _, kv = tu.partition(': ')

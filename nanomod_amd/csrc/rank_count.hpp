@@ -42,7 +42,9 @@ namespace nmod {
 constexpr int kCntLanes = 16;                                   // lanes per position
 constexpr int kCntWindow = 2048;                                // values of the direct-address window
 constexpr int kCntBlockWords = 36;                              // a lane's block: 4 pad words + 32 words of byte counters
-constexpr int kCntPosWords = kCntLanes * kCntBlockWords;        // 576
+constexpr int kCntTail = 16;                                    // samples far from the position's level (outliers) it may hold: one per lane
+constexpr int kCntTableWords = kCntLanes * kCntBlockWords;      // 576
+constexpr int kCntPosWords = kCntTableWords + kCntTail;         // + the tail list: 592 words, 37.9 KB per block of four waves: four blocks per CU
 constexpr int kCntMaxN = 255;                                   // byte counters and byte prefix sums
 constexpr int kCntMinN = 4;                                     // (KsRows reads shorter rows through a conditional path)
 __host__ __device__ constexpr size_t rank_count_lds_bytes() { return (size_t)kWavesPerBlock * 4 * kCntPosWords * 4 + 16; }
@@ -69,6 +71,9 @@ __device__ __forceinline__ void cnt_lookup_chunk(unsigned ap0, unsigned ap1, uns
 #endif
 #ifndef NMOD_CNT_WAVES
 #define NMOD_CNT_WAVES 4
+#endif
+#ifndef NMOD_CNT_TAILS
+#define NMOD_CNT_TAILS 1     // 1: the probe lets batches with a few outliers per position through (the kernel's tail path); 0: round 5's probe
 #endif
 
 // min / max over the 16 lanes of a position, in every lane
@@ -104,8 +109,8 @@ constexpr int kCntProbeSamples = 64;
 
 template <int DTYPE>
 __global__ __launch_bounds__(1024) void cnt_probe_kernel(CntProbeArgs a) {
-  __shared__ int fits, seen;
-  if (threadIdx.x == 0) { fits = 0; seen = 0; }
+  __shared__ int fits, seen, far;
+  if (threadIdx.x == 0) { fits = 0; seen = 0; far = 0; }
   __syncthreads();
   int64_t count = a.npos;
   const int32_t* list = nullptr;
@@ -117,28 +122,50 @@ __global__ __launch_bounds__(1024) void cnt_probe_kernel(CntProbeArgs a) {
     const int64_t pos = list ? (int64_t)list[li] : li;
     bool ok = true;
     int lo = 0x7fffffff, hi = (int)0x80000000;
+    long long ksum = 0; int ntot = 0;
+    auto key_at = [&](int g, int64_t o, int i, int& k) -> bool {
+      const void* sig = g ? a.sig1 : a.sig0;
+      if constexpr (DTYPE == 0) return grid_key<true>(reinterpret_cast<const float*>(sig)[o + i], k);
+      else if constexpr (DTYPE == 2) return cnt_int_key(reinterpret_cast<const float*>(sig)[o + i], k);
+      else { k = (int)reinterpret_cast<const int16_t*>(sig)[o + i]; return true; }
+    };
+    int64_t oo[2]; int nn[2];
     for (int g = 0; g < 2; ++g) {
       const int64_t st = g ? a.stride1 : a.stride0;
       const int64_t* off = g ? a.off1 : a.off0;
-      const int64_t o = st > 0 ? pos * st : off[pos];
-      const int n = st > 0 ? (int)st : (int)(off[pos + 1] - o);
-      if (n < kCntMinN || n > kCntMaxN) ok = false;
-      const void* sig = g ? a.sig1 : a.sig0;
-      for (int i = lane; i < n && i <= kCntMaxN; i += 64) {
+      oo[g] = st > 0 ? pos * st : off[pos];
+      nn[g] = st > 0 ? (int)st : (int)(off[pos + 1] - oo[g]);
+      if (nn[g] < kCntMinN || nn[g] > kCntMaxN) ok = false;
+      ntot += min(nn[g], kCntMaxN + 1);
+      for (int i = lane; i < nn[g] && i <= kCntMaxN; i += 64) {
         int k;
-        if constexpr (DTYPE == 0) { if (!grid_key<true>(reinterpret_cast<const float*>(sig)[o + i], k)) ok = false; }
-        else if constexpr (DTYPE == 2) { if (!cnt_int_key(reinterpret_cast<const float*>(sig)[o + i], k)) ok = false; }
-        else k = (int)reinterpret_cast<const int16_t*>(sig)[o + i];
-        lo = min(lo, k); hi = max(hi, k);
+        if (!key_at(g, oo[g], i, k)) ok = false;
+        lo = min(lo, k); hi = max(hi, k); ksum += k;
       }
     }
     const int vmax = (int)(wave_max_u32((unsigned)hi ^ 0x80000000u) ^ 0x80000000u);
     const int vmin = (int)(~wave_max_u32(~((unsigned)lo ^ 0x80000000u)) ^ 0x80000000u);
-    const bool fit = __ballot(!ok) == 0ull && (unsigned)(vmax - vmin) < (unsigned)kCntWindow;
+    bool fit = __ballot(!ok) == 0ull && (unsigned)(vmax - vmin) < (unsigned)kCntWindow;
+#if NMOD_CNT_TAILS
+    if (!fit && __ballot(!ok) == 0ull) {
+      // a few outliers: the kernel keeps the position when at most kCntTail samples lie further than 1 024 from the mean of its keys
+      // (half of that here: the batch should mostly take the kernel's path without them)
+      const int centre = (int)__builtin_rintf((float)(long long)wave_sum_u64((unsigned long long)ksum) / (float)max(ntot, 1));
+      const int base = max(-32768, min(centre - kCntWindow / 2, 32768 - kCntWindow));
+      int tails = 0;
+      for (int g = 0; g < 2; ++g)
+        for (int i = lane; i < nn[g] && i <= kCntMaxN; i += 64) { int k; key_at(g, oo[g], i, k); tails += ((unsigned)(k - base) >= (unsigned)kCntWindow) ? 1 : 0; }
+      const int nfar = (int)wave_sum_u64((unsigned long long)tails);
+      fit = nfar <= kCntTail / 2;
+      if (fit && lane == 0) atomicAdd(&far, nfar);
+    }
+#endif
     if (lane == 0) { atomicAdd(&seen, 1); if (fit) atomicAdd(&fits, 1); }
   }
   __syncthreads();
-  if (threadIdx.x == 0) a.gate[0] = (seen > 0 && fits * 8 >= seen * 7) ? 1 : 0;
+  // (the kernel's outlier path costs ~15 % where a wave meets one such position and ~40 % at four outliers per position, measured
+  // on configs[2] rows — the sorting form is 38 % slower than the clean counting form: worth it up to ~2.5 outliers per position)
+  if (threadIdx.x == 0) a.gate[0] = (seen > 0 && fits * 8 >= seen * 7 && far * 2 <= seen * 5) ? 1 : 0;
 }
 
 template <int DTYPE>
@@ -287,6 +314,148 @@ void rank_count_kernel(RankStatsArgs args) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // ---- the window: the position's smallest key is value 0 (moved up: the outlier path below needs the range)
+    int kmin = cnt_allmin_i32(min((int)MN.x, (int)MN.y)), kmax = cnt_allmax_i32(max((int)MX.x, (int)MX.y));
+    // ---- outliers (round 6).  A mis-segmented read sits anywhere in the +-5 unit clip range (myRefBaseSignalAnnotation.py:251-259)
+    // and pushes the position's key range past the window.  Where a position of the wave is that wide, its samples further than
+    // 1 024 milli-units from the mean of its keys — TAIL samples, at most kCntTail = 16 — leave their slots (which become empty
+    // slots) for a list in LDS; the rank statistics depend on the ORDER of the keys only, so the tail samples come back as one
+    // extra sample slot per lane with REMAPPED keys: the distinct tail values below the window take the values just below the
+    // smallest remaining key, those above it the values just above the largest, in order, ties kept (dense ranks from an all-pairs
+    // pass over the list).  Tables, scans, look-ups and sums then run as for any position; only the Welch moments use the true keys.
+    int xk = 0; unsigned xg = 0u; bool xv = false;       // the lane's extra slot: remapped key, group, in use
+    int xd[2] = {0, 0}; double xdd[2] = {0.0, 0.0};      // ... its true moment terms about the reference key (int16 rows)
+    bool have_x = false;                                  // (wave-uniform) some lane of the wave holds an extra slot
+    {
+      const bool wide = fit && (unsigned)(kmax - kmin) >= (unsigned)kCntWindow;
+      if (__ballot(wide) != 0ull) {                       // (wave-uniform; never on rows without outliers)
+        // the mean of the position's keys: empty slots carry their group's first key, taken out again by their count
+        int ksum = 0, kf[2], nv[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          kf[g] = (int)(short)(__builtin_amdgcn_ds_bpermute((lane & ~(LG - 1)) << 2, (int)KP[8 * g]) & 0xffff);
+          const int n = rows_n(cur, g ? n1 : n0);
+          nv[g] = 0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) nv[g] += min(max(n - (c * 64 + 4 * gl), 0), 4);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) if ((anym >> (4 * g + (i >> 1))) & 1u) ksum = __builtin_amdgcn_sdot2(__builtin_bit_cast(CntS2, KP[8 * g + i]), ones, ksum, false);
+          int held = 0;                                   // slots of the chunks that exist: 4 per chunk
+#pragma unroll
+          for (int c = 0; c < 4; ++c) held += ((anym >> (4 * g + c)) & 1u) ? 4 : 0;
+          ksum -= kf[g] * (held - nv[g]);
+        }
+        const int ntot = max(rows_n(cur, n0) + rows_n(cur, n1), 1);
+        const int centre = (int)__builtin_rintf((float)cnt_allsum_i32(ksum) * __builtin_amdgcn_rcpf((float)ntot));
+        const int base = max(-32768, min(centre - kCntWindow / 2, 32768 - kCntWindow));
+        const int cref = base + kCntWindow / 2;           // the reference key of the moments; |k - cref| <= 1 024 for what stays
+        const unsigned base2 = ((unsigned)base & 0xffffu) * 0x10001u;
+        const CntU2 win2 = {(unsigned short)kCntWindow, (unsigned short)kCntWindow};
+        unsigned* tlist = tbl + kCntTableWords;           // the position's tail list: key | group << 16
+        int listed = 0;                                   // (the same in the 16 lanes of a position)
+        unsigned tmask = 0u, cht = 0u;                    // bit s: slot s of this lane is a tail sample; (wave-uniform) bit ch: chunk ch holds one
+        auto push = [&](bool t, int key, unsigned grp) {
+          const unsigned long long mk = __ballot(t);
+          if (mk == 0ull) return false;
+          const unsigned seg = (unsigned)(mk >> (lane & 48)) & 0xffffu;
+          const int idx = listed + (int)__popc(seg & ((1u << gl) - 1u));
+          if (t && idx < kCntTail) tlist[idx] = ((unsigned)key & 0xffffu) | (grp << 16);
+          listed += (int)__popc(seg);
+          return true;
+        };
+        // one cheap pass over the 16 registers: u = min(k - base, 2 048) per slot (2 048: outside the window), the smallest and the
+        // largest u below 2 048, (int16 rows) the sums of u - 1 024 and its square over ALL slots — the outside and the empty slots'
+        // constant shares are taken out below by their counts; only a register in which some lane of the wave holds an outside slot
+        // pays for the validity tests and the appends
+        CntU2 UMN = {65535, 65535}, UMX = {65535, 65535};   // min u; min of 2 047 - u as unsigned (an outside slot gives 65 535: ignored)
+        int j1[2] = {0, 0}, j2[2] = {0, 0}, ntl[2] = {0, 0};
+        const CntU2 top2 = {(unsigned short)(kCntWindow - 1), (unsigned short)(kCntWindow - 1)};
+        const CntS2 half2 = {(short)(kCntWindow / 2), (short)(kCntWindow / 2)};
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const int ch = i >> 1;                          // chunk 4 g + c; the register holds its slots 2 (i & 1), 2 (i & 1) + 1
+          if (!((anym >> ch) & 1u)) continue;
+          const int grp = ch >> 2;
+          const CntU2 u2 = __builtin_elementwise_min(__builtin_bit_cast(CntU2, __builtin_bit_cast(CntS2, KP[i]) - __builtin_bit_cast(CntS2, base2)), win2);
+          UMN = __builtin_elementwise_min(UMN, u2); UMX = __builtin_elementwise_min(UMX, top2 - u2);
+          if constexpr (DTYPE == 1) {
+            const CntS2 d = __builtin_bit_cast(CntS2, u2) - half2;
+            j1[grp] = __builtin_amdgcn_sdot2(d, ones, j1[grp], false);
+            j2[grp] = __builtin_amdgcn_sdot2(d, d, j2[grp], false);
+          }
+          const unsigned ub = __builtin_bit_cast(unsigned, u2);
+          if (__ballot(wide && (ub & 0x08000800u) != 0u) != 0ull) {   // (wave-uniform) some lane: a slot outside the window
+            const bool fullc = ((fullm >> ch) & 1u) != 0u;
+            const bool v0 = fullc || ((vmask >> (2 * i)) & 1u) != 0u, v1 = fullc || ((vmask >> (2 * i + 1)) & 1u) != 0u;
+            const bool t0 = wide && v0 && (ub & 0x0800u) != 0u, t1 = wide && v1 && ub >= 0x08000000u;
+            const bool a0 = push(t0, (int)(short)(KP[i] & 0xffffu), (unsigned)grp), a1 = push(t1, (int)(short)(KP[i] >> 16), (unsigned)grp);
+            if (a0 || a1) cht |= 1u << ch;
+            tmask |= (t0 ? 1u << (2 * i) : 0u) | (t1 ? 1u << (2 * i + 1) : 0u);
+            ntl[grp] += (t0 ? 1 : 0) + (t1 ? 1 : 0);
+          }
+        }
+        if constexpr (DTYPE == 1) {
+          // a tail slot entered the sums as 1 024 (u = 2 048), an empty slot as its group's first key does
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            int held = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) held += ((anym >> (4 * g + c)) & 1u) ? 4 : 0;
+            const int de = (int)min((unsigned)(kf[g] - base) , (unsigned)kCntWindow) - kCntWindow / 2, ne = held - nv[g];
+            j1[g] -= (kCntWindow / 2) * ntl[g] + de * ne;
+            j2[g] -= (kCntWindow / 2) * (kCntWindow / 2) * ntl[g] + de * de * ne;
+          }
+        }
+        // the chunks that lost a sample are not "full" any more: their slots get validity bits, the tail slots lose theirs
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) if (((cht >> ch) & 1u) && ((fullm >> ch) & 1u)) vmask |= 0xfu << (4 * ch);
+        fullm &= ~cht;
+        vmask &= ~tmask;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (wide) {
+          if constexpr (DTYPE == 1) { i1[0] = j1[0]; i1[1] = j1[1]; i2[0] = j2[0]; i2[1] = j2[1]; kfirst[0] = cref; kfirst[1] = cref; }
+          fit = listed <= kCntTail;
+        }
+        // lane gl < listed holds tail sample gl; every one against every other: earlier copies, distinct values between it and the window
+        const bool tv = wide && fit && gl < listed;
+        const unsigned te = tv ? tlist[gl] : 0u;
+        const int tk = (int)(short)(te & 0xffffu);
+        const bool tlow = tk < base;
+        int tp = 0, dr = 0;
+        const int maxn = max(max(__builtin_amdgcn_readlane(wide && fit ? listed : 0, 0), __builtin_amdgcn_readlane(wide && fit ? listed : 0, 16)),
+                             max(__builtin_amdgcn_readlane(wide && fit ? listed : 0, 32), __builtin_amdgcn_readlane(wide && fit ? listed : 0, 48)));
+#pragma unroll 1
+        for (int j = 0; j < maxn; ++j) {
+          const int mine = (tk & 0xffff) | (tp == 0 ? 0x10000 : 0);                   // (lane j's count of earlier copies is complete by round j)
+          const int wj = __builtin_amdgcn_ds_bpermute(((lane & ~(LG - 1)) + j) << 2, mine);
+          const int kj = (int)(short)(wj & 0xffff);
+          const bool vj = tv && j < listed, firstj = vj && (wj & 0x10000) != 0, lowj = kj < base;
+          tp += (vj && kj == tk && j < gl) ? 1 : 0;
+          dr += (firstj && lowj == tlow && (tlow ? kj > tk : kj < tk)) ? 1 : 0;
+        }
+        // the distinct tail values on either side of the window (first copies), per position
+        const unsigned fl = (unsigned)(__ballot(tv && tp == 0 && tlow) >> (lane & 48)) & 0xffffu, fh = (unsigned)(__ballot(tv && tp == 0 && !tlow) >> (lane & 48)) & 0xffffu;
+        const int ndl = (int)__popc(fl), ndh = (int)__popc(fh);
+        if (wide && fit) {
+          // what stayed spans [in_min, in_max] (inside the window); the distinct tail values sit just outside it, in order
+          const int umin = cnt_allmin_i32((int)min(UMN.x, UMN.y));
+          const bool none = umin >= kCntWindow;                                         // (no sample inside the window at all: the tail keys sit around cref)
+          const int in_min = none ? cref : base + umin, in_max = none ? cref - 1 : base + (kCntWindow - 1) - cnt_allmin_i32((int)min(UMX.x, UMX.y));
+          kmin = in_min - ndl; kmax = in_max + ndh;
+          fit = kmin >= -32768 && kmax <= 32767;                                       // (the remapped keys are int16 keys; the range is tested below)
+          xk = tlow ? in_min - 1 - dr : in_max + 1 + dr;
+          xg = (te >> 16) & 1u;
+          xv = tv && fit;
+          if constexpr (DTYPE == 1) {                      // the sample's true terms about cref (|d| < 2^16: d^2 as a double)
+            const int d = tk - cref;
+            xd[0] = (xv && xg == 0u) ? d : 0; xd[1] = (xv && xg != 0u) ? d : 0;
+            xdd[0] = (double)xd[0] * (double)xd[0]; xdd[1] = (double)xd[1] * (double)xd[1];
+          }
+        }
+        have_x = __ballot(xv) != 0ull;
+      }
+    }
     // ---- the moments are final here: written at once (a position that turns out not to fit is written again by rank_hist_kernel)
     if constexpr (DTYPE != 2) {
       double mean[2], m2[2];
@@ -299,7 +468,8 @@ void rank_count_kernel(RankStatsArgs args) {
           const double K = (double)xfirst2[g];
           mean[g] = K + s1 * rn; m2[g] = s2 - s1 * s1 * rn;
         } else {
-          const double S1 = (double)cnt_allsum_i32(i1[g]), S2 = (double)cnt_allsum_i32(i2[g]);   // exact: |S1| < 2^20, S2 < 2^31 (fitting positions)
+          double S1 = (double)cnt_allsum_i32(i1[g] + xd[g]), S2 = (double)cnt_allsum_i32(i2[g]);   // exact: |S1| < 2^21, S2 < 2^31 (fitting positions)
+          if (have_x) S2 += seg_allsum_f64<LG>(xdd[g]);                                          // (wave-uniform) + the tail samples' squares
           mean[g] = ((double)kfirst[g] + S1 * rn) * 1e-3;
           m2[g] = __fma_rn(dn, S2, -S1 * S1) * rn * 1e-6;                                       // (n S2 - S1^2: exact integers)
         }
@@ -310,8 +480,7 @@ void rank_count_kernel(RankStatsArgs args) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- the window: the position's smallest key is value 0; the lane blocks are as long as the widest position of the wave needs
-    const int kmin = cnt_allmin_i32(min((int)MN.x, (int)MN.y)), kmax = cnt_allmax_i32(max((int)MX.x, (int)MX.y));
+    // ---- the lane blocks are as long as the widest position of the wave needs
     {
       const unsigned long long bm = __ballot(bad);
       const bool pos_bad = ((unsigned)(bm >> (lane & 48)) & 0xffffu) != 0u;
@@ -334,6 +503,7 @@ void rank_count_kernel(RankStatsArgs args) {
     // the two groups' counts of value v, sum_v (a + b)^3 = sum_{e in group 1} (a^2 + 3 a b + 3 b^2)(e) + sum_v b^3, the last term
     // from the arrival numbers the counting adds of group 2 return: sum_{e in group 2} (3 p^2 + 3 p + 1), p = earlier copies.
     unsigned mws = 0u, saa = 0u, sab = 0u, sbb = 0u, b3 = 0u;
+    unsigned AX = 0u, xA = 0u, xA1 = 0u, xnum0 = 0u, xnum1 = 0u;   // the extra slot: its table address, A[v], A[v-1], its two KS candidates
     CntU2 BEST = {0, 0};
     double dmax = 0.0;
     constexpr int NP = NS / 2;                           // pairs of group 1's slots
@@ -367,6 +537,10 @@ void rank_count_kernel(RankStatsArgs args) {
           }
         };
         if ((fullm >> ch) & 1u) addr(std::true_type{}); else addr(std::false_type{});
+      }
+      if (have_x) {                                        // (wave-uniform) the extra slot: a tail sample under its remapped key
+        const unsigned u = (unsigned)(xk - kmin) & 0xffffu;
+        AX = xv ? tb + 15u + u + ((__umul24(u, bdiv) >> 22) << 4) : tb;
       }
       // (made opaque after every phase: otherwise the compiler keeps unpacked copies alive beside the packed registers)
 #pragma unroll
@@ -402,6 +576,15 @@ void rank_count_kernel(RankStatsArgs args) {
             }
           };
           if ((fullm >> ch) & 1u) add4(std::true_type{}); else add4(std::false_type{});
+        }
+        if (have_x) {                                      // (wave-uniform) the tail samples of this group, one per lane
+          const unsigned a1 = AX + 1u;
+          const unsigned old = __hip_atomic_fetch_add((CntLdsU32)(uintptr_t)(a1 & ~3u), (xv && xg == (unsigned)g) ? 1u << ((a1 & 3u) * 8u) : 0u,
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (g == 1) {
+            const unsigned pcnt = (xv && xg != 0u) ? (old >> ((a1 & 3u) * 8u)) & 0xffu : 0u;
+            b3 += __umul24(pcnt, pcnt) + pcnt;
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -465,6 +648,7 @@ void rank_count_kernel(RankStatsArgs args) {
         for (int h = 0; h < 2; ++h) { CAp[2 * ch + h] = c0[h]; CA1p[2 * ch + h] = c1[h]; }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (have_x) { const CntLdsU8 px = (CntLdsU8)(uintptr_t)AX; xA1 = px[0]; xA = px[1]; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -503,6 +687,17 @@ void rank_count_kernel(RankStatsArgs args) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (have_x) {                                        // (wave-uniform) group 1's tail samples: the same terms, unpacked
+        const CntLdsU8 px = (CntLdsU8)(uintptr_t)AX;
+        const bool g1 = xv && xg == 0u;
+        const unsigned cB1 = g1 ? px[0] : 0u, cB = g1 ? px[1] : 0u, cA1 = g1 ? xA1 : 0u, cA = g1 ? xA : 0u;
+        const unsigned ta = cA - cA1, tbq = cB - cB1;
+        saa += ta * ta; sab += ta * tbq; sbb += tbq * tbq; mws += cB + cB1;
+        const int x0 = (int)(cA * (unsigned)n1) - (int)(cB * (unsigned)n0), x1 = (int)(cA1 * (unsigned)n1) - (int)(cB1 * (unsigned)n0);
+        xnum0 = (unsigned)(x0 < 0 ? -x0 : x0); xnum1 = (unsigned)(x1 < 0 ? -x1 : x1);
+        const unsigned short xb = (unsigned short)max(xnum0, xnum1);
+        BEST = __builtin_elementwise_max(BEST, CntU2{xb, xb});
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -533,6 +728,18 @@ void rank_count_kernel(RankStatsArgs args) {
           dmax = hit ? fmax(dmax, d) : dmax;
         }
         if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (have_x) {                                        // (wave-uniform) ... and at group 1's tail samples
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const bool hit = fit && xv && xg == 0u && (e ? xnum1 : xnum0) == best && best != 0u;
+          if (__ballot(hit) != 0ull) {
+            const int cA = (int)(e ? xA1 : xA);
+            const int cB = (int)((CntLdsU8)(uintptr_t)AX)[e ? 0 : 1];
+            const double d = fabs(hist_exact_quot(cA, dn0, r0) - hist_exact_quot(cB, dn1, r1));
+            dmax = hit ? fmax(dmax, d) : dmax;
+          }
+        }
       }
 #endif
       dmax = seg_allmax_f64<LG>(dmax);

@@ -523,6 +523,78 @@ def test_counting_form_edges(nm, dtype):
     H.assert_close_p(sub['t_p'][1:], got['t_p'][lo + 1:], 1e-9, 't_p')
 
 
+@pytest.mark.parametrize('dtype', ['i16', 'f32', 'f64'])
+def test_counting_form_outliers_vs_oracle(nm, dtype):
+    """rank_count.hpp's outlier path (round 6): samples further than 1 024 milli-units from the mean of the position's keys leave the
+    table for a list and come back under remapped keys (order and ties kept).  Positions with 1, 2, 15, 16 and 17 such samples
+    below / above / on both sides, in group 1 / group 2 / both; the same outlier value several times and in both groups; outliers at
+    the ends of the int16 domain; an outlier as a group's first sample; two clusters 3 units apart (every sample an outlier:
+    handed on); then random contamination at 1 / 10 / 30 per mille.  Every number against the oracle; the form keeps every position
+    with at most 16 tail samples (nmod_last_dispatch_stats); the sorting form alone gives the same integers"""
+    import oracle_c
+    L = nm._lib
+    f64 = L.FLAG_NO_HOST_NARROW if dtype == 'f64' else 0
+    rng = np.random.default_rng(zlib.crc32(('cnt-outliers' + dtype).encode()))
+    rows0, rows1, kept = [], [], []
+
+    def add(a, b, keep=True):
+        rows0.append(np.asarray(a, dtype=np.int64)); rows1.append(np.asarray(b, dtype=np.int64)); kept.append(keep)
+
+    def ev(n, lev=0, s=150):
+        return lev + np.clip(np.rint(s * rng.normal(0, 1, n)), -600, 600).astype(np.int64)
+
+    def out(n, side, lev=0):
+        lo = rng.integers(-5000, lev - 1300, n) if lev - 1300 > -5000 else np.full(n, -5000)
+        hi = rng.integers(lev + 1300, 5001, n) if lev + 1300 < 5000 else np.full(n, 5000)
+        return lo if side < 0 else hi if side > 0 else np.where(rng.random(n) < 0.5, lo, hi)
+    for _ in range(700):                                     # the bulk: ordinary event-like positions (the probe wants 7 of 8 sampled ones to fit)
+        lev = int(rng.integers(-3000, 3000)); add(ev(int(rng.integers(130, 256)), lev), ev(int(rng.integers(130, 256)), lev))
+    edge_at = len(rows0)
+    for n_out in (1, 2, 15, 16, 17):
+        for side in (-1, 1, 0):
+            lev = int(rng.integers(-2500, 2500))
+            add(np.r_[ev(200 - n_out, lev), out(n_out, side, lev)], ev(180, lev), n_out <= 16)            # in group 1 (the group that is looked up)
+            add(ev(180, lev), np.r_[out(n_out, side, lev), ev(200 - n_out, lev)], n_out <= 16)            # in group 2, first in its row
+            if n_out <= 8:
+                add(np.r_[out(n_out, side, lev), ev(150, lev)], np.r_[ev(150, lev), out(n_out, -side, lev)])   # both groups (first sample of group 1)
+    add(np.r_[ev(190), [4000] * 6, [-4000] * 2], np.r_[ev(190), [4000] * 3, [-4000] * 4, 4001])          # the same outlier value several times, in both groups
+    add(np.r_[ev(196), [32767, 32767, -32768, -32767]], np.r_[ev(198), [32767, -32768]])                  # the ends of the int16 domain
+    add(np.r_[ev(199, 31000), [-32768]], ev(200, 31000)); add(np.r_[ev(199, -31000), [32767]], ev(200, -31000))   # a window clamped at the domain's end
+    add(np.r_[ev(100, -1500, 80), ev(100, 1500, 80)], np.r_[ev(100, -1500, 80), ev(100, 1500, 80)], False)        # two clusters: every sample is far from the mean
+    add(np.r_[ev(250), out(5, 0)], np.r_[ev(250), out(5, 0)])                                              # 255 samples per group with outliers
+    add(np.r_[[0] * 100, [1] * 100, [3000] * 4], np.r_[[0] * 60, [1] * 140, [3000] * 2, [-3000] * 2])      # heavy ties inside the window, tied outliers
+    for frac, npos_f in ((0.001, 60), (0.01, 60), (0.03, 30)):
+        for _ in range(npos_f):
+            lev = int(rng.integers(-3000, 3000)); a, b = ev(int(rng.integers(130, 256)), lev), ev(int(rng.integers(130, 256)), lev)
+            n_o = 0
+            for v in (a, b):
+                hit = rng.random(len(v)) < frac
+                v[hit] = rng.integers(-5000, 5001, int(hit.sum())); n_o += int((np.abs(v - lev) > 1300).sum())
+            add(a, b, None)                                  # (kept unless more than 16 of them ended up far away: decided by the library's own centre)
+    P = len(rows0)
+    off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum([len(r) for r in rows0])
+    off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum([len(r) for r in rows1])
+    k0 = np.concatenate(rows0).astype(np.int16); k1 = np.concatenate(rows1).astype(np.int16)
+    rid = np.zeros(P, np.int32)
+    s0, s1 = _as_dtype(k0, dtype), _as_dtype(k1, dtype)
+    exp = oracle_c.detect_batch(s0 if dtype == 'f32' else k0, off0, s1 if dtype == 'f32' else k1, off1, rid, 0, 2.0, 'fisher', tests=7)
+    assert L.load().nmod_host_pipeline_config(1 << 30, 0, 0, 0) == 0          # (one chunk: one probe over the whole batch)
+    try:
+        got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=f64)
+        st = L.last_dispatch_stats()
+        srt = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=f64 | L.FLAG_NO_COUNTING)
+    finally:
+        assert L.load().nmod_host_pipeline_config(0, 0, 0, 0) == 0
+    H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
+    assert np.array_equal(got['status'], exp['status'])
+    for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p'):
+        assert np.array_equal(srt[k], got[k]), k
+    H.assert_close_p(srt['t_p'], got['t_p'], 1e-9, 't_p')
+    must_reject = kept.count(False)
+    assert st['skipped'] == 0 and st['count_tried'] == P and st['rank_count'] + st['count_rejected'] == P, st
+    assert must_reject <= st['count_rejected'] <= must_reject + 12 and st['rank_count'] >= P - must_reject - 12, (must_reject, st)
+
+
 def _event_rows(rng, sizes0, sizes1, spread, shift_every=5):
     """int16 event-like rows: a level per position, reads spread around it, group 2 shifted at every shift_every-th position"""
     P = len(sizes0)

@@ -34,7 +34,9 @@ CONFIGS = [('ks_f32', []), ('all_f32', ['--config', 'alltests']), ('ks_i16', ['-
            ('all_i16', ['--config', 'alltests', '--dtype', 'i16']), ('ks_f32_realties', ['--ties', 'real']),
            ('ks_f32_rationald', ['--rational-d']),
            ('all_f32_spread200', ['--config', 'alltests', '--spread', '200']), ('all_i16_spread200', ['--config', 'alltests', '--spread', '200', '--dtype', 'i16']),
-           ('ks_f32_spread200', ['--spread', '200']), ('ks_i16_spread200', ['--spread', '200', '--dtype', 'i16'])]
+           ('ks_f32_spread200', ['--spread', '200']), ('ks_i16_spread200', ['--spread', '200', '--dtype', 'i16']),
+           # round 6: event-like rows with 10 per mille outliers (mis-segmented reads over +-5 units)
+           ('all_i16_spread200_outl10', ['--config', 'alltests', '--spread', '200', '--dtype', 'i16', '--outliers', '10'])]
 if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minutes per pass): only on request
     CONFIGS += [('ragged_all_f32', ['--config', 'ragged', '--all-tests', '--steps', '3', '--warmup', '1']),
                 ('ragged_all_f32_realties', ['--config', 'ragged', '--all-tests', '--ties', 'real', '--steps', '3', '--warmup', '1']),
@@ -47,7 +49,11 @@ if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minut
                 ('chr20_all_f32_spread200', ['--config', 'chr20', '--all-tests', '--spread', '200', '--steps', '3', '--warmup', '1']),
                 ('ragged_ks_i16_spread200', ['--config', 'ragged', '--dtype', 'i16', '--spread', '200', '--steps', '3', '--warmup', '1']),
                 ('chr20_ks_i16_spread200', ['--config', 'chr20', '--dtype', 'i16', '--spread', '200', '--steps', '3', '--warmup', '1']),
-                ('chr20_ks_f32_spread200', ['--config', 'chr20', '--spread', '200', '--steps', '3', '--warmup', '1'])]
+                ('chr20_ks_f32_spread200', ['--config', 'chr20', '--spread', '200', '--steps', '3', '--warmup', '1']),
+                ('ragged_all_i16_spread200_outl1', ['--config', 'ragged', '--all-tests', '--dtype', 'i16', '--spread', '200', '--outliers', '1', '--steps', '3', '--warmup', '1']),
+                ('ragged_all_i16_spread200_outl10', ['--config', 'ragged', '--all-tests', '--dtype', 'i16', '--spread', '200', '--outliers', '10', '--steps', '3', '--warmup', '1']),
+                ('ragged_all_f32_spread200_outl10', ['--config', 'ragged', '--all-tests', '--spread', '200', '--outliers', '10', '--steps', '3', '--warmup', '1']),
+                ('chr20_all_i16_spread200_outl10', ['--config', 'chr20', '--all-tests', '--dtype', 'i16', '--spread', '200', '--outliers', '10', '--steps', '3', '--warmup', '1'])]
 if len(sys.argv) > 2:                      # python3 tools/profile_round.py r3 ks_f32,all_f32
     CONFIGS = [c for c in CONFIGS if c[0] in sys.argv[2].split(',')]
 K1_NAMES = ('ks_rank_kernel', 'rank_hist_kernel', 'rank_pair_kernel', 'big_rank_kernel', 'big_hist_kernel', 'rank_count_kernel', 'rank_count_wide_kernel')
@@ -62,9 +68,15 @@ def run(cmd, **kw):
     return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, **kw)
 
 
-def bench_line(extra, steps=20, warmup=5):
-    r = run(['python3', BENCH, '--steps', str(steps), '--warmup', str(warmup)] + extra)      # (a later --steps in `extra` wins)
+SIDE = '/tmp/prof_side.json'
+
+
+def bench_line(extra, steps=20, warmup=5, keep_side=None):
+    """the LAST stdout line (the compact record); the verbose record + side legs (bench.py --side-file) go to `keep_side`"""
+    r = run(['python3', BENCH, '--steps', str(steps), '--warmup', str(warmup), '--side-file', SIDE] + extra)      # (a later --steps in `extra` wins)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    if keep_side and os.path.exists(SIDE):
+        shutil.copy(SIDE, keep_side)
     return json.loads(lines[-1]) if lines else {'error': r.stderr[-2000:]}
 
 
@@ -81,12 +93,13 @@ def k1_rows(pattern, col):
 
 traffic = {}
 for cfg, extra in CONFIGS:
-    line = bench_line(extra + (['--no-cpu', '--no-side', '--no-host-path'] if cfg != 'ks_f32' else []))   # the headline: the full default line
+    line = bench_line(extra + (['--no-cpu', '--no-side', '--no-host-path'] if cfg != 'ks_f32' else []),     # the headline: the full default line ...
+                      keep_side=os.path.join(OUT, '%s_bench_side_%s.json' % (TAG, cfg)) if cfg == 'ks_f32' else None)   # ... and its side file
     json.dump(line, open(os.path.join(OUT, '%s_bench_%s.json' % (TAG, cfg)), 'w'))
     # kernel trace + stats
     d = '/tmp/prof_%s_trace' % cfg
     shutil.rmtree(d, ignore_errors=True)
-    r = run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', 'python3', BENCH, '--steps', '10', '--warmup', '3', '--no-cpu', '--no-side', '--no-host-path'] + extra)
+    r = run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', 'python3', BENCH, '--steps', '10', '--warmup', '3', '--no-cpu', '--no-side', '--no-host-path', '--side-file', SIDE] + extra)
     under = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     for f in glob.glob(d + '/*/*kernel_stats.csv'):
         shutil.copy(f, os.path.join(OUT, '%s_%s_kernel_stats.csv' % (TAG, cfg)))
@@ -99,7 +112,7 @@ for cfg, extra in CONFIGS:
     for gi, group in enumerate(PMC_GROUPS):
         d = '/tmp/prof_%s_pmc%d' % (cfg, gi)
         shutil.rmtree(d, ignore_errors=True)
-        run(['rocprofv3', '--pmc'] + group + ['--output-format', 'csv', '-d', d, '--', 'python3', BENCH] + extra + ['--steps', '2', '--warmup', '1', '--no-cpu', '--no-side', '--no-host-path'])
+        run(['rocprofv3', '--pmc'] + group + ['--output-format', 'csv', '-d', d, '--', 'python3', BENCH] + extra + ['--steps', '2', '--warmup', '1', '--no-cpu', '--no-side', '--no-host-path', '--side-file', SIDE])
         vals, meta = k1_rows(d + '/*/*counter_collection.csv', 'Counter_Name')
         # per bench step: 4 passes of the hot path run under the profiler (verify, warm-up, 2 timed); a ragged pass is
         # many size-class launches, so the counters are summed over the K1 kernels and divided by the passes

@@ -118,7 +118,10 @@ __global__ __launch_bounds__(1024) void cnt_probe_kernel(CntProbeArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nsamp = count < kCntProbeSamples ? count : kCntProbeSamples;
   for (int64_t j = wave; j < nsamp; j += 16) {
-    const int64_t li = (j * count) / nsamp;
+    // one position per stratum of count / nsamp list entries, at a pseudo-random place inside it (evenly strided samples alias
+    // with anything periodic in the batch: round 6 found half of them on the benchmark generator's planted positions)
+    const int64_t s_lo = (j * count) / nsamp, s_len = ((j + 1) * count) / nsamp - s_lo;
+    const int64_t li = s_lo + (int64_t)(((uint64_t)(j + 1) * 0x9E3779B97F4A7C15ull >> 20) % (uint64_t)(s_len > 0 ? s_len : 1));
     const int64_t pos = list ? (int64_t)list[li] : li;
     bool ok = true;
     int lo = 0x7fffffff, hi = (int)0x80000000;

@@ -81,7 +81,10 @@ __global__ __launch_bounds__(1024) void cnt_wide_probe_kernel(CntWideProbeArgs a
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nsamp = count < kCntProbeSamples ? count : kCntProbeSamples;
   for (int64_t j = wave; j < nsamp; j += 16) {
-    const int64_t li = (j * count) / nsamp;
+    // one position per stratum of count / nsamp list entries, at a pseudo-random place inside it (evenly strided samples alias
+    // with anything periodic in the batch: round 6 found half of them on the benchmark generator's planted positions)
+    const int64_t s_lo = (j * count) / nsamp, s_len = ((j + 1) * count) / nsamp - s_lo;
+    const int64_t li = s_lo + (int64_t)(((uint64_t)(j + 1) * 0x9E3779B97F4A7C15ull >> 20) % (uint64_t)(s_len > 0 ? s_len : 1));
     const int64_t pos = list ? (int64_t)list[li] : li;
     bool ok = true;
     int nn[2]; int64_t oo[2];
@@ -322,8 +325,8 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, int32_t* w
       }
     }
     fit = fit && __ballot(bad) == 0ull;
-    // the window: 2 048 values around a robust centre of S — its mid-range where S spans less than half a window (no outlier in S:
-    // the common case), else its mean, then the mean of its samples within 1 024 of that (one mis-segmented read among ~57 moves
+    // the window: 2 048 values around a robust centre of S — its mid-range where S spans less than three quarters of a window (no
+    // far outlier in S: the common case), else its mean, then the mean of its samples within 1 024 of that (one mis-segmented read among ~57 moves
     // the mean by ~90 milli-units and not the second estimate); samples of either group outside it are the position's tail
     // (header comment).  E = 1 << lgE entries per lane block.  (A window of 512 / 1 024 values
     // where S's range allowed it — a shorter clear and scan — was measured in round 5: event-like rows at sigma >= 0.1 never took
@@ -338,8 +341,8 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, int32_t* w
       for (int r = 1; r < RS; ++r) { kmx = max(kmx, ks[r]); kmn = min(kmn, ks[r]); }
       const unsigned P = cw_wave_max_pk_u16(((unsigned)(kmx + 32768) & 0xffffu) | ((unsigned)(32767 - kmn) << 16));   // (a float32 key out of range: `bad`)
       const int smax = (int)(P & 0xffffu) - 32768, smin = 32767 - (int)(P >> 16);
-      s_narrow = (smax - smin) < kCwWindow / 2;
-      centre = (smin + smax) >> 1;                         // S within 1 024 values: no outlier in it, the window sits on its mid-range
+      s_narrow = (smax - smin) < (kCwWindow * 3) / 4;
+      centre = (smin + smax) >> 1;                         // S within 1 536 values: the window on its mid-range holds all of S with >= 256 values to spare on either side
     }
     if (!s_narrow) {                                       // (wave-uniform) an outlier in S: its mean, then the mean of the samples within 1 024 of that
       int s1 = 0;
@@ -422,17 +425,22 @@ __device__ __forceinline__ void cw_segment(const RankStatsArgs& args, int32_t* w
         }
       };
       // ---- S
+      bool s_tail = false;
 #pragma unroll
       for (int r = 0; r < RS; ++r) {
         const bool have = r * 64 + lane < m;
         const unsigned u = (unsigned)(ks[r] - base);
         const bool in = have && u < (unsigned)W;
         inmask |= in ? (1u << r) : 0u;
-        tail_push(have && !in, ks[r], 0u);
+        s_tail = s_tail || (have && !in);
         const unsigned a_ = in ? entry(u) : tb + 4u;             // (no sample in the window: a zero word of block 0's pad; nothing is added, nothing comes back)
         if constexpr (KEEPA) addr[r] = a_;
         arrive(a_, 1u, in);
         if constexpr (RDT == 1 && !KS) { const int d = in ? ks[r] - c : 0; is1 += d; is2 += (unsigned)__mul24(d, d); }
+      }
+      if (__ballot(s_tail) != 0ull) {                        // (rare; wave-uniform) samples of S outside the window
+#pragma unroll
+        for (int r = 0; r < RS; ++r) tail_push(r * 64 + lane < m && (unsigned)(ks[r] - base) >= (unsigned)W, ks[r], 0u);
       }
 
       // ---- Q, streamed once

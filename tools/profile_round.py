@@ -36,6 +36,7 @@ CONFIGS = [('ks_f32', []), ('all_f32', ['--config', 'alltests']), ('ks_i16', ['-
            ('all_f32_spread200', ['--config', 'alltests', '--spread', '200']), ('all_i16_spread200', ['--config', 'alltests', '--spread', '200', '--dtype', 'i16']),
            ('ks_f32_spread200', ['--spread', '200']), ('ks_i16_spread200', ['--spread', '200', '--dtype', 'i16']),
            # round 6: event-like rows with 10 per mille outliers (mis-segmented reads over +-5 units)
+           ('all_i16_spread200_outl1', ['--config', 'alltests', '--spread', '200', '--dtype', 'i16', '--outliers', '1']),
            ('all_i16_spread200_outl10', ['--config', 'alltests', '--spread', '200', '--dtype', 'i16', '--outliers', '10'])]
 if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minutes per pass): only on request
     CONFIGS += [('ragged_all_f32', ['--config', 'ragged', '--all-tests', '--steps', '3', '--warmup', '1']),

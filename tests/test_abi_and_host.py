@@ -99,7 +99,8 @@ def test_dispatch_stats_without_a_call_and_form_flags():
     t = threading.Thread(target=fresh_thread); t.start(); t.join()
     assert out == {'rc': -1, 'pos': 0, 'null': -1}
     assert (L.FLAG_NO_COUNTING, L.FLAG_NO_COUNT_WIDE) == (4, 8)
-    prm = L.make_params(flags=16)
+    assert L.FLAG_NO_HOST_NARROW == 16
+    prm = L.make_params(flags=64)                             # (an unknown flag bit)
     assert lib.nmod_workspace_bytes(C.byref(prm), 10) > 0 and lib.nmod_detect_batch(C.byref(prm), 1, None, None, None, None, None, None, 0, None) == -1
     src = open(os.path.join(ROOT, 'nanomod_amd', 'csrc', 'nanomod_hip.hip')).read() + open(os.path.join(ROOT, 'nanomod_amd', 'csrc', 'rank_stats_inst.hip')).read()
     assert 'getenv("NMOD_NO_COUNT' not in src

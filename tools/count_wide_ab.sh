@@ -1,11 +1,11 @@
 #!/bin/bash
 # A/B of the counting form for any coverage (rank_count_wide.hpp) on one box: all tests on the ragged preset (configs[4], ~1 131 v ~57)
 # and on the chr20 shape (500 v 500), event-like rows (--spread S) and the unit-variance rows (S = 0), float32 and int16, with the
-# form (default) and without (NMOD_NO_COUNT_WIDE=1)
+# form (default) and without (NMOD_NO_COUNT_WIDE=1: bench.py turns the variable into NMOD_FLAG_NO_COUNT_WIDE; the library reads no environment)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
 for CFG in ${CONFIGS:-ragged chr20}; do
-  POS=$([ $CFG = ragged ] && echo 2000000 || echo 2000000)
+  POS=${POS:-2000000}
   for S in ${SPREADS:-200 0}; do
     for DT in ${DTYPES:-f32 i16}; do
       for OFF in 0 1; do

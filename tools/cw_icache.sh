@@ -1,4 +1,6 @@
 #!/bin/bash
+# tools/cw_icache.sh: instruction-cache and wait counters of rank_count_wide_kernel (separate --pmc passes) on the ragged preset and the
+# 500 v 500 shape, int16 event-like rows, per pass of 2 M positions (GPU box; prints to stdout)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
 for ARGS in "--config ragged --positions 2000000 --dtype i16 --spread 200" "--config chr20 --positions 2000000 --dtype i16 --spread 200"; do

@@ -781,6 +781,17 @@ def test_count_wide_outliers_vs_oracle(nm, dtype):
         add(np.r_[ev(big - 4, lev), [32767, 32767, -32768, -32767]], np.r_[ev(small - 2, lev), [32767, -32768]]); kept.append(True)  # the ends of the int16 domain
         add(np.r_[ev(big - 1, 30000), [-32768]], ev(small, 30000)); kept.append(True)                                               # a window clamped at the domain's end
         add(np.r_[ev(big - 1, -30000), [32767]], ev(small, -30000)); kept.append(True)
+    # the other register counts of the smaller group (128 / 256 / 1 024 samples: RS = 2, 4, 16 — the last one keeps no addresses in
+    # registers): a class each, clean positions and positions with 1 ... 20 outliers in either group
+    for big, small in ((1000, 100), (1000, 200), (1000, 1000)):
+        for i in range(48):
+            lev = int(rng.integers(-2500, 2500)); n_out = (0 if i < 32 else int(rng.integers(1, 21)))
+            a, b = ev(big, lev), ev(small, lev)
+            if n_out:
+                a[rng.choice(big, n_out, replace=False)] = out(n_out, 0, lev)
+                nb_ = min(n_out, small // 8)
+                b[rng.choice(small, nb_, replace=False)] = out(nb_, 0, lev)
+            add(a, b); kept.append(True)
     for frac, npos_f in ((0.001, 40), (0.01, 40), (0.05, 16)):   # random contamination of both groups
         for _ in range(npos_f):
             lev = int(rng.integers(-3000, 3000)); n0, n1 = int(rng.integers(700, 1400)), int(rng.integers(30, 65))

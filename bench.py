@@ -573,7 +573,7 @@ def rank_plan(args, world, rank):
             samples += (hi_h - lo_h) * (n0 + n1)
     k_tracks = 8 if all_tests else 4
     dev_bytes = (samples * sb + (16 * with_halo if csr else 0) + 4 * with_halo          # rows, offsets, run ids
-                 + 90 * (B + 2 * NB) + 4096                                              # workspace (one block at a time; nmod_workspace_bytes)
+                 + 92 * (B + 2 * NB) + 8192                                              # workspace (one block at a time; nmod_workspace_bytes)
                  + (8 * k_tracks + 1) * with_halo                                        # result tracks + status
                  + 2 * 8 * total)                                                        # gathered ks_p / comb_p (full length on every rank)
     return {'positions_total': total, 'positions_own': own, 'positions_with_halo': with_halo, 'block': B, 'chunks': chunks,

@@ -10,12 +10,79 @@
  *     out:  writable C-contiguous float64 buffer with room for all of them (ValueError otherwise)
  *   filter_coverage(norm, base, min_cov), join_strand(norm0, norm1, base0, base1): mfilter_coverage's inner loop and
  *     mtest2's loop header for one (chrom, strand), one C pass over the dicts each (see below)
+ *   join_strand_plan(norm0, norm1, base0, base1) + copy_plan(plan, out0, start0, out1, start1) (round 6): the same join in two
+ *     steps — first the positions and sizes of every (chrom, strand), then the rows of all of them straight into ONE pair of CSR
+ *     arrays (no per-strand arrays to concatenate: that copy was 0.17 s of build_csr's 0.23 s at 460 000 x 200 v 200), as float64
+ *     or — where every sample is k / 1000.0 with |k| <= 32 767, what stored events are — narrowed to int16 milli-units on the way
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <string.h>
 #define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
 #include <numpy/arrayobject.h>
+#include <math.h>
+
+/* x == k / 1000.0 with |k| <= 32 767?  Division-free: q = fl(k / 1000) by one Newton step on k * fl(1 / 1000), correctly rounded
+ * for every such k (the same test as csrc/host_pipeline.hpp's narrow_f64_to_i16; tests/test_abi_and_host.py checks both exhaustively) */
+static inline int narrow_one(double x, short* out) {
+  if (!(fabs(x) <= 33.0)) return 0;
+  const double k = nearbyint(x * 1000.0);
+  const double q0 = k * 0.001;
+  const double q = fma(fma(-q0, 1000.0, k), 0.001, q0);
+  *out = (short)(int)k;
+  return q == x && fabs(k) <= 32767.0;
+}
+static int narrow_scalar(const double* src, short* dst, Py_ssize_t n) {
+  for (Py_ssize_t i = 0; i < n; ++i) if (!narrow_one(src[i], dst + i)) return 0;
+  return 1;
+}
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2,fma"))) static int narrow_avx2(const double* src, short* dst, Py_ssize_t n) {
+  const __m256d k1000 = _mm256_set1_pd(1000.0), r = _mm256_set1_pd(0.001), lim = _mm256_set1_pd(32767.0);
+  const __m256d absmask = _mm256_castsi256_pd(_mm256_set1_epi64x(0x7fffffffffffffffll));
+  __m256d good = _mm256_castsi256_pd(_mm256_set1_epi64x(-1));
+  Py_ssize_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    __m128i kk[2];
+    for (int h = 0; h < 2; ++h) {
+      const __m256d x = _mm256_loadu_pd(src + i + 4 * h);
+      const __m256d k = _mm256_round_pd(_mm256_mul_pd(x, k1000), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+      const __m256d q0 = _mm256_mul_pd(k, r);
+      const __m256d q = _mm256_fmadd_pd(_mm256_fnmadd_pd(q0, k1000, k), r, q0);
+      good = _mm256_and_pd(good, _mm256_and_pd(_mm256_cmp_pd(q, x, _CMP_EQ_OQ), _mm256_cmp_pd(_mm256_and_pd(k, absmask), lim, _CMP_LE_OQ)));
+      kk[h] = _mm256_cvtpd_epi32(k);
+    }
+    _mm_storeu_si128((__m128i*)(dst + i), _mm_packs_epi32(kk[0], kk[1]));
+  }
+  if (i < n) {                                           /* the last < 8 samples: the same vector code on a zero-padded copy (rows of ~20 samples
+                                                            would otherwise spend their time in libm's scalar fma) */
+    double pad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    short out8[8];
+    memcpy(pad, src + i, (size_t)(n - i) * 8);
+    __m128i kk[2];
+    for (int h = 0; h < 2; ++h) {
+      const __m256d x = _mm256_loadu_pd(pad + 4 * h);
+      const __m256d k = _mm256_round_pd(_mm256_mul_pd(x, k1000), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+      const __m256d q0 = _mm256_mul_pd(k, r);
+      const __m256d q = _mm256_fmadd_pd(_mm256_fnmadd_pd(q0, k1000, k), r, q0);
+      good = _mm256_and_pd(good, _mm256_and_pd(_mm256_cmp_pd(q, x, _CMP_EQ_OQ), _mm256_cmp_pd(_mm256_and_pd(k, absmask), lim, _CMP_LE_OQ)));
+      kk[h] = _mm256_cvtpd_epi32(k);
+    }
+    _mm_storeu_si128((__m128i*)out8, _mm_packs_epi32(kk[0], kk[1]));
+    memcpy(dst + i, out8, (size_t)(n - i) * 2);
+  }
+  return _mm256_movemask_pd(good) == 0xf;
+}
+#endif
+static int narrow_row(const double* src, short* dst, Py_ssize_t n) {
+#if defined(__x86_64__)
+  static int have = -1;
+  if (have < 0) have = (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) ? 1 : 0;
+  if (have) return narrow_avx2(src, dst, n);
+#endif
+  return narrow_scalar(src, dst, n);
+}
 
 static int put_generic(PyObject* row, double* dst, Py_ssize_t room, Py_ssize_t* wrote) {
   PyObject* fast = PySequence_Fast(row, "rows must be sequences");
@@ -170,6 +237,7 @@ static int copy_row(PyObject* row, double* dst, Py_ssize_t n) {
 typedef struct {
   const ent_t* e; const Py_ssize_t* ix; const int* nn; const long long* start; double* dst;
   Py_ssize_t lo, hi; unsigned char* slow;
+  short* dst16; volatile int* refused;       /* dst16 != NULL: the rows are narrowed to int16 milli-units; *refused = 1 when a sample is not one */
 } copy_job_t;
 
 static void* copy_worker(void* arg) {
@@ -182,8 +250,31 @@ static void* copy_worker(void* arg) {
       else if (PyArray_Check(o)) __builtin_prefetch(PyArray_DATA((PyArrayObject*)o));
     }
     PyObject* row = jb->e[jb->ix[j]].row;
-    double* d = jb->dst + jb->start[j];
     const int n = jb->nn[j];
+    if (jb->dst16) {                                       /* narrowing copy */
+      if (*jb->refused) return NULL;
+      short* d16 = jb->dst16 + jb->start[j];
+      if (PyArray_Check(row) && PyArray_TYPE((PyArrayObject*)row) == NPY_DOUBLE && PyArray_IS_C_CONTIGUOUS((PyArrayObject*)row) &&
+          PyArray_NDIM((PyArrayObject*)row) == 1 && PyArray_DIM((PyArrayObject*)row, 0) == n) {
+        if (!narrow_row((const double*)PyArray_DATA((PyArrayObject*)row), d16, n)) { *jb->refused = 1; return NULL; }
+      } else if (PyList_CheckExact(row) && PyList_GET_SIZE(row) == n) {
+        PyObject** items = ((PyListObject*)row)->ob_item;
+        double buf[256];
+        for (int i0 = 0; i0 < n && !jb->slow[j]; i0 += 256) {       /* 256 values at a time through the vector code */
+          const int m = n - i0 < 256 ? n - i0 : 256;
+          for (int i = 0; i < m; ++i) {
+            PyObject* it = items[i0 + i];
+            if (!PyFloat_Check(it)) { jb->slow[j] = 1; break; }
+            buf[i] = PyFloat_AS_DOUBLE(it);
+          }
+          if (!jb->slow[j] && !narrow_row(buf, d16 + i0, m)) { *jb->refused = 1; return NULL; }
+        }
+      } else {
+        jb->slow[j] = 1;
+      }
+      continue;
+    }
+    double* d = jb->dst + jb->start[j];
     if (PyArray_Check(row) && PyArray_TYPE((PyArrayObject*)row) == NPY_DOUBLE && PyArray_IS_C_CONTIGUOUS((PyArrayObject*)row) &&
         PyArray_NDIM((PyArrayObject*)row) == 1 && PyArray_DIM((PyArrayObject*)row, 0) == n) {
       memcpy(d, PyArray_DATA((PyArrayObject*)row), (size_t)n * 8);
@@ -213,8 +304,10 @@ static int host_threads(void) {
   return t < 1 ? 1 : (t > 16 ? 16 : t);
 }
 
-/* rows of one group -> dst (CSR order); 0 or -1 with an exception set */
-static int copy_rows(const ent_t* e, const Py_ssize_t* ix, const int* nn, Py_ssize_t n, double* dst) {
+/* rows of one group -> dst (CSR order; dst16 != NULL: narrowed to int16 milli-units instead); 0, 1 = a sample refused the narrowing
+ * (dst16 is then unspecified), or -1 with an exception set */
+static int copy_rows(const ent_t* e, const Py_ssize_t* ix, const int* nn, Py_ssize_t n, double* dst, short* dst16) {
+  volatile int refused = 0;
   long long* start = (long long*)malloc((size_t)(n ? n : 1) * sizeof(long long));
   unsigned char* slow = (unsigned char*)calloc((size_t)(n ? n : 1), 1);
   if (!start || !slow) { free(start); free(slow); PyErr_NoMemory(); return -1; }
@@ -226,17 +319,25 @@ static int copy_rows(const ent_t* e, const Py_ssize_t* ix, const int* nn, Py_ssi
   long long per = at / T + 1, acc = 0; Py_ssize_t lo = 0; int used = 0;
   for (Py_ssize_t j = 0; j < n && used < T - 1; ++j) {           /* ranges of about equal sample counts */
     acc += nn[j];
-    if (acc >= per) { jobs[used] = (copy_job_t){e, ix, nn, start, dst, lo, j + 1, slow}; lo = j + 1; acc = 0; ++used; }
+    if (acc >= per) { jobs[used] = (copy_job_t){e, ix, nn, start, dst, lo, j + 1, slow, dst16, &refused}; lo = j + 1; acc = 0; ++used; }
   }
-  jobs[used] = (copy_job_t){e, ix, nn, start, dst, lo, n, slow}; ++used;
+  jobs[used] = (copy_job_t){e, ix, nn, start, dst, lo, n, slow, dst16, &refused}; ++used;
   for (int t = 1; t < used; ++t) started[t] = pthread_create(&th[t], NULL, copy_worker, &jobs[t]) == 0;
   copy_worker(&jobs[0]);
   for (int t = 1; t < used; ++t) { if (started[t]) pthread_join(th[t], NULL); else copy_worker(&jobs[t]); }
   int rc = 0;
-  for (Py_ssize_t j = 0; j < n && rc == 0; ++j)
-    if (slow[j]) rc = copy_row(e[ix[j]].row, dst + start[j], nn[j]);      /* under the GIL: sequence protocol, float() */
-  free(start); free(slow);
-  return rc;
+  double* tmp = NULL;
+  for (Py_ssize_t j = 0; j < n && rc == 0 && !refused; ++j) {
+    if (!slow[j]) continue;                                /* under the GIL: sequence protocol, float() */
+    if (!dst16) { rc = copy_row(e[ix[j]].row, dst + start[j], nn[j]); continue; }
+    double* t2 = (double*)realloc(tmp, (size_t)(nn[j] ? nn[j] : 1) * 8);
+    if (!t2) { PyErr_NoMemory(); rc = -1; break; }
+    tmp = t2;
+    rc = copy_row(e[ix[j]].row, tmp, nn[j]);
+    if (rc == 0 && !narrow_scalar(tmp, dst16 + start[j], nn[j])) refused = 1;
+  }
+  free(tmp); free(start); free(slow);
+  return rc < 0 ? -1 : (refused ? 1 : 0);
 }
 
 /* join_strand(norm0, norm1, base0, base1) -> (pos int64[n], n0 int32[n], n1 int32[n], sig0 float64[sum n0], sig1 float64[sum n1],
@@ -244,9 +345,19 @@ static int copy_rows(const ent_t* e, const Py_ssize_t* ix, const int* nn, Py_ssi
  *                                             base_codes uint32[n]: the code point of a one-character base, else 0)
  * The loop header of mtest2 for one (chrom, strand) (myDetect.py:427-436): the positions both datasets hold, ascending, their
  * rows flattened into two CSR sample arrays, and the indices where the two datasets disagree about the base (:432-434). */
-static PyObject* join_strand(PyObject* self, PyObject* args) {
+/* what join_strand_plan leaves for copy_plan: the joined entries of one (chrom, strand) — rows BORROWED from the two dicts, which the
+ * plan keeps alive (the caller must not change them between the two calls: build_csr does not) */
+typedef struct { ent_t *e0, *e1; Py_ssize_t *i0, *i1; PyObject *n0_a, *n1_a, *d0, *d1; Py_ssize_t n; } plan_t;
+static void plan_free(PyObject* cap) {
+  plan_t* p = (plan_t*)PyCapsule_GetPointer(cap, "nanomod_amd.join_plan");
+  if (!p) return;
+  free(p->e0); free(p->e1); free(p->i0); free(p->i1);
+  Py_XDECREF(p->n0_a); Py_XDECREF(p->n1_a); Py_XDECREF(p->d0); Py_XDECREF(p->d1);
+  free(p);
+}
+
+static PyObject* join_impl(PyObject* args, int defer) {
   PyObject *d0, *d1, *b0, *b1;
-  (void)self;
   if (!PyArg_ParseTuple(args, "O!O!O!O!", &PyDict_Type, &d0, &PyDict_Type, &d1, &PyDict_Type, &b0, &PyDict_Type, &b1)) return NULL;
   Py_ssize_t m0 = 0, m1 = 0, mb0 = 0, mb1 = 0;
   ent_t *e0 = NULL, *e1 = NULL, *eb0 = NULL, *eb1 = NULL;
@@ -306,11 +417,23 @@ static PyObject* join_strand(PyObject* self, PyObject* args) {
       if (!eq) { PyObject* ix = PyLong_FromSsize_t(j); if (!ix || PyList_Append(mism, ix) < 0) { Py_XDECREF(ix); goto done; } Py_DECREF(ix); }
     }
   }
+  if (defer) {                                           /* the rows are copied later, by copy_plan, into arrays the caller makes */
+    plan_t* pl = (plan_t*)calloc(1, sizeof(plan_t));
+    if (!pl) { PyErr_NoMemory(); goto done; }
+    PyObject* cap = PyCapsule_New(pl, "nanomod_amd.join_plan", plan_free);
+    if (!cap) { free(pl); goto done; }
+    pl->e0 = e0; pl->e1 = e1; pl->i0 = i0; pl->i1 = i1; pl->n = n;
+    pl->n0_a = n0_a; Py_INCREF(n0_a); pl->n1_a = n1_a; Py_INCREF(n1_a); pl->d0 = d0; Py_INCREF(d0); pl->d1 = d1; Py_INCREF(d1);
+    e0 = e1 = NULL; i0 = i1 = NULL;                        /* (owned by the plan now) */
+    ret = PyTuple_Pack(7, pos_a, n0_a, n1_a, cap, bases, mism, codes_a);
+    Py_DECREF(cap);
+    goto done;
+  }
   npy_intp d0n = (npy_intp)t0, d1n = (npy_intp)t1;
   s0_a = PyArray_SimpleNew(1, &d0n, NPY_DOUBLE); s1_a = PyArray_SimpleNew(1, &d1n, NPY_DOUBLE);
   if (!s0_a || !s1_a) goto done;
   double* s0 = (double*)PyArray_DATA((PyArrayObject*)s0_a); double* s1 = (double*)PyArray_DATA((PyArrayObject*)s1_a);
-  if (copy_rows(e0, i0, n0, n, s0) < 0 || copy_rows(e1, i1, n1, n, s1) < 0) goto done;   /* one group after the other */
+  if (copy_rows(e0, i0, n0, n, s0, NULL) < 0 || copy_rows(e1, i1, n1, n, s1, NULL) < 0) goto done;   /* one group after the other */
   ret = PyTuple_Pack(8, pos_a, n0_a, n1_a, s0_a, s1_a, bases, mism, codes_a);
 done:
   free(e0); free(e1); free(eb0); free(eb1); free(i0); free(i1);
@@ -318,10 +441,49 @@ done:
   return ret;
 }
 
+static PyObject* join_strand(PyObject* self, PyObject* args) { (void)self; return join_impl(args, 0); }
+static PyObject* join_strand_plan(PyObject* self, PyObject* args) { (void)self; return join_impl(args, 1); }
+
+/* copy_plan(plan, out0, start0, out1, start1) -> True, or False when out is int16 and a sample is not k / 1000.0 with |k| <= 32 767
+ * (the int16 arrays then hold nothing usable).  out0 / out1: writable C-contiguous 1-D arrays, both float64 or both int16, with room
+ * for the strand's samples from element start0 / start1 on. */
+static PyObject* copy_plan(PyObject* self, PyObject* args) {
+  PyObject *cap, *o0, *o1; long long st0, st1;
+  (void)self;
+  if (!PyArg_ParseTuple(args, "OO!LO!L", &cap, &PyArray_Type, &o0, &st0, &PyArray_Type, &o1, &st1)) return NULL;
+  plan_t* pl = (plan_t*)PyCapsule_GetPointer(cap, "nanomod_amd.join_plan");
+  if (!pl) return NULL;
+  PyArrayObject *a0 = (PyArrayObject*)o0, *a1 = (PyArrayObject*)o1;
+  const int ty = PyArray_TYPE(a0);
+  if ((ty != NPY_DOUBLE && ty != NPY_INT16) || PyArray_TYPE(a1) != ty || PyArray_NDIM(a0) != 1 || PyArray_NDIM(a1) != 1 ||
+      !PyArray_IS_C_CONTIGUOUS(a0) || !PyArray_IS_C_CONTIGUOUS(a1) || !PyArray_ISWRITEABLE(a0) || !PyArray_ISWRITEABLE(a1)) {
+    PyErr_SetString(PyExc_ValueError, "copy_plan: out0 / out1 must be writable contiguous 1-D arrays, both float64 or both int16"); return NULL;
+  }
+  const int* n0 = (const int*)PyArray_DATA((PyArrayObject*)pl->n0_a); const int* n1 = (const int*)PyArray_DATA((PyArrayObject*)pl->n1_a);
+  long long t0 = 0, t1 = 0;
+  for (Py_ssize_t j = 0; j < pl->n; ++j) { t0 += n0[j]; t1 += n1[j]; }
+  if (st0 < 0 || st1 < 0 || st0 + t0 > (long long)PyArray_DIM(a0, 0) || st1 + t1 > (long long)PyArray_DIM(a1, 0)) {
+    PyErr_SetString(PyExc_ValueError, "copy_plan: the strand's samples do not fit the output arrays"); return NULL;
+  }
+  int r0, r1 = 0;
+  if (ty == NPY_DOUBLE) {
+    r0 = copy_rows(pl->e0, pl->i0, n0, pl->n, (double*)PyArray_DATA(a0) + st0, NULL);
+    if (r0 == 0) r1 = copy_rows(pl->e1, pl->i1, n1, pl->n, (double*)PyArray_DATA(a1) + st1, NULL);
+  } else {
+    r0 = copy_rows(pl->e0, pl->i0, n0, pl->n, NULL, (short*)PyArray_DATA(a0) + st0);
+    if (r0 == 0) r1 = copy_rows(pl->e1, pl->i1, n1, pl->n, NULL, (short*)PyArray_DATA(a1) + st1);
+  }
+  if (r0 < 0 || r1 < 0) return NULL;
+  if (r0 == 1 || r1 == 1) Py_RETURN_FALSE;
+  Py_RETURN_TRUE;
+}
+
 static PyMethodDef methods[] = {
   {"flatten", flatten, METH_VARARGS, "flatten(rows, out): copy the values of every row into the float64 buffer `out`, in order"},
   {"filter_coverage", filter_coverage, METH_VARARGS, "filter_coverage(norm, base, min_cov): delete the positions with fewer than min_cov samples from both dicts"},
   {"join_strand", join_strand, METH_VARARGS, "join_strand(norm0, norm1, base0, base1): positions of both datasets, ascending, as CSR arrays"},
+  {"join_strand_plan", join_strand_plan, METH_VARARGS, "join_strand_plan(norm0, norm1, base0, base1): the same join without the rows: (pos, n0, n1, plan, bases, mismatches, base codes)"},
+  {"copy_plan", copy_plan, METH_VARARGS, "copy_plan(plan, out0, start0, out1, start1): the rows of a planned strand into float64 or (narrowed) int16 arrays; False: a sample refused int16"},
   {NULL, NULL, 0, NULL}
 };
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_hostwalk", "host-side row flattening for detect.build_csr", -1, methods,

@@ -387,6 +387,33 @@ def _join_strand_py(d0, d1, b0, b1, sk, quiet):
             list(b1v))
 
 
+def _gather_rows(hw, parts, plans, total0, total1):
+    """The rows of every (chrom, strand) in ONE pair of CSR arrays, in the device dtype encode_signals would pick.  Planned strands
+    (csrc/hostwalk.c: join_strand_plan) are copied by the C walk's threads straight into the arrays — first as int16 milli-units,
+    narrowed on the way (what stored events are: x = k / 1000.0; 2 bytes written per 8 read), and only when a sample refuses that
+    as float64, which then goes through encode_pair as before.  A strand that took the Python walk brings its own arrays."""
+    if not all(p is not None for p in plans):             # a strand of exotic rows / keys: the general way (per-strand arrays, one concatenate)
+        for i, (part, plan) in enumerate(zip(parts, plans)):
+            if plan is not None:
+                s0 = np.empty(int(part[1].sum(dtype=np.int64)), dtype=np.float64); s1 = np.empty(int(part[2].sum(dtype=np.int64)), dtype=np.float64)
+                hw.copy_plan(plan, s0, 0, s1, 0)
+                parts[i] = part[:3] + (s0, s1) + part[5:]
+        cat = lambda k: np.concatenate([p[k] for p in parts]) if len(parts) > 1 else parts[0][k]
+        return encode_pair(cat(3), cat(4))
+    for dt in (np.int16, np.float64):
+        sig0 = np.empty(total0, dtype=dt); sig1 = np.empty(total1, dtype=dt)
+        at0 = at1 = 0
+        ok = True
+        for part, plan in zip(parts, plans):
+            if not hw.copy_plan(plan, sig0, at0, sig1, at1):
+                ok = False
+                break
+            at0 += int(part[1].sum(dtype=np.int64)); at1 += int(part[2].sum(dtype=np.int64))
+        if ok:
+            return (sig0, sig1) if dt == np.int16 else encode_pair(sig0, sig1)
+    raise AssertionError('copy_plan refused float64 output')
+
+
 def build_csr(moptions):
     """The tested-position set and order of mtest2 (myDetect.py:421,427-431) as CSR arrays + array-shaped metadata.
 
@@ -405,31 +432,37 @@ def build_csr(moptions):
     quiet = moptions.get('outLevel', OUTPUT_ERROR) > OUTPUT_ERROR
     hw = _hostwalk_module()
     chrom, strand, counts = [], [], []                    # one entry per (chrom, strand) key
-    parts = []                                            # per key: (pos, n0, n1, sig0, sig1, bases)
+    parts = []                                            # per key: (pos, n0, n1, sig0, sig1, bases) — sig0 / sig1 None for a planned strand
+    plans = []                                            # per key: the C walk's plan (rows copied later, all strands into ONE pair of arrays) or None
+    two_step = hw is not None and hasattr(hw, 'join_strand_plan')
     for sk in sorted(ds0['norm_mean'].keys()):
         if sk not in ds1['norm_mean']:
             continue
         d0, d1 = ds0['norm_mean'][sk], ds1['norm_mean'][sk]
         b0, b1 = ds0['base'][sk], ds1['base'][sk]
-        part = None
+        part, plan = None, None
         if hw is not None and all(type(x) is dict for x in (d0, d1, b0, b1)):
             try:
                 # the loop header of mtest2 for this strand in one C pass: merge join of the two dicts read in storage
-                # order, rows flattened straight into the CSR arrays (csrc/hostwalk.c: join_strand)
-                p_, n0_, n1_, s0_, s1_, bases_, mism, codes_ = hw.join_strand(d0, d1, b0, b1)
+                # order (csrc/hostwalk.c: join_strand_plan); the rows follow below, every strand's straight into the batch's CSR arrays
+                if two_step:
+                    p_, n0_, n1_, plan, bases_, mism, codes_ = hw.join_strand_plan(d0, d1, b0, b1)
+                    s0_ = s1_ = None
+                else:
+                    p_, n0_, n1_, s0_, s1_, bases_, mism, codes_ = hw.join_strand(d0, d1, b0, b1)
                 if mism and not quiet:
                     b0l = [b0[int(p_[j])] for j in mism]
                     for j, x0 in zip(mism, b0l):
                         print('Error not equal', sk, int(p_[j]), bases_[j], x0)
                 part = (p_, n0_, n1_, s0_, s1_, bases_, codes_)
             except TypeError:                             # position keys that are not integers: the general way below
-                part = None
+                part, plan = None, None
         if part is None:
             part = _join_strand_py(d0, d1, b0, b1, sk, quiet)
         if len(part[0]) == 0:
             continue
         chrom.append(sk[0]); strand.append(sk[1]); counts.append(len(part[0]))
-        parts.append(part)
+        parts.append(part); plans.append(plan)
     cat = lambda k, dt: (np.concatenate([p[k] for p in parts]) if len(parts) > 1 else parts[0][k]) if parts else np.zeros(0, dtype=dt)
     pos = cat(0, np.int64); n0 = cat(1, np.int32); n1 = cat(2, np.int32)
     base = [x for p in parts for x in p[5]] if len(parts) != 1 else parts[0][5]
@@ -439,7 +472,7 @@ def build_csr(moptions):
     if npos:
         np.cumsum(n0, out=off0[1:])
         np.cumsum(n1, out=off1[1:])
-        sig0, sig1 = encode_pair(cat(3, np.float64), cat(4, np.float64))
+        sig0, sig1 = _gather_rows(hw, parts, plans, int(off0[-1]), int(off1[-1]))
     else:
         sig0 = sig1 = np.zeros(0, dtype=np.float32)
     names = sorted(set(chrom))

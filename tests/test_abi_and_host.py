@@ -568,6 +568,67 @@ def test_hostwalk_dict_walks_equal_the_python_loops(capsys, monkeypatch):
     assert len(p_) == 0 and len(s0) == 0 and bases == [] and mism == []
 
 
+def test_hostwalk_two_step_join_gathers_and_narrows():
+    """csrc/hostwalk.c join_strand_plan + copy_plan (round 6): the positions and sizes first, then the rows of several strands straight
+    into ONE pair of arrays at running offsets — float64 equal to join_strand's own arrays, int16 equal to rint(1000 x) where every
+    sample is k / 1000.0 with |k| <= 32 767 and refused (False) where one is not: off the grid, beyond the int16 range, NaN — for
+    rows that are arrays, lists of numpy.float64 and tuples; build_csr then hands int16 CSR arrays over, or float64 ones it
+    narrows the numpy way"""
+    hw = pytest.importorskip('nanomod_amd._hostwalk', reason='make -C nanomod_amd/csrc')
+    import nanomod_amd.detect as D
+    rng = np.random.default_rng(5)
+
+    def strand(npos, spoil=None):
+        d0, d1, b0, b1 = {}, {}, {}, {}
+        for p_ in rng.permutation(npos).tolist():
+            for d in (d0, d1):
+                v = np.round(rng.normal(0, 1, int(rng.integers(1, 300))) * 3, 3)
+                d[p_] = v if p_ % 3 == 0 else ([np.float64(x) for x in v] if p_ % 3 == 1 else tuple(v.tolist()))
+            b0[p_] = b1[p_] = 'ACGT'[p_ % 4]
+        if spoil is not None:
+            row = np.array(d1[npos // 2], dtype=np.float64); row[len(row) // 2] = spoil; d1[npos // 2] = row
+        return d0, d1, b0, b1
+    strands = [strand(5000), strand(300), strand(1)]
+    whole = [hw.join_strand(*st) for st in strands]
+    plans = [hw.join_strand_plan(*st) for st in strands]
+    for w, pl in zip(whole, plans):
+        assert all(np.array_equal(a, b) for a, b in zip(w[:3], pl[:3])) and w[5] == pl[4] and w[6] == pl[5] and np.array_equal(w[7], pl[6])
+    t0 = sum(int(w[1].sum()) for w in whole); t1 = sum(int(w[2].sum()) for w in whole)
+    ref0 = np.concatenate([w[3] for w in whole]); ref1 = np.concatenate([w[4] for w in whole])
+    for dt in (np.float64, np.int16):
+        o0 = np.full(t0 + 7, 99, dtype=dt); o1 = np.full(t1 + 3, 99, dtype=dt)
+        a0, a1 = 7, 3                                          # (not from element 0: the running offsets are the caller's)
+        for w, pl in zip(whole, plans):
+            assert hw.copy_plan(pl[3], o0, a0, o1, a1) is True
+            a0 += int(w[1].sum()); a1 += int(w[2].sum())
+        want0, want1 = (ref0, ref1) if dt == np.float64 else (np.rint(ref0 * 1000).astype(np.int16), np.rint(ref1 * 1000).astype(np.int16))
+        assert np.array_equal(o0[7:], want0) and np.array_equal(o1[3:], want1) and np.all(o0[:7] == 99) and np.all(o1[:3] == 99)
+    for spoil in (0.12345, 32.768, -40.0, np.nan, np.nextafter(0.5, 1.0)):
+        pl = hw.join_strand_plan(*strand(200, spoil))
+        n_0, n_1 = int(pl[1].sum()), int(pl[2].sum())
+        assert hw.copy_plan(pl[3], np.empty(n_0, np.int16), 0, np.empty(n_1, np.int16), 0) is False
+        f0, f1 = np.empty(n_0), np.empty(n_1)
+        assert hw.copy_plan(pl[3], f0, 0, f1, 0) is True and (np.isnan(spoil) or spoil in f1)
+    with pytest.raises(ValueError):
+        hw.copy_plan(plans[0][3], np.empty(10), 0, np.empty(10), 0)                      # too small
+    with pytest.raises(ValueError):
+        hw.copy_plan(plans[0][3], np.empty(t0, np.float32), 0, np.empty(t1, np.float32), 0)
+    with pytest.raises((TypeError, ValueError)):
+        hw.copy_plan(object(), np.empty(t0), 0, np.empty(t1), 0)
+    # build_csr: int16 CSR arrays straight from the dicts; float64 rows that are not on the grid take the numpy way as before
+    def moptions(strs):
+        mo = {'ds2': ['a', 'b'], 'MinCoverage': 1, 'outLevel': 3}
+        for g, name in enumerate(('a', 'b')):
+            mo[name] = {'norm_mean': {('c%d' % i, '+'): st[g] for i, st in enumerate(strs)}, 'base': {('c%d' % i, '+'): st[2 + g] for i, st in enumerate(strs)}, 'basedict': {}}
+        return mo
+    meta, s0, off0, s1, off1, rid = D.build_csr(moptions(strands))
+    assert s0.dtype == np.int16 and np.array_equal(s0, np.rint(ref0 * 1000).astype(np.int16)) and np.array_equal(s1, np.rint(ref1 * 1000).astype(np.int16))
+    assert off0[-1] == t0 and off1[-1] == t1 and len(meta['pos']) == 5301
+    sp = strand(200, 0.12345)
+    meta, s0, off0, s1, off1, rid = D.build_csr(moptions([strands[1], sp]))
+    assert s0.dtype == np.float64 and 0.12345 in s1
+
+
 def test_dispatch_forms_keep_16_keys_per_lane():
     """what runs for the uniform sizes of BASELINE.json's configs: every wave-resident form up to 1 024 samples sorts
     at most 16 keys per lane (four waves per SIMD) — the description is host code, no device needed"""

@@ -106,6 +106,7 @@ struct CntProbeArgs {
   const int32_t* pos_list; const int32_t* class_meta; int32_t class_id; int32_t dtype; int32_t* gate;
 };
 constexpr int kCntProbeSamples = 64;
+constexpr int kCntProbeWindow = 1536;                   // (the kernel's: kCntWindow = 2 048)
 
 template <int DTYPE>
 __global__ __launch_bounds__(1024) void cnt_probe_kernel(CntProbeArgs a) {
@@ -152,12 +153,15 @@ __global__ __launch_bounds__(1024) void cnt_probe_kernel(CntProbeArgs a) {
 #if NMOD_CNT_TAILS
     if (!fit && __ballot(!ok) == 0ull) {
       // a few outliers: the kernel keeps the position when at most kCntTail samples lie further than 1 024 from the mean of its keys
-      // (half of that here: the batch should mostly take the kernel's path without them)
+      // (half of that here: the batch should mostly take the kernel's path without them).  The probe counts against a NARROWER
+      // window, 768 either side: a mis-segmented read anywhere in +-5 units is outside both alike, but rows whose bulk fills the
+      // kernel's window (sigma 0.4: ~20 samples beyond 768, 2-3 beyond 1 024 at EVERY position, the longest scans) cost the
+      // counting form more than the sorting form takes — 6.37 v 6.11 ms on configs[2], measured in round 6 — and are left to it.
       const int centre = (int)__builtin_rintf((float)(long long)wave_sum_u64((unsigned long long)ksum) / (float)max(ntot, 1));
-      const int base = max(-32768, min(centre - kCntWindow / 2, 32768 - kCntWindow));
+      const int base = max(-32768, min(centre - kCntProbeWindow / 2, 32768 - kCntProbeWindow));
       int tails = 0;
       for (int g = 0; g < 2; ++g)
-        for (int i = lane; i < nn[g] && i <= kCntMaxN; i += 64) { int k; key_at(g, oo[g], i, k); tails += ((unsigned)(k - base) >= (unsigned)kCntWindow) ? 1 : 0; }
+        for (int i = lane; i < nn[g] && i <= kCntMaxN; i += 64) { int k; key_at(g, oo[g], i, k); tails += ((unsigned)(k - base) >= (unsigned)kCntProbeWindow) ? 1 : 0; }
       const int nfar = (int)wave_sum_u64((unsigned long long)tails);
       fit = nfar <= kCntTail / 2;
       if (fit && lane == 0) atomicAdd(&far, nfar);

@@ -689,7 +689,7 @@ def short_build_info(info):
     parts = info.split(' | ')
     head = parts[0]
     shipped = {'NMOD_SKIP': '0', 'NMOD_EXP': '0', 'NMOD_SWZ_MASK': '0', 'NMOD_PK_SELECT': '0', 'NMOD_CE_BUILTIN': '0', 'NMOD_XOR4_BANKS': '0',
-               'NMOD_NO_GRID': '0', 'NMOD_CNT_SKIP': '0', 'NMOD_CW_OR3': '1', 'NMOD_CNT_TAILS': '1'}
+               'NMOD_NO_GRID': '0', 'NMOD_CNT_SKIP': '0', 'NMOD_CW_OR3': '1', 'NMOD_CNT_TAILS': '1', 'NMOD_WIDE_TAILS': '1'}
     odd = set()
     for tu in parts[1:]:
         name, _, kv = tu.partition(': ')

@@ -79,10 +79,15 @@
 #else
 #define NMOD_BI_CNT_TAILS "1"
 #endif
+#ifdef NMOD_WIDE_TAILS
+#define NMOD_BI_WIDE_TAILS NMOD_STR(NMOD_WIDE_TAILS)
+#else
+#define NMOD_BI_WIDE_TAILS "1"
+#endif
 #define NMOD_BUILD_FLAGS                                                                                              \
   "NMOD_SKIP=" NMOD_BI_SKIP " NMOD_EXP=" NMOD_BI_EXP " NMOD_HIST_WAVES=" NMOD_BI_HIST_WAVES                            \
   " NMOD_WIDE_I16_WORDS=" NMOD_BI_WIDE_I16_WORDS " NMOD_SWZ_MASK=" NMOD_BI_SWZ_MASK \
   " NMOD_PK_SELECT=" NMOD_BI_PK_SELECT " NMOD_CE_BUILTIN=" NMOD_BI_CE_BUILTIN     \
   " NMOD_XOR4_BANKS=" NMOD_BI_XOR4_BANKS " NMOD_NO_GRID=" NMOD_BI_NO_GRID " NMOD_CNT_SKIP=" NMOD_BI_CNT_SKIP \
   " NMOD_CNT_WAVES=" NMOD_BI_CNT_WAVES " NMOD_KS_TOPS=" NMOD_BI_KS_TOPS " NMOD_WIDE_TOPS=" NMOD_BI_WIDE_TOPS \
-  " NMOD_CW_OR3=" NMOD_BI_CW_OR3 " NMOD_CNT_TAILS=" NMOD_BI_CNT_TAILS
+  " NMOD_CW_OR3=" NMOD_BI_CW_OR3 " NMOD_CNT_TAILS=" NMOD_BI_CNT_TAILS " NMOD_WIDE_TAILS=" NMOD_BI_WIDE_TAILS

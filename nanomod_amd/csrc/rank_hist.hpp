@@ -182,6 +182,10 @@ __device__ __forceinline__ unsigned pos_allsum_u32(unsigned v) {     // sum over
 // that table takes goes on a redo list for wide_redo_kernel (big_rank.hpp).  See the streaming section below.
 constexpr unsigned kWideEmpty = 0xffffffffu;
 constexpr int kWideList = 128;                     // words of the list in front of the exact table: < 64 waiting + <= 64 of one flush
+constexpr int kWideTail = 64;                      // counters: samples of Q outside the window wait here for an all-pairs tie count (round 6)
+#ifndef NMOD_WIDE_TAILS
+#define NMOD_WIDE_TAILS 1                          // 0: round 5's form — any sample outside the window sends the position to recount16
+#endif
 
 // AFTER (R = LG = 16 only): the launch follows rank_count_kernel (rank_count.hpp) over the same work list.  When the probe's
 // gate is set, that kernel has left one flag byte per position, four per work item (cnt_done as dwords): a wave reads the
@@ -460,7 +464,15 @@ void rank_hist_kernel(RankStatsArgs args) {
     // WIDE: the direct-address tie counters (int16 input, and float32 input on the milli-unit grid).  The wave's table holds
     // one 8-bit counter per VALUE of a window of the milli-unit domain (four per 32-bit word): one returning LDS add per
     // sample gives the number of earlier copies of its value, p - 1 — no hashing, no walks, one round trip.
-    unsigned long long redo = 0ull;                                          // lanes that saw a counter at 255 or a sample outside
+    unsigned long long redo = 0ull;                                          // lanes that saw a counter at 255 (round 5: or a sample outside)
+    // Round 6: a sample of Q OUTSIDE the window — a mis-segmented read anywhere in the +-5 unit clip range
+    // (myRefBaseSignalAnnotation.py:251-259) — no longer voids the counts.  It cannot tie with a counted value, so it waits on a
+    // list of kWideTail words (ballot + mbcnt compaction; int16: the table's last 64 words, the window is 7 936 values; float32
+    // on the grid: the deferred list's words, unused on this path) and tail_ties() counts the ties among the listed samples by
+    // all pairs after the pass.  More than kWideTail of them: recount16 as before.
+    int wtails = 0;                                                          // (wave-uniform) samples put on the tail list
+    const int wcount = WIDE ? wslots - ((NMOD_WIDE_TAILS && DTYPE == 1) ? kWideTail : 0) : 0;   // words of 8-bit counters
+    [[maybe_unused]] unsigned* const wtail = reinterpret_cast<unsigned*>(keys) + BIN_WORDS + wcount;   // (float32: wcount = wslots, the deferred list)
     [[maybe_unused]] auto count_many = [&](auto cb_tag, auto nv_tag, const int* iv, const bool* have, int base) {
       constexpr int BITS = decltype(cb_tag)::value, NV = decltype(nv_tag)::value;
       constexpr int PW_LOG = (BITS == 16) ? 1 : 2;
@@ -469,13 +481,24 @@ void rank_hist_kernel(RankStatsArgs args) {
 #pragma unroll
       for (int e = 0; e < NV; ++e) {
         const unsigned u = (unsigned)(iv[e] - base);
-        const bool in = u < ((unsigned)wslots << PW_LOG);
+        const bool in = u < ((unsigned)((BITS == 8) ? wcount : wslots) << PW_LOG);
         sh[e] = (u & ((1u << PW_LOG) - 1u)) * (unsigned)BITS;
         old[e] = 0u;
 #if !(NMOD_SKIP & 128)
         if (have[e] && in) old[e] = atomicAdd(&ht[u >> PW_LOG], 1u << sh[e]);
 #endif
-        if constexpr (BITS == 8) redo |= __ballot(have[e] && !in);
+        if constexpr (BITS == 8) {
+#if NMOD_WIDE_TAILS
+          const unsigned long long mk = __ballot(have[e] && !in);
+          if (mk != 0ull) {                                                  // (wave-uniform; never on rows without outliers)
+            const int idx = wtails + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            if (have[e] && !in && idx < kWideTail) wtail[idx] = (unsigned)iv[e];
+            wtails += (int)__popcll(mk);
+          }
+#else
+          redo |= __ballot(have[e] && !in);
+#endif
+        }
       }
 #pragma unroll
       for (int e = 0; e < NV; ++e) {
@@ -491,7 +514,21 @@ void rank_hist_kernel(RankStatsArgs args) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     };
-    // The exceptions — a sample outside the window (a range beyond 8 units, or groups far apart), or 256 samples of one
+    // the ties among the listed samples: lane i holds sample i and meets every earlier one — c copies before it add c (c + 1)
+    [[maybe_unused]] auto tail_ties = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const bool tv = lane < wtails;
+      const int v = tv ? (int)wtail[lane] : 0;
+      unsigned c = 0u;
+#pragma unroll 1
+      for (int j = 0; j + 1 < wtails; ++j) {
+        const int vj = __builtin_amdgcn_readlane(v, j);
+        c += (tv && j < lane && vj == v) ? 1u : 0u;
+      }
+      ppq += __umul24(c, c) + c;
+    };
+    // The exceptions — more than kWideTail samples outside the window (groups far apart, a range beyond 8 units), or 256 samples of one
     // value (a constant stretch of signal): the counts are void.  The ties of the position are counted again the plain
     // way: min and max of Q, then one pass per window of [min, max] with 16-bit counters, one sample per lane and trip.
     // key_at(i, have): the integer key of sample i of Q.
@@ -525,7 +562,7 @@ void rank_hist_kernel(RankStatsArgs args) {
       // int16 samples.  The window is centred on the median of S (the two groups are reads of one position: real events
       // spread a few hundred milli-units around their level).  A position with a sample of Q outside the window, or with a
       // value that occurs 256 times (the counter wraps into its neighbour), is counted again after the pass (recount16).
-      const int wb = (int)keys[Lay::word(m > 0 ? (m >> 1) : 0)] - 2 * wslots;   // four values per word (m = 0: key 0 is the +inf pad -> any window)
+      const int wb = (int)keys[Lay::word(m > 0 ? (m >> 1) : 0)] - 2 * wcount;   // four values per word (m = 0: key 0 is the +inf pad -> any window)
       const int kq = (q > 0) ? (int)rk : 0;                                 // shift of Q's moment sums
       int s1i = 0; long long s2i = 0;                                        // sum (x - kq), sum (x - kq)^2: exact integers
       clear_table();
@@ -564,7 +601,8 @@ void rank_hist_kernel(RankStatsArgs args) {
         s1i += d; s2i += (long long)d * (long long)d;
         count_many(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, iv1, hv, wb);
       }
-      if (redo != 0ull) recount16([&](int i, bool have) { return (int)load_q1(sig_q, off_q, i, have); });
+      if (redo != 0ull || wtails > kWideTail) recount16([&](int i, bool have) { return (int)load_q1(sig_q, off_q, i, have); });
+      else if (wtails > 1) tail_ties();
       // exact sums to doubles (|s1| < 2^23 and s2 < 2^39 per lane): the common moments code below reduces them
       s1w = (double)s1i; s2w = (double)s2i;
     } else if constexpr (WIDE) {
@@ -774,7 +812,7 @@ void rank_hist_kernel(RankStatsArgs args) {
         // ---- S is on the milli-unit grid: rank and sum the moments as above, count Q's ties by VALUE with the direct-address
         // counters of the int16 form (window of 4 x wslots = 8 192 values centred on the median of S) — as long as every
         // sample of Q is on the grid too
-        const int wb = (int)__builtin_rintf(__fmul_rn(keys[Lay::word(m >> 1)], 1000.0f)) - 2 * wslots;
+        const int wb = (int)__builtin_rintf(__fmul_rn(keys[Lay::word(m >> 1)], 1000.0f)) - 2 * wcount;
         bool offl = false;                            // this lane saw a sample of Q off the grid
         clear_table();
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -818,12 +856,12 @@ void rank_hist_kernel(RankStatsArgs args) {
         if (__ballot(offl) != 0ull) {                 // Q has samples off the grid: its ties through the bitmaps after all
           ppq = 0u;
           bitmap_passes(false);
-        } else if (redo != 0ull) {
+        } else if (redo != 0ull || wtails > kWideTail) {
           if (!recount16([&](int i, bool have) { int k; grid_key<false>((float)load_q1(sig_q, off_q, i, have), k); return k; })) {
             ppq = 0u;                                 // keys over more than 65 535 milli-units: the bitmaps
             bitmap_passes(false);
           }
-        }
+        } else if (wtails > 1) tail_ties();
       }
     } else {
     __builtin_amdgcn_s_waitcnt(0x0F70);            // everything requested before the sort has arrived

@@ -39,7 +39,7 @@ def test_shipped_binary_is_a_product_build():
     assert names == ['abi_tu', 'k1_f32_ks', 'k1_f32_all', 'k1_i16_ks', 'k1_i16_all']
     want = {'NMOD_SKIP': '0', 'NMOD_EXP': '0', 'NMOD_HIST_WAVES': '4', 'NMOD_WIDE_I16_WORDS': '2048',
             'NMOD_SWZ_MASK': '0', 'NMOD_PK_SELECT': '0', 'NMOD_CE_BUILTIN': '0', 'NMOD_XOR4_BANKS': '0', 'NMOD_NO_GRID': '0',
-            'NMOD_CNT_SKIP': '0', 'NMOD_CNT_WAVES': '4', 'NMOD_KS_TOPS': '1', 'NMOD_WIDE_TOPS': '0', 'NMOD_CW_OR3': '1', 'NMOD_CNT_TAILS': '1'}
+            'NMOD_CNT_SKIP': '0', 'NMOD_CNT_WAVES': '4', 'NMOD_KS_TOPS': '1', 'NMOD_WIDE_TOPS': '0', 'NMOD_CW_OR3': '1', 'NMOD_CNT_TAILS': '1', 'NMOD_WIDE_TAILS': '1'}
     for p in parts[1:]:
         got = dict(kv.split('=') for kv in p.split(': ', 1)[1].split())
         assert got == want, (p, got)

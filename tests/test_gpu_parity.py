@@ -1140,7 +1140,7 @@ def test_ks_only_large_ranked_group(nm):
 
 
 @pytest.mark.parametrize('mode', ['cont', 'grid1', 'const', 'i16', 'i16const', 'i16span', 'i16heavy', 'f64', 'f64ties',
-                                  'g32', 'g32span', 'g32heavy', 'g32mixed', 'offconst'])
+                                  'g32', 'g32span', 'g32heavy', 'g32mixed', 'offconst', 'i16tails', 'g32tails'])
 def test_unequal_classes_streamed_larger_group(nm, mode):
     """positions whose groups fall in different capacity classes with the smaller one <= 256 samples: the WIDE form of
     rank_hist_kernel (smaller group sorted, larger one streamed and counted in a per-wave hash table), the larger group up
@@ -1153,7 +1153,10 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
     group is on the milli-unit grid of real events takes the same counters (rank_hist.hpp: grid_key) while the larger
     group's samples are on the grid too: `g32` (3-decimal values), `g32span` / `g32heavy` (the recount paths), `g32mixed`
     (samples off the grid, one ulp beside it, or beyond +-32.767 in either group: back to the hash, mid-position); `offconst`:
-    hundreds to thousands of equal samples off the grid — the bitmap form's fall-back, the hash passes with the table full"""
+    hundreds to thousands of equal samples off the grid — the bitmap form's fall-back, the hash passes with the table full.
+    `i16tails` / `g32tails` (round 6): event-like rows with samples of the streamed group OUTSIDE the counters' window — 1, 2 equal
+    ones, a dozen with repeats, exactly 64, 65 and 200 (past the tail list: the recount), and tails beside a value of 256 copies;
+    the counting forms are switched off for these two (NMOD_FLAG_NO_COUNTING), so the sorting form's tail list is what runs"""
     import nanomod_oracle as orc
     rng = np.random.default_rng(zlib.crc32(mode.encode()))
     sizes = [(50, 1000), (1000, 50), (3, 130), (64, 65), (65, 2048), (130, 700), (256, 2048), (256, 4096), (4096, 256),
@@ -1182,6 +1185,18 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
                 y[: b // 2] = -1.7654321
             elif i % 3 == 1:
                 y[::3] = rng.normal(0, 1, len(y[::3]))
+        elif mode in ('i16tails', 'g32tails'):
+            lev = rng.uniform(-1, 1)
+            x = np.round(lev + 0.2 * rng.normal(0, 1, a), 3); y = np.round(lev + 0.2 * rng.normal(0.3, 1, b), 3)
+            big = x if a > b else y
+            nt = (1, 2, 12, 64, 65, 200, 30, 0)[i % 8]
+            nt = min(nt, len(big) - 1)
+            far = np.round(lev + rng.choice([-1.0, 1.0], nt) * rng.uniform(4.3, 9.0, nt), 3)
+            if nt >= 2:
+                far[1::3] = far[0]                     # copies among the outside samples (2: a pair; 12 ..: every third)
+            if nt == 30 and len(big) > 400:
+                big[40:296] = np.round(lev, 3)         # 256 copies of one value inside the window: the counter wraps -> recount
+            big[rng.permutation(len(big))[:nt] if nt != 30 else np.arange(nt)] = far
         elif mode in ('const', 'i16const'):
             x[:] = 0.25; y[:] = 0.25
             if i % 3 == 0:
@@ -1223,8 +1238,12 @@ def test_unequal_classes_streamed_larger_group(nm, mode):
                     if j + 2 < ob[i + 1]:
                         big_[j + 2] = big_[j]
         r0, r1 = sig0, sig1
-    got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=1, weights_dif=2.0, method='fisher')
+    tails = mode in ('i16tails', 'g32tails')
+    got = nm.detect_host(sig0, off0, sig1, off1, rid, nb=1, weights_dif=2.0, method='fisher', flags=nm._lib.FLAG_NO_COUNTING if tails else 0)
     exp = orc.detect_batch(r0, off0, r1, off1, rid, 1, 2.0, orc.METHOD_FISHER)
+    if tails:
+        st = nm._lib.last_dispatch_stats()
+        assert st['rank_count'] == 0 and st['rank_count_wide'] == 0 and st['rank_hist_wide'] >= 8, st
     ident = (exp['status'] & 1) != 0                  # all samples identical: U / p NaN on both sides
     assert np.array_equal(np.isnan(got['mwu_u']), np.isnan(exp['mwu_u']))
     got['mwu_u'][ident] = 0.0; exp['mwu_u'][ident] = 0.0

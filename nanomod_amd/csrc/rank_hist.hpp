@@ -112,8 +112,9 @@ __device__ __forceinline__ void ce_raw(float& lo, float& hi) {
 // k / 1000.0f for every |k| <= 32 767 (exhaustive host test, tests/test_grid_key.py).  Equal keys <=> equal samples among
 // the samples that pass: the integer keys order and tie exactly as the floats do.
 // RANGE = false leaves the |k| <= 32 767 test out (one compare per sample of the streamed group): an accepted sample is a function
-// of its key whatever the range (x == q(t)), so equal keys still mean equal samples; keys outside the counters' window send the
-// position to the recount, which checks the range once per position (a key beyond +-2^31 saturates there and fails it).
+// of its key whatever the range (x == q(t)), so equal keys still mean equal samples; keys outside the counters' window wait on the
+// tail list (compared as 32-bit keys) or, past its 64 entries, send the position to the recount, which checks the range once per
+// position (a key beyond +-2^31 saturates and fails the test above unless it is that one float: no two samples share it).
 template <bool RANGE = true>
 __device__ __forceinline__ bool grid_key(float x, int& k) {
   const float t = __builtin_rintf(__fmul_rn(x, 1000.0f));
@@ -560,8 +561,9 @@ void rank_hist_kernel(RankStatsArgs args) {
     };
     if constexpr (WIDE && DTYPE == 1) {
       // int16 samples.  The window is centred on the median of S (the two groups are reads of one position: real events
-      // spread a few hundred milli-units around their level).  A position with a sample of Q outside the window, or with a
-      // value that occurs 256 times (the counter wraps into its neighbour), is counted again after the pass (recount16).
+      // spread a few hundred milli-units around their level).  Samples of Q outside the window: the tail list (count_many).  A position
+      // with more than kWideTail of them, or with a value that occurs 256 times (the counter wraps into its neighbour), is counted
+      // again after the pass (recount16).
       const int wb = (int)keys[Lay::word(m > 0 ? (m >> 1) : 0)] - 2 * wcount;   // four values per word (m = 0: key 0 is the +inf pad -> any window)
       const int kq = (q > 0) ? (int)rk : 0;                                 // shift of Q's moment sums
       int s1i = 0; long long s2i = 0;                                        // sum (x - kq), sum (x - kq)^2: exact integers

@@ -1,3 +1,6 @@
+#!/bin/bash
+# tools/skiprun.sh (round 3): the bench over phase-skip builds of the library (-DNMOD_SKIP=<bits>, libnanomod_hip_s<bits>.so beside the build) —
+# where the instructions of the all-tests kernel go (profiles/HISTORY.md B.3).  Timing only: phase-skip builds give wrong numbers.
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cp $R/nanomod_amd/libnanomod_hip.so /tmp/base.so

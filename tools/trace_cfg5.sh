@@ -1,3 +1,5 @@
+#!/bin/bash
+# tools/trace_cfg5.sh (round 2): every launch of one configs[4] all-tests step with its duration (profiles/r2_cfg5_kernel_trace.txt)
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/p5

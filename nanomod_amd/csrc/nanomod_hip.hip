@@ -587,9 +587,11 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     if (classes.empty()) return hipSuccess;
     hipError_t e = cw_prepare(classes);
     if (e != hipSuccess) return e;
+    bool vc = false;                                          // (both groups above 1 024 samples: the value-domain form, all tests)
+    for (int c : classes) vc = vc || (all && count_wide_rs_index(c) == 5);
     if (prm->dtype == NMOD_DTYPE_F32)
-      return all ? launch_count_wide_run_d0_a1(num_cus, npos, stream, ra, cww) : launch_count_wide_run_d0_a0(num_cus, npos, stream, ra, cww);
-    return all ? launch_count_wide_run_d1_a1(num_cus, npos, stream, ra, cww) : launch_count_wide_run_d1_a0(num_cus, npos, stream, ra, cww);
+      return all ? launch_count_wide_run_d0_a1(num_cus, npos, stream, ra, cww, vc) : launch_count_wide_run_d0_a0(num_cus, npos, stream, ra, cww, vc);
+    return all ? launch_count_wide_run_d1_a1(num_cus, npos, stream, ra, cww, vc) : launch_count_wide_run_d1_a0(num_cus, npos, stream, ra, cww, vc);
   };
   // a class's sorting form; where the counting form was in play (its gate is set, on the device) it walks the work list
   auto launch_class = [&](int cls, int64_t work, bool counted) -> hipError_t {

@@ -769,7 +769,7 @@ void rank_count_wide_kernel(CntWideArgs cw) {
       case 2: cw_segment<DTYPE, 4, KS>(args, cw.work_list, cw.work_meta + cls, tbl, count, loff, list, start, nw, lane); break;
       case 3: cw_segment<DTYPE, 8, KS>(args, cw.work_list, cw.work_meta + cls, tbl, count, loff, list, start, nw, lane); break;
       case 4: cw_segment<DTYPE, 16, KS>(args, cw.work_list, cw.work_meta + cls, tbl, count, loff, list, start, nw, lane); break;
-      default: break;
+      default: break;                                      // (index 5 — both groups above 1 024 samples: rank_count_value_kernel, rank_count_value.hpp)
     }
   }
 }

@@ -9,6 +9,7 @@
 #include "rank_hist.hpp"
 #include "rank_count.hpp"
 #include "rank_count_wide.hpp"
+#include "rank_count_value.hpp"
 #include "rank_stats_launch.hpp"
 #include "build_info.hpp"
 
@@ -236,7 +237,7 @@ hipError_t NMOD_CW_PREP_NAME(const int* classes, int nclasses, hipStream_t strea
   return hipGetLastError();
 }
 
-hipError_t NMOD_CW_RUN_NAME(int num_cus, int64_t work_items, hipStream_t stream, const RankStatsArgs& a, const CountWideWs& w) {
+hipError_t NMOD_CW_RUN_NAME(int num_cus, int64_t work_items, hipStream_t stream, const RankStatsArgs& a, const CountWideWs& w, bool value_class) {
   typedef void (*CwFn)(CntWideArgs);
 #if NMOD_INST_DTYPE == 0
   const bool int_keys = a.tied != nullptr;
@@ -264,6 +265,31 @@ hipError_t NMOD_CW_RUN_NAME(int num_cus, int64_t work_items, hipStream_t stream,
   int64_t blocks = std::min<int64_t>((work_items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)num_cus * pc);
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream, ca);
+#if NMOD_INST_ALL
+  if (value_class) {
+    // the class whose groups both hold more than 1 024 samples: the value-domain form (rank_count_value.hpp), a launch of its own
+#if NMOD_INST_DTYPE == 0
+    CwFn vfn = int_keys ? (CwFn)rank_count_value_kernel<2> : (CwFn)rank_count_value_kernel<0>;
+#else
+    CwFn vfn = (CwFn)rank_count_value_kernel<1>;
+#endif
+    static std::atomic<int> vper_cu[64][2];
+    int vpc = cacheable ? vper_cu[dev][slot].load(std::memory_order_relaxed) : 0;
+    if (vpc <= 0) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&vpc, vfn, 64 * kWavesPerBlock, lds);
+      if (e != hipSuccess) return e;
+      if (vpc < 1) return hipErrorLaunchOutOfResources;
+      if (cacheable) vper_cu[dev][slot].store(vpc, std::memory_order_relaxed);
+    }
+    int64_t vblocks = std::min<int64_t>((work_items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)num_cus * vpc);
+    if (vblocks < 1) vblocks = 1;
+    hipLaunchKernelGGL(vfn, dim3((unsigned)vblocks), dim3(64 * kWavesPerBlock), lds, stream, ca);
+  }
+#else
+  (void)value_class;
+#endif
   return hipGetLastError();
 }
 

@@ -843,6 +843,90 @@ def _count_wide_outlier_checks(nm, dtype, s0, off0, s1, off1, rid, exp, kept, P)
     assert np.all(np.abs(kr['ks_d'] - exp['ks_d']) <= 4.5e-16)
 
 
+@pytest.mark.parametrize('dtype', ['i16', 'f32', 'f64'])
+def test_value_domain_form_vs_oracle(nm, dtype):
+    """rank_count_value.hpp (round 6): all tests on event-like positions whose groups BOTH hold 1 025 ... 2 048 samples — counted by value,
+    every statistic from the table's values in order.  Clean positions, 1 / 2 equal / 64 / 65 samples outside the window (below,
+    above, both; either group), ties inside and across the groups, groups a unit apart (D = 1), constant groups, a window clamped at
+    the end of the int16 domain, random contamination at 1 / 10 per mille — every number against the oracle; the form keeps every
+    position with at most 64 outside samples (nmod_last_dispatch_stats) and the sorting form (rank_pair_kernel) gives the same integers"""
+    import oracle_c
+    L = nm._lib
+    rng = np.random.default_rng(zlib.crc32(('value-domain' + dtype).encode()))
+    rows0, rows1, kept = [], [], []
+
+    def add(a, b, keep=True):
+        rows0.append(np.asarray(a, dtype=np.int64)); rows1.append(np.asarray(b, dtype=np.int64)); kept.append(keep)
+
+    def ev(n, lev=0, s=150):
+        return lev + np.clip(np.rint(s * rng.normal(0, 1, n)), -700, 700).astype(np.int64)
+
+    def out(n, side, lev=0):
+        lo = rng.integers(-5000, lev - 1100, n) if lev - 1100 > -5000 else np.full(n, -5000)
+        hi = rng.integers(lev + 1100, 5001, n) if lev + 1100 < 5000 else np.full(n, 5000)
+        return lo if side < 0 else hi if side > 0 else np.where(rng.random(n) < 0.5, lo, hi)
+
+    def sz():
+        return int(rng.integers(1025, 2049))
+    for _ in range(100):                                     # the bulk: the probe wants 7 of 8 sampled positions to fit
+        lev = int(rng.integers(-3000, 3000)); add(ev(sz(), lev), ev(sz(), lev + int(rng.choice([0, 0, 60, -200]))))
+    for n_out in (1, 2, 64, 65):
+        for side in (-1, 1, 0):
+            for grp in (0, 1):
+                lev = int(rng.integers(-2500, 2500)); a, b = ev(sz(), lev), ev(sz(), lev)
+                tgt = a if grp == 0 else b
+                far = out(n_out, side, lev)
+                if n_out == 2:
+                    far[1] = far[0]
+                tgt[64 + rng.choice(len(tgt) - 64, n_out, replace=False)] = far     # (not among the first 64: the centre's sample)
+                add(a, b, n_out <= 64)
+    lev = 0
+    a, b = ev(2048, lev), ev(1025, lev); a[100:130] = 4000; b[200:202] = 4000; b[300:302] = -4000; add(a, b)      # one value 32 times over both groups, outside
+    a, b = ev(1500, lev), ev(1500, lev); a[:] = 250; b[:] = 250; add(a, b)                                        # every sample equal: U / p NaN
+    a, b = ev(1500, lev), ev(1600, lev); a[:] = 100; b[:] = 900; a[0] = 101; b[0] = 899; add(a, b)                # (all but) constant groups apart: D = 1 (exactly constant ones have no t to compare: 0 / 0 in exact arithmetic, rounding noise in the reference)
+    a, b = ev(1300, 0, 60), ev(1300, 1000, 60); add(a, b)                                                          # a unit apart: both inside one window, D = 1
+    a, b = ev(2048, lev, 20), ev(2048, lev, 20); add(a, b)                                                         # narrow: ~150 copies per value
+    add(ev(1100, 31500), ev(1100, 31500)); add(ev(1100, -31500), ev(1100, -31500))                                # the window clamped at the domain's ends
+    a, b = ev(1200, 30000), ev(1200, 30000); a[70] = -32768; b[80] = 32767; add(a, b, True if dtype == 'i16' else None)   # (-32.768 is not a float32 / float64 key of the form: |k| <= 32 767)
+    a, b = ev(1400, lev), ev(1400, lev); a[:64] = out(64, 0, lev); add(a, b, None)                                       # the first 64 of a group all outliers: the centre from the other group's
+    for frac, npos_f in ((0.001, 24), (0.01, 24)):
+        for _ in range(npos_f):
+            lev = int(rng.integers(-3000, 3000)); a, b = ev(sz(), lev), ev(sz(), lev)
+            for v in (a, b):
+                hit = rng.random(len(v)) < frac
+                v[hit] = rng.integers(-5000, 5001, int(hit.sum()))
+            add(a, b, None)
+    P = len(rows0)
+    off0 = np.zeros(P + 1, np.int64); off0[1:] = np.cumsum([len(r) for r in rows0])
+    off1 = np.zeros(P + 1, np.int64); off1[1:] = np.cumsum([len(r) for r in rows1])
+    k0 = np.concatenate(rows0).astype(np.int16); k1 = np.concatenate(rows1).astype(np.int16)
+    rid = np.zeros(P, np.int32)
+    s0, s1 = _as_dtype(k0, dtype), _as_dtype(k1, dtype)
+    exp = oracle_c.detect_batch(s0 if dtype == 'f32' else k0, off0, s1 if dtype == 'f32' else k1, off1, rid, 0, 2.0, 'fisher', tests=7)
+    f64 = L.FLAG_NO_HOST_NARROW if dtype == 'f64' else 0
+    assert L.load().nmod_host_pipeline_config(1 << 30, 0, 0, 0) == 0      # (one chunk: one probe over the class)
+    try:
+        got = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=f64)
+        st = L.last_dispatch_stats()
+        srt = nm.detect_host(s0, off0, s1, off1, rid, nb=0, weights_dif=2.0, method='fisher', flags=f64 | L.FLAG_NO_COUNTING)
+        st_srt = L.last_dispatch_stats()
+    finally:
+        assert L.load().nmod_host_pipeline_config(0, 0, 0, 0) == 0
+    ident = (exp['status'] & 1) != 0
+    assert np.array_equal(np.isnan(got['mwu_u']), ident) and np.array_equal(np.isnan(srt['mwu_u']), ident)
+    for r in (got, srt):
+        r['mwu_u'][ident] = 0.0
+    exp['mwu_u'][ident] = 0.0
+    H.compare_outputs(got, exp, True, t_abs=H.t_abs_gate(s0, off0, s1, off1))
+    assert np.array_equal(got['status'], exp['status'])
+    n_rej = kept.count(False)
+    assert st['skipped'] == 0 and st['count_tried'] == P and st_srt['count_tried'] == 0 and st_srt['rank_pair'] == P, (st, st_srt)
+    assert n_rej <= st['count_rejected'] <= n_rej + 6 and st['rank_count_wide'] == P - st['count_rejected'] and st['rank_pair'] == st['count_rejected'], (n_rej, st)
+    for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p'):
+        assert np.array_equal(srt[k], got[k], equal_nan=True), k
+    H.assert_close_p(srt['t_p'], got['t_p'], 1e-9, 't_p')
+
+
 # general (64 lanes per group) and packed (two positions per wave) kernels, every capacity class
 @pytest.mark.parametrize('sizes', [(5, 64, 5, 64), (65, 128, 3, 30), (65, 128, 65, 128), (129, 256, 129, 256),
                                    (100, 128, 129, 220), (257, 512, 257, 512), (300, 512, 20, 256),

@@ -1189,7 +1189,8 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
     if (count_wide_rs_index(cls) >= 0) snprintf(buf, buflen, "rank_count_wide_kernel<%s> (event-like rows) | rank_hist_kernel<%d,64,%s,wide>", kd, 1 << std::min(c0, c1), dt);
     else snprintf(buf, buflen, "rank_hist_kernel<%d,64,%s,wide>", 1 << std::min(c0, c1), dt);
   } else {
-    if (count_wide_rs_index(cls) >= 0) snprintf(buf, buflen, "rank_count_wide_kernel<%s> (event-like rows) | rank_pair_kernel<%d,%d,%s>", kd, 1 << c0, 1 << c1, dt);
+    if (count_wide_rs_index(cls) == 5) snprintf(buf, buflen, "rank_count_value_kernel<%s> (event-like rows) | rank_pair_kernel<%d,%d,%s>", kd, 1 << c0, 1 << c1, dt);
+    else if (count_wide_rs_index(cls) >= 0) snprintf(buf, buflen, "rank_count_wide_kernel<%s> (event-like rows) | rank_pair_kernel<%d,%d,%s>", kd, 1 << c0, 1 << c1, dt);
     else snprintf(buf, buflen, "rank_pair_kernel<%d,%d,%s>", 1 << c0, 1 << c1, dt);
   }
   return NMOD_OK;

@@ -925,6 +925,11 @@ def test_value_domain_form_vs_oracle(nm, dtype):
     for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p'):
         assert np.array_equal(srt[k], got[k], equal_nan=True), k
     H.assert_close_p(srt['t_p'], got['t_p'], 1e-9, 't_p')
+    import ctypes as C
+    buf = C.create_string_buffer(160)
+    prm = L.make_params(method=L.METHOD_FISHER, nb=1)
+    assert L.load().nmod_describe_dispatch(C.byref(prm), 1500, 2048, buf, 160) == 0
+    assert buf.value == b'rank_count_value_kernel<f32> (event-like rows) | rank_pair_kernel<32,32,f32>', buf.value
 
 
 # general (64 lanes per group) and packed (two positions per wave) kernels, every capacity class

@@ -37,7 +37,10 @@ CONFIGS = [('ks_f32', []), ('all_f32', ['--config', 'alltests']), ('ks_i16', ['-
            ('ks_f32_spread200', ['--spread', '200']), ('ks_i16_spread200', ['--spread', '200', '--dtype', 'i16']),
            # round 6: event-like rows with 10 per mille outliers (mis-segmented reads over +-5 units)
            ('all_i16_spread200_outl1', ['--config', 'alltests', '--spread', '200', '--dtype', 'i16', '--outliers', '1']),
-           ('all_i16_spread200_outl10', ['--config', 'alltests', '--spread', '200', '--dtype', 'i16', '--outliers', '10'])]
+           ('all_i16_spread200_outl10', ['--config', 'alltests', '--spread', '200', '--dtype', 'i16', '--outliers', '10']),
+           # round 6: both groups above 1 024 samples (the value-domain counting form, rank_count_value.hpp)
+           ('all_i16_2048v2048_spread200', ['--config', 'alltests', '--n0', '2048', '--n1', '2048', '--positions', '450000', '--spread', '200', '--dtype', 'i16']),
+           ('all_i16_2048v2048_spread200_outl10', ['--config', 'alltests', '--n0', '2048', '--n1', '2048', '--positions', '450000', '--spread', '200', '--dtype', 'i16', '--outliers', '10'])]
 if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minutes per pass): only on request
     CONFIGS += [('ragged_all_f32', ['--config', 'ragged', '--all-tests', '--steps', '3', '--warmup', '1']),
                 ('ragged_all_f32_realties', ['--config', 'ragged', '--all-tests', '--ties', 'real', '--steps', '3', '--warmup', '1']),
@@ -57,7 +60,7 @@ if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minut
                 ('chr20_all_i16_spread200_outl10', ['--config', 'chr20', '--all-tests', '--dtype', 'i16', '--spread', '200', '--outliers', '10', '--steps', '3', '--warmup', '1'])]
 if len(sys.argv) > 2:                      # python3 tools/profile_round.py r3 ks_f32,all_f32
     CONFIGS = [c for c in CONFIGS if c[0] in sys.argv[2].split(',')]
-K1_NAMES = ('ks_rank_kernel', 'rank_hist_kernel', 'rank_pair_kernel', 'big_rank_kernel', 'big_hist_kernel', 'rank_count_kernel', 'rank_count_wide_kernel')
+K1_NAMES = ('ks_rank_kernel', 'rank_hist_kernel', 'rank_pair_kernel', 'big_rank_kernel', 'big_hist_kernel', 'rank_count_kernel', 'rank_count_wide_kernel', 'rank_count_value_kernel')
 PMC_GROUPS = [
     ['FETCH_SIZE'], ['WRITE_SIZE'],
     ['SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_VALU', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY'],

@@ -14,14 +14,20 @@
 // (both groups sorted by the 64-lane network: 230 registers, two waves per SIMD): 2.5e7 positions/s at 1 025 v 1 025, a twelfth of the
 // 1 024 v 1 024 rate (tools/coverage_sweep.sh).
 // Window and outliers as in rank_count_wide.hpp: 2 048 values around a robust centre (here: of the first 64 samples of either group);
-// a sample outside it goes to the tail list (<= kCwTail = 64, ballot + mbcnt); the samples below the window enter the scan as its
+// a sample outside it goes to the tail list (<= kCvTail = 128: two per lane; ballot + mbcnt); the samples below the window enter the scan as its
 // carry-in, and the listed samples are finished by an all-pairs pass in the same value-domain terms: a distinct tail value's copies
-// in either group, the samples below it.  A position with a float32 sample off the grid or more than 64 samples outside the window is
+// in either group, the samples below it.  A position with a float32 sample off the grid or more than 128 samples outside the window is
 // handed on to the class's sorting form (the work list rank_count_wide_kernel appends to).
 #pragma once
 #include "rank_count_wide.hpp"
 
 namespace nmod {
+
+// the tail list of this form: two listed samples per lane.  A position of this class holds 2 050 ... 4 096 samples, so 10 per mille
+// outliers are ~33 tail samples and 64 entries would hand every other position back
+constexpr int kCvTail = 128;
+constexpr int kCvWaveWords = kCwTableWords + kCvTail;          // 9 760 B per wave: four blocks of four waves per CU
+__host__ __device__ constexpr size_t rank_count_value_lds_bytes() { return (size_t)kWavesPerBlock * kCvWaveWords * 4; }
 
 template <int DTYPE>
 __device__ __forceinline__ void cv_segment(const RankStatsArgs& args, int32_t* work_list, int32_t* work_cnt, unsigned* tbl, int64_t count, int64_t loff,
@@ -107,7 +113,7 @@ __device__ __forceinline__ void cv_segment(const RankStatsArgs& args, int32_t* w
         const unsigned long long mk = __ballot(have && ok && !in);
         if (mk != 0ull) {                                  // (wave-uniform)
           const unsigned idx = (unsigned)listed + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-          if (have && ok && !in && idx < (unsigned)kCwTail) tail[idx] = ((unsigned)k & 0xffffu) | ((unsigned)g << 16);
+          if (have && ok && !in && idx < (unsigned)kCvTail) tail[idx] = ((unsigned)k & 0xffffu) | ((unsigned)g << 16);
           listed += (int)__popcll(mk);
         }
       };
@@ -127,7 +133,7 @@ __device__ __forceinline__ void cv_segment(const RankStatsArgs& args, int32_t* w
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const bool fit = __ballot(bad) == 0ull && listed <= kCwTail;
+    const bool fit = __ballot(bad) == 0ull && listed <= kCvTail;
 
     if (!fit) {                                            // (wave-uniform) left to the sorting form; the table is cleared for the next position
 #pragma unroll
@@ -138,14 +144,18 @@ __device__ __forceinline__ void cv_segment(const RankStatsArgs& args, int32_t* w
       continue;
     }
 
-    // ---- the listed samples: lane i < nt holds sample i
+    // ---- the listed samples: lane i holds samples i and i + 64
     const int nt = listed;
-    const bool tv = lane < nt;
-    const unsigned te = tv ? tail[lane] : 0u;
-    const int tk = (int)(short)(te & 0xffffu);
-    const unsigned tg = te >> 16;
-    const bool tlow = tk < base;
-    const unsigned low = (unsigned)__popcll(__ballot(tv && tlow && tg == 0u)) | ((unsigned)__popcll(__ballot(tv && tlow && tg != 0u)) << 16);
+    bool tv[2], tlow[2]; unsigned te[2]; int tk[2];
+    unsigned low = 0u;                                     // the listed samples below the window, A | B << 16: the scan's carry-in
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      tv[h] = lane + 64 * h < nt;
+      te[h] = tv[h] ? tail[lane + 64 * h] : 0u;
+      tk[h] = (int)(short)(te[h] & 0xffffu);
+      tlow[h] = tk[h] < base;
+      low += (unsigned)__popcll(__ballot(tv[h] && tlow[h] && (te[h] >> 16) == 0u)) | ((unsigned)__popcll(__ballot(tv[h] && tlow[h] && (te[h] >> 16) != 0u)) << 16);
+    }
 
     // ---- first walk over the lane's 32 values: A | B << 16 running, the integer KS maximum, the MWU sum, the cubes
     unsigned tot = 0u;
@@ -174,24 +184,30 @@ __device__ __forceinline__ void cv_segment(const RankStatsArgs& args, int32_t* w
       }
     }
     // the listed samples, every one against every other: the tail samples below its value and the copies of its value, by group
-    unsigned t_run = 0u, t_cand = 0u;                      // of a distinct tail value (its first copy's lane): A | B << 16 at the value, its candidate
-    bool t_first = false;
+    unsigned t_run[2] = {0u, 0u}, t_cand[2] = {0u, 0u};     // of a distinct tail value (its first copy's slot): A | B << 16 at the value, its candidate
+    bool t_first[2] = {false, false};
     if (nt > 0) {                                          // (wave-uniform)
-      unsigned lt = 0u, eq = 0u; int earlier = 0;
+      unsigned lt[2] = {0u, 0u}, eq[2] = {0u, 0u}; int earlier[2] = {0, 0};
 #pragma unroll 1
       for (int j = 0; j < nt; ++j) {
-        const unsigned wj = (unsigned)__builtin_amdgcn_readlane((int)te, j);
+        const unsigned wj = (unsigned)(j < 64 ? __builtin_amdgcn_readlane((int)te[0], j) : __builtin_amdgcn_readlane((int)te[1], j - 64));
         const int kj = (int)(short)(wj & 0xffffu);
         const unsigned one = (wj >> 16) ? 0x10000u : 1u;
-        lt += kj < tk ? one : 0u;
-        eq += kj == tk ? one : 0u;
-        earlier += (kj == tk && j < lane) ? 1 : 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          lt[h] += kj < tk[h] ? one : 0u;
+          eq[h] += kj == tk[h] ? one : 0u;
+          earlier[h] += (kj == tk[h] && j < lane + 64 * h) ? 1 : 0;
+        }
       }
-      t_first = tv && earlier == 0;
-      unsigned run = lt + (tlow ? 0u : inwin);             // (a value above the window: every sample inside it lies below)
-      const unsigned cand = value(t_first ? eq : 0u, run);
-      t_run = run; t_cand = t_first ? cand : 0u;
-      best = max(best, t_cand);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        t_first[h] = tv[h] && earlier[h] == 0;
+        unsigned run = lt[h] + (tlow[h] ? 0u : inwin);     // (a value above the window: every sample inside it lies below)
+        const unsigned cand = value(t_first[h] ? eq[h] : 0u, run);
+        t_run[h] = run; t_cand[h] = t_first[h] ? cand : 0u;
+        best = max(best, t_cand[h]);
+      }
     }
     best = wave_max_u32(best);
 
@@ -218,10 +234,13 @@ __device__ __forceinline__ void cv_segment(const RankStatsArgs& args, int32_t* w
           }
         }
       }
-      const bool hit = t_first && best != 0u && t_cand == best;
-      if (__ballot(hit) != 0ull) {
-        const double d = fabs(hist_exact_quot((int)(t_run & 0xffffu), dn0, r0) - hist_exact_quot((int)(t_run >> 16), dn1, r1));
-        dmax = hit ? fmax(dmax, d) : dmax;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool hit = t_first[h] && best != 0u && t_cand[h] == best;
+        if (__ballot(hit) != 0ull) {
+          const double d = fabs(hist_exact_quot((int)(t_run[h] & 0xffffu), dn0, r0) - hist_exact_quot((int)(t_run[h] >> 16), dn1, r1));
+          dmax = hit ? fmax(dmax, d) : dmax;
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -265,7 +284,7 @@ void rank_count_value_kernel(CntWideArgs cw) {
   const RankStatsArgs& args = cw.rs;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  unsigned* tbl = lds_cv + wave * kCwWaveWords;
+  unsigned* tbl = lds_cv + wave * kCvWaveWords;
   const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
   const int nseg = cw.segs[0];

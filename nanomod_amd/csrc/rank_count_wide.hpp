@@ -119,7 +119,9 @@ __global__ __launch_bounds__(1024) void cnt_wide_probe_kernel(CntWideProbeArgs a
         for (int i = lane; i < nn[g] && i <= kCwMaxQ; i += 64) { int k; if (!key_at(g, i, k)) ok = false; tails += ((unsigned)(k - base) >= 2048u) ? 1 : 0; }
       tails = (int)wave_sum_u64((unsigned long long)tails);
     }
-    const bool fit = __ballot(!ok) == 0ull && tails <= kCwTail / 2;      // (half the list: the probe's window is only close to the kernel's)
+    // (half the list: the probe's window is only close to the kernel's; the class whose groups both exceed 1 024 samples — max_s 2 048,
+    // rank_count_value.hpp — lists 128)
+    const bool fit = __ballot(!ok) == 0ull && tails <= (a.max_s[blockIdx.x] > 1024 ? 96 : kCwTail / 2);
     if (lane == 0) {
       atomicAdd(&looked, 1);
       if (q >= a.min_q) { atomicAdd(&seen, 1); if (fit) { atomicAdd(&fits, 1); atomicAdd(&far, tails); atomicAdd(&tot, m + q); } }

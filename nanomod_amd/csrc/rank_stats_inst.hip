@@ -274,18 +274,19 @@ hipError_t NMOD_CW_RUN_NAME(int num_cus, int64_t work_items, hipStream_t stream,
     CwFn vfn = (CwFn)rank_count_value_kernel<1>;
 #endif
     static std::atomic<int> vper_cu[64][2];
+    const size_t vlds = rank_count_value_lds_bytes();
     int vpc = cacheable ? vper_cu[dev][slot].load(std::memory_order_relaxed) : 0;
     if (vpc <= 0) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds);
       if (e != hipSuccess) return e;
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&vpc, vfn, 64 * kWavesPerBlock, lds);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&vpc, vfn, 64 * kWavesPerBlock, vlds);
       if (e != hipSuccess) return e;
       if (vpc < 1) return hipErrorLaunchOutOfResources;
       if (cacheable) vper_cu[dev][slot].store(vpc, std::memory_order_relaxed);
     }
     int64_t vblocks = std::min<int64_t>((work_items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)num_cus * vpc);
     if (vblocks < 1) vblocks = 1;
-    hipLaunchKernelGGL(vfn, dim3((unsigned)vblocks), dim3(64 * kWavesPerBlock), lds, stream, ca);
+    hipLaunchKernelGGL(vfn, dim3((unsigned)vblocks), dim3(64 * kWavesPerBlock), vlds, stream, ca);
   }
 #else
   (void)value_class;

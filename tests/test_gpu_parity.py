@@ -846,10 +846,10 @@ def _count_wide_outlier_checks(nm, dtype, s0, off0, s1, off1, rid, exp, kept, P)
 @pytest.mark.parametrize('dtype', ['i16', 'f32', 'f64'])
 def test_value_domain_form_vs_oracle(nm, dtype):
     """rank_count_value.hpp (round 6): all tests on event-like positions whose groups BOTH hold 1 025 ... 2 048 samples — counted by value,
-    every statistic from the table's values in order.  Clean positions, 1 / 2 equal / 64 / 65 samples outside the window (below,
+    every statistic from the table's values in order.  Clean positions, 1 / 2 equal / 64 / 65 / 128 / 129 samples outside the window (below,
     above, both; either group), ties inside and across the groups, groups a unit apart (D = 1), constant groups, a window clamped at
     the end of the int16 domain, random contamination at 1 / 10 per mille — every number against the oracle; the form keeps every
-    position with at most 64 outside samples (nmod_last_dispatch_stats) and the sorting form (rank_pair_kernel) gives the same integers"""
+    position with at most 128 outside samples (nmod_last_dispatch_stats) and the sorting form (rank_pair_kernel) gives the same integers"""
     import oracle_c
     L = nm._lib
     rng = np.random.default_rng(zlib.crc32(('value-domain' + dtype).encode()))
@@ -870,7 +870,7 @@ def test_value_domain_form_vs_oracle(nm, dtype):
         return int(rng.integers(1025, 2049))
     for _ in range(100):                                     # the bulk: the probe wants 7 of 8 sampled positions to fit
         lev = int(rng.integers(-3000, 3000)); add(ev(sz(), lev), ev(sz(), lev + int(rng.choice([0, 0, 60, -200]))))
-    for n_out in (1, 2, 64, 65):
+    for n_out in (1, 2, 64, 65, 128, 129):
         for side in (-1, 1, 0):
             for grp in (0, 1):
                 lev = int(rng.integers(-2500, 2500)); a, b = ev(sz(), lev), ev(sz(), lev)
@@ -879,7 +879,7 @@ def test_value_domain_form_vs_oracle(nm, dtype):
                 if n_out == 2:
                     far[1] = far[0]
                 tgt[64 + rng.choice(len(tgt) - 64, n_out, replace=False)] = far     # (not among the first 64: the centre's sample)
-                add(a, b, n_out <= 64)
+                add(a, b, n_out <= 128)
     lev = 0
     a, b = ev(2048, lev), ev(1025, lev); a[100:130] = 4000; b[200:202] = 4000; b[300:302] = -4000; add(a, b)      # one value 32 times over both groups, outside
     a, b = ev(1500, lev), ev(1500, lev); a[:] = 250; b[:] = 250; add(a, b)                                        # every sample equal: U / p NaN

@@ -227,7 +227,7 @@ typedef struct nmod_dispatch_stats {
   int64_t rank_hist_wide;   /* rank_hist_kernel, WIDE form: the smaller group sorted, the larger one streamed */
   int64_t rank_pair;        /* rank_pair_kernel: all tests, both groups beyond 256 samples and of different capacity */
   int64_t rank_count;       /* rank_count_kernel: the counting form of the 256-capacity class (event-like rows) */
-  int64_t rank_count_wide;  /* rank_count_wide_kernel: the counting form for any coverage (event-like rows) */
+  int64_t rank_count_wide;  /* rank_count_wide_kernel: the counting form for any coverage (event-like rows); rank_count_value_kernel's too */
   int64_t big;              /* big_rank_kernel / big_hist_kernel: a group beyond NMOD_MAX_GROUP */
   int64_t skipped;          /* no K1 form (NMOD_STATUS_EMPTY / NMOD_STATUS_TOO_LARGE) */
   int64_t count_tried;      /* positions of the classes whose probe let a counting form run */

@@ -24,6 +24,9 @@ def run_round(rng):
     lo0 = int(rng.integers(1, hi0 + 1)) if rng.random() < 0.5 else 1
     lo1 = int(rng.integers(1, hi1 + 1)) if rng.random() < 0.5 else 1
     mode = rng.choice(['cont', 'grid2', 'grid0', 'grid3', 'offt', 'gmix', 'i16', 'i16t', 'i16w', 'f64', 'f64near', 'nonf', 'evt', 'evt16', 'evt64', 'evto', 'evto16', 'evto64'])
+    if rng.random() < 0.08:                   # both groups above 1 024 samples, event-like: the value-domain counting form (rank_count_value.hpp)
+        lo0, lo1 = int(rng.integers(1000, 1400)), int(rng.integers(1000, 1400)); hi0, hi1 = int(rng.integers(lo0, 2049)), int(rng.integers(lo1, 2049))
+        mode = rng.choice(['evt', 'evt16', 'evt64', 'evto', 'evto16', 'evto64', 'i16t', 'grid2'])
     npos = int(rng.integers(1, (400 if max(hi0, hi1) <= 600 else 40) // (4 if mode.startswith('f64') or mode in ('evt64', 'evto64') else 1) + 1))
     n0 = rng.integers(lo0, hi0 + 1, npos); n1 = rng.integers(lo1, hi1 + 1, npos)
     off0 = np.zeros(npos + 1, np.int64); off0[1:] = np.cumsum(n0)

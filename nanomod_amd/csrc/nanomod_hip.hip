@@ -588,7 +588,7 @@ static int detect_device(const nmod_params* prm, int64_t npos, const void* sig0,
     hipError_t e = cw_prepare(classes);
     if (e != hipSuccess) return e;
     bool vc = false;                                          // (both groups above 1 024 samples: the value-domain form, all tests)
-    for (int c : classes) vc = vc || (all && count_wide_rs_index(c) == 5);
+    for (int c : classes) vc = vc || count_wide_rs_index(c) == 5;
     if (prm->dtype == NMOD_DTYPE_F32)
       return all ? launch_count_wide_run_d0_a1(num_cus, npos, stream, ra, cww, vc) : launch_count_wide_run_d0_a0(num_cus, npos, stream, ra, cww, vc);
     return all ? launch_count_wide_run_d1_a1(num_cus, npos, stream, ra, cww, vc) : launch_count_wide_run_d1_a0(num_cus, npos, stream, ra, cww, vc);
@@ -1171,7 +1171,9 @@ int nmod_describe_dispatch(const nmod_params* prm, int64_t n0, int64_t n1, char*
     const int cs = std::min(c0, c1);
     const int LG = ksonly_lanes_per_group(cs), R = (64 << cs) / LG;
     // (the larger group of at least kCwKsMinQ samples, the smaller one of at most 1 024: the counting form when the probe finds the class event-like)
-    if (cs <= 4 && std::max(n0, n1) >= kCwKsMinQ && std::max(n0, n1) <= 4095)
+    if (cs == 5 && std::max(n0, n1) <= 4095)
+      snprintf(buf, buflen, "rank_count_value_kernel<%s,ks> (event-like rows) | ks_rank_kernel<%d,%d,%s>", prm->dtype == NMOD_DTYPE_F64 ? "f32 keys" : dt, R, LG, dt);
+    else if (cs <= 4 && std::max(n0, n1) >= kCwKsMinQ && std::max(n0, n1) <= 4095)
       snprintf(buf, buflen, "rank_count_wide_kernel<%s,ks> (event-like rows) | ks_rank_kernel<%d,%d,%s>", prm->dtype == NMOD_DTYPE_F64 ? "f32 keys" : dt, R, LG, dt);
     else snprintf(buf, buflen, "ks_rank_kernel<%d,%d,%s>", R, LG, dt);
     return NMOD_OK;

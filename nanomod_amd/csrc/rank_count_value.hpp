@@ -1,4 +1,4 @@
-// K1, counting form in the VALUE domain (round 6) — all tests, event-like positions whose groups BOTH hold more than 1 024 samples
+// K1, counting form in the VALUE domain (round 6) — all tests or KS only, event-like positions whose groups BOTH hold more than 1 024 samples
 // (launch class (5, 5): 1 025 ... 2 048 v 1 025 ... 2 048).  rank_count_wide.hpp keeps the smaller group in registers (<= 16 per lane:
 // 1 024 samples) and looks every one of its samples up in the scanned table; here neither group fits, and neither has to: with a word
 // per VALUE of the window, a[v] | b[v] << 16 (the copies of value v in group 1 / group 2), every statistic is a sum or a maximum over
@@ -29,7 +29,7 @@ constexpr int kCvTail = 128;
 constexpr int kCvWaveWords = kCwTableWords + kCvTail;          // 9 760 B per wave: four blocks of four waves per CU
 __host__ __device__ constexpr size_t rank_count_value_lds_bytes() { return (size_t)kWavesPerBlock * kCvWaveWords * 4; }
 
-template <int DTYPE>
+template <int DTYPE, bool KS>
 __device__ __forceinline__ void cv_segment(const RankStatsArgs& args, int32_t* work_list, int32_t* work_cnt, unsigned* tbl, int64_t count, int64_t loff,
                                            const int32_t* list, int64_t start, int64_t wave_stride, int lane) {
   constexpr int RDT = (DTYPE == 1) ? 1 : 0;
@@ -98,7 +98,9 @@ __device__ __forceinline__ void cv_segment(const RankStatsArgs& args, int32_t* w
         int k;
         const bool ok = key_of(x, k);
         bad = bad || (have && !ok);
-        if constexpr (DTYPE == 1) {
+        if constexpr (KS) {
+          // (KS only: no moments)
+        } else if constexpr (DTYPE == 1) {
           const int d = have ? k - c : 0;
           const unsigned ud = (unsigned)d;
           is1[g] += d;
@@ -166,12 +168,17 @@ __device__ __forceinline__ void cv_segment(const RankStatsArgs& args, int32_t* w
     const int n0 = n[0], n1 = n[1];
     unsigned best = 0u, mws = 0u;
     unsigned long long cubes = 0ull;
+    [[maybe_unused]] bool any_tie = false;
     auto value = [&](unsigned w, unsigned& run) -> unsigned {                                     // the value's candidate |A n2 - B n1|; run: A | B << 16 at the value
       run += w;
       const int A = (int)(run & 0xffffu), B = (int)(run >> 16);
       const unsigned a = w & 0xffffu, b = w >> 16, t = a + b;
-      mws += a * (unsigned)(2 * B - (int)b);
-      cubes += (unsigned long long)(t * t) * (unsigned long long)t;
+      if constexpr (KS) {
+        any_tie = any_tie || t > 1u;                       // (float64 front end: do two float32 images tie anywhere?)
+      } else {
+        mws += a * (unsigned)(2 * B - (int)b);
+        cubes += (unsigned long long)(t * t) * (unsigned long long)t;
+      }
       const int x = A * n1 - B * n0;
       return (unsigned)(x < 0 ? -x : x);
     };
@@ -246,38 +253,47 @@ __device__ __forceinline__ void cv_segment(const RankStatsArgs& args, int32_t* w
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     dmax = wave_max_f64(dmax);
-    const unsigned MWS = cw_wave_sum_u32(mws);             // <= 2 n1 n2 < 2^26
-    const unsigned long long CUBES = wave_sum_u64(cubes);
-    const unsigned long long TIE = CUBES - (unsigned long long)(n0 + n1);
-    double mean[2] = {0.0, 0.0}, m2[2] = {0.0, 0.0};
+    if constexpr (KS) {
+      const bool tie = __ballot(any_tie) != 0ull;
+      if (lane == 0) {
+        args.ks_num[pos] = best;
+        args.ks_d_ref[pos] = dmax;
+        if (args.tied) args.tied[pos] = tie ? 1 : 0;
+      }
+    } else {
+      const unsigned MWS = cw_wave_sum_u32(mws);           // <= 2 n1 n2 < 2^26
+      const unsigned long long CUBES = wave_sum_u64(cubes);
+      const unsigned long long TIE = CUBES - (unsigned long long)(n0 + n1);
+      double mean[2] = {0.0, 0.0}, m2[2] = {0.0, 0.0};
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const double dn = g ? dn1 : dn0, rn = g ? r1 : r0;
-      if constexpr (DTYPE == 0) {
-        const double s1 = wave_sum_f64(fs1[g]), s2 = wave_sum_f64(fs2[g]);
-        mean[g] = (double)xf[g] + s1 * rn; m2[g] = s2 - s1 * s1 * rn;
-      } else if constexpr (DTYPE == 1) {
-        // exact integers: |S1| <= 4 095 * 1 024 + 64 * 2^16, S2 <= 4 095 * 2^20 + 64 * 2^32; n S2 and S1^2 below 2^53
-        const double S1 = (double)(int)cw_wave_sum_u32((unsigned)is1[g]), S2 = (double)wave_sum_u64(is2[g]);
-        mean[g] = ((double)c + S1 * rn) * 1e-3; m2[g] = __fma_rn(dn, S2, -S1 * S1) * rn * 1e-6;
+      for (int g = 0; g < 2; ++g) {
+        const double dn = g ? dn1 : dn0, rn = g ? r1 : r0;
+        if constexpr (DTYPE == 0) {
+          const double s1 = wave_sum_f64(fs1[g]), s2 = wave_sum_f64(fs2[g]);
+          mean[g] = (double)xf[g] + s1 * rn; m2[g] = s2 - s1 * s1 * rn;
+        } else if constexpr (DTYPE == 1) {
+          // exact integers: |S1| <= 4 095 * 1 024 + 128 * 2^16, S2 <= 4 095 * 2^20 + 128 * 2^32; n S2 and S1^2 below 2^53
+          const double S1 = (double)(int)cw_wave_sum_u32((unsigned)is1[g]), S2 = (double)wave_sum_u64(is2[g]);
+          mean[g] = ((double)c + S1 * rn) * 1e-3; m2[g] = __fma_rn(dn, S2, -S1 * S1) * rn * 1e-6;
+        }
       }
-    }
-    if (lane == 0) {
-      args.ks_num[pos] = best;
-      args.ks_d_ref[pos] = dmax;
-      args.mwu_s[pos] = (unsigned long long)MWS;
-      args.tie[pos] = TIE;
-      if constexpr (DTYPE != 2) {
-        double* mo = args.moments + pos * 4;
-        mo[0] = mean[0]; mo[1] = m2[0]; mo[2] = mean[1]; mo[3] = m2[1];
+      if (lane == 0) {
+        args.ks_num[pos] = best;
+        args.ks_d_ref[pos] = dmax;
+        args.mwu_s[pos] = (unsigned long long)MWS;
+        args.tie[pos] = TIE;
+        if constexpr (DTYPE != 2) {
+          double* mo = args.moments + pos * 4;
+          mo[0] = mean[0]; mo[1] = m2[0]; mo[2] = mean[1]; mo[3] = m2[1];
+        }
+        if (args.tied) args.tied[pos] = TIE != 0ull ? 1 : 0;
       }
-      if (args.tied) args.tied[pos] = TIE != 0ull ? 1 : 0;
     }
   }
 }
 
 // the classes of index 5 the probe accepted (today: one), laid end to end like rank_count_wide_kernel's
-template <int DTYPE>
+template <int DTYPE, bool KS>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 4)
 void rank_count_value_kernel(CntWideArgs cw) {
   extern __shared__ __attribute__((aligned(16))) unsigned lds_cv[];
@@ -298,7 +314,7 @@ void rank_count_value_kernel(CntWideArgs cw) {
     int64_t start = wave_global - rot;
     if (start < 0) start += nw;
     rot = (rot + count) % nw;
-    cv_segment<DTYPE>(args, cw.work_list, cw.work_meta + cls, tbl, count, loff, list, start, nw, lane);
+    cv_segment<DTYPE, KS>(args, cw.work_list, cw.work_meta + cls, tbl, count, loff, list, start, nw, lane);
   }
 }
 

@@ -134,7 +134,9 @@ __global__ __launch_bounds__(1024) void cnt_wide_probe_kernel(CntWideProbeArgs a
     // KS only, where the form's lead on clean rows is +24 % (int16) / +4 .. +24 % (float32) — level at ~8 / ~4 per mille.
     constexpr int kTailShare = KS ? (DTYPE == 1 ? 6 : 4) : 20;                // per mille of the sampled positions' samples
     // (KS-only: at least half of the class must be of the form's sizes — it walks the whole class list)
-    a.gate[cid] = (seen > 0 && fits * 8 >= seen * 7 && seen * 2 >= looked && (long long)far * 1000 <= (long long)tot * kTailShare) ? 1 : 0;
+    // (the class whose groups both exceed 1 024 samples: its sorting forms are 2 - 10 x behind the value-domain form at any share it can hold)
+    const int share = a.max_s[blockIdx.x] > 1024 ? 1000 : kTailShare;
+    a.gate[cid] = (seen > 0 && fits * 8 >= seen * 7 && seen * 2 >= looked && (long long)far * 1000 <= (long long)tot * share) ? 1 : 0;
     a.segs[1 + blockIdx.x] = cid;
     a.work_meta[cid] = 0; a.work_meta[kClassStride + cid] = a.pos_list ? a.class_meta[kClassStride + cid] : 0;
     if (blockIdx.x == 0) a.segs[0] = a.nclasses;

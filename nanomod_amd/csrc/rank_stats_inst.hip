@@ -265,13 +265,12 @@ hipError_t NMOD_CW_RUN_NAME(int num_cus, int64_t work_items, hipStream_t stream,
   int64_t blocks = std::min<int64_t>((work_items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)num_cus * pc);
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream, ca);
-#if NMOD_INST_ALL
   if (value_class) {
     // the class whose groups both hold more than 1 024 samples: the value-domain form (rank_count_value.hpp), a launch of its own
 #if NMOD_INST_DTYPE == 0
-    CwFn vfn = int_keys ? (CwFn)rank_count_value_kernel<2> : (CwFn)rank_count_value_kernel<0>;
+    CwFn vfn = int_keys ? (CwFn)rank_count_value_kernel<2, NMOD_INST_ALL == 0> : (CwFn)rank_count_value_kernel<0, NMOD_INST_ALL == 0>;
 #else
-    CwFn vfn = (CwFn)rank_count_value_kernel<1>;
+    CwFn vfn = (CwFn)rank_count_value_kernel<1, NMOD_INST_ALL == 0>;
 #endif
     static std::atomic<int> vper_cu[64][2];
     const size_t vlds = rank_count_value_lds_bytes();
@@ -288,9 +287,6 @@ hipError_t NMOD_CW_RUN_NAME(int num_cus, int64_t work_items, hipStream_t stream,
     if (vblocks < 1) vblocks = 1;
     hipLaunchKernelGGL(vfn, dim3((unsigned)vblocks), dim3(64 * kWavesPerBlock), vlds, stream, ca);
   }
-#else
-  (void)value_class;
-#endif
   return hipGetLastError();
 }
 

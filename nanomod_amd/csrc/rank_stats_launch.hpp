@@ -123,7 +123,7 @@ __host__ __device__ inline int count_wide_rs_index(int cls) {
   if (cls >= kWideBigBase && cls < kWideBigBase + kNumWideBig) return cls - kWideBigBase;           // smaller group in class 0..2
   if (cls >= kNumGeneralClasses && cls < kKsClassBase) { const int cm = cls - kNumGeneralClasses; return cm == 3 ? 3 : (cm == 4 ? 4 : -1); }
   if (cls >= 0 && cls < kNumGeneralClasses) { const int c0 = cls / kNumSizeClasses, c1 = cls % kNumSizeClasses, s = c0 < c1 ? c0 : c1; return s; }   // (5: both groups of 1 025 .. 2 048 samples — the value-domain form, rank_count_value.hpp)
-  if (cls >= kKsClassBase && cls < kKsClassBase + kNumKsClasses) { const int cs = cls - kKsClassBase; return cs <= 4 ? cs : -1; }   // KS-only: class of the smaller group
+  if (cls >= kKsClassBase && cls < kKsClassBase + kNumKsClasses) { const int cs = cls - kKsClassBase; return cs <= 5 ? cs : -1; }   // KS-only: class of the smaller group (5: both above 1 024, the value-domain form)
   return -1;
 }
 // KS-only mode: a class holds every position whose SMALLER group has the class's capacity; the form takes those whose larger group has at
@@ -136,7 +136,7 @@ hipError_t launch_count_wide_prepare_d1_a1(const int* classes, int nclasses, hip
 hipError_t launch_count_wide_prepare_d0_a0(const int* classes, int nclasses, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w);   // (KS-only)
 hipError_t launch_count_wide_prepare_d1_a0(const int* classes, int nclasses, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w);
 // then, before the classes' sorting launches: rank_count_wide_kernel over every class whose gate is set; it appends what it hands on
-// to the work lists itself (value_class: a class of index 5 is among them — all tests only —, rank_count_value_kernel follows in a launch of its own)
+// to the work lists itself (value_class: a class of index 5 is among them, rank_count_value_kernel follows in a launch of its own)
 hipError_t launch_count_wide_run_d0_a1(int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w, bool value_class);
 hipError_t launch_count_wide_run_d1_a1(int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w, bool value_class);
 hipError_t launch_count_wide_run_d0_a0(int num_cus, int64_t work_items, hipStream_t s, const RankStatsArgs& a, const CountWideWs& w, bool value_class);

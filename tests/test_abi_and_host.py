@@ -639,7 +639,7 @@ def test_dispatch_forms_keep_16_keys_per_lane():
         (1, 100, 100): b'ks_rank_kernel<16,8,f32>', (1, 200, 200): b'ks_rank_kernel<16,16,f32>',
         (1, 500, 500): b'rank_count_wide_kernel<f32,ks> (event-like rows) | ks_rank_kernel<16,32,f32>',
         (1, 1000, 1000): b'rank_count_wide_kernel<f32,ks> (event-like rows) | ks_rank_kernel<16,64,f32>',
-        (1, 2000, 2000): b'ks_rank_kernel<32,64,f32>', (1, 50, 1000): b'rank_count_wide_kernel<f32,ks> (event-like rows) | ks_rank_kernel<8,8,f32>',
+        (1, 2000, 2000): b'rank_count_value_kernel<f32,ks> (event-like rows) | ks_rank_kernel<32,64,f32>', (7, 2000, 1100): b'rank_count_value_kernel<f32> (event-like rows) | rank_pair_kernel<32,32,f32>', (1, 50, 1000): b'rank_count_wide_kernel<f32,ks> (event-like rows) | ks_rank_kernel<8,8,f32>',
         (1, 50, 300): b'ks_rank_kernel<8,8,f32>',
         (7, 200, 200): b'rank_count_kernel<f32> (event-like rows) | rank_hist_kernel<16,16,f32>', (7, 500, 500): b'rank_count_wide_kernel<f32> (event-like rows) | rank_hist_kernel<16,32,f32>',
         (7, 1000, 1000): b'rank_count_wide_kernel<f32> (event-like rows) | rank_hist_kernel<16,64,f32>',

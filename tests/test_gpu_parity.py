@@ -925,6 +925,17 @@ def test_value_domain_form_vs_oracle(nm, dtype):
     for k in ('mwu_u', 'mwu_p', 'ks_d', 'ks_p'):
         assert np.array_equal(srt[k], got[k], equal_nan=True), k
     H.assert_close_p(srt['t_p'], got['t_p'], 1e-9, 't_p')
+    # KS only: the form's instance without the sums; D bit for bit, the sorting form (ks_rank_kernel) gives the same
+    assert L.load().nmod_host_pipeline_config(1 << 30, 0, 0, 0) == 0
+    try:
+        ks = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=f64)
+        st_ks = L.last_dispatch_stats()
+        ks_srt = nm.detect_host(s0, off0, s1, off1, rid, nb=2, weights_dif=2.0, method='stouffer', tests=L.TEST_KS, flags=f64 | L.FLAG_NO_COUNTING)
+    finally:
+        assert L.load().nmod_host_pipeline_config(0, 0, 0, 0) == 0
+    assert np.array_equal(ks['ks_d'], exp['ks_d']) and np.array_equal(ks_srt['ks_d'], ks['ks_d']) and np.array_equal(ks_srt['ks_p'], ks['ks_p'])
+    H.assert_close_p(ks['ks_p'], exp['ks_p'], 1e-9, 'ks_p')
+    assert st_ks['count_tried'] == P and st_ks['rank_count_wide'] >= P - n_rej - 6 and st_ks['rank_count_wide'] + st_ks['ks_rank'] == P, st_ks
     import ctypes as C
     buf = C.create_string_buffer(160)
     prm = L.make_params(method=L.METHOD_FISHER, nb=1)

@@ -40,6 +40,7 @@ CONFIGS = [('ks_f32', []), ('all_f32', ['--config', 'alltests']), ('ks_i16', ['-
            ('all_i16_spread200_outl10', ['--config', 'alltests', '--spread', '200', '--dtype', 'i16', '--outliers', '10']),
            # round 6: both groups above 1 024 samples (the value-domain counting form, rank_count_value.hpp)
            ('all_i16_2048v2048_spread200', ['--config', 'alltests', '--n0', '2048', '--n1', '2048', '--positions', '450000', '--spread', '200', '--dtype', 'i16']),
+           ('ks_i16_2048v2048_spread200', ['--n0', '2048', '--n1', '2048', '--positions', '450000', '--spread', '200', '--dtype', 'i16']),
            ('all_i16_2048v2048_spread200_outl10', ['--config', 'alltests', '--n0', '2048', '--n1', '2048', '--positions', '450000', '--spread', '200', '--dtype', 'i16', '--outliers', '10'])]
 if os.environ.get('NMOD_PROFILE_RAGGED'):  # configs[4] (47 GB of samples, minutes per pass): only on request
     CONFIGS += [('ragged_all_f32', ['--config', 'ragged', '--all-tests', '--steps', '3', '--warmup', '1']),
